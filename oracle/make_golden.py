@@ -1,0 +1,121 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (under oracle/ref_shim.py).
+
+Build-container only (needs /root/reference).  Usage:  python -m oracle.make_golden
+
+Each vector file holds inputs and the reference's outputs only (data, no code):
+the low-rate clip, the prior noise drawn from the torch CPU generator, and the
+reference's cond-mel, sampled mel, vocoder waveform, final waveform and integer
+cutoff bin.  Weights are not stored: they are re-derived on any box from
+`flowhigh_amd.synth.make_state_dict(cfg, seed)`; a checksum of the state dict is
+stored to detect generator drift.
+"""
+import json
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from flowhigh_amd import synth  # noqa: E402
+from oracle import ref_shim     # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+
+CASES = {
+    # name: (cfg, seed, seconds, sr_in, ode method, steps, cfm_method, sigma, int16 input?)
+    "tiny_euler": (synth.TINY_CFG, 0, 0.25, 12000, "euler", 1, "basic_cfm", 0.0, False),
+    "alt_midpoint": (synth.ALT_CFG, 1, 0.2, 8000, "midpoint", 2, "basic_cfm", 0.0, False),
+    "tiny_adaptive_i16": (synth.TINY_CFG, 2, 0.15, 24000, "euler", 2, "independent_cfm_adaptive", 1e-4, True),
+    "tiny_ragged_16k": (synth.TINY_CFG, 3, 0.2017, 16000, "midpoint", 1, "basic_cfm", 0.0, False),
+}
+
+
+def sd_checksum(sd):
+    return float(sum(float(v.double().sum()) for v in sd.values()))
+
+
+def run_case(name, cfg, seed, seconds, sr_in, method, steps, cfm_method, sigma, as_int16):
+    d = tempfile.mkdtemp(prefix="fh_ckpt_")
+    sd = synth.write_checkpoint_dir(d, cfg, seed)
+    model = ref_shim.build_reference_model(d, method, cfm_method, sigma)
+    audio = synth.lowres_clip(seed, seconds, sr_in)
+    if as_int16:
+        audio = np.round(audio / np.abs(audio).max() * 20000.0).astype(np.int16)
+
+    # the reference's own pre-step, to learn T48 / N (flowhighsr.py:59-72)
+    import scipy.signal
+    a = audio.astype(np.float64) / 32768.0 if audio.max() > 1 else audio
+    cond48 = scipy.signal.resample_poly(a, 48000, sr_in)
+    cond48 = (cond48 / np.max(np.abs(cond48))).astype(np.float32)
+    n_frames = len(cond48) // 480
+    noise = synth.prior_noise(seed, n_frames)
+
+    # reference draws y0 / epsilon with torch.randn_like(cond) from the default CPU generator
+    def seeded(fn):
+        torch.manual_seed(2000 + seed)
+        return fn()
+
+    out = seeded(lambda: model.generate(audio, sr_in, 48000, steps))
+    cond_t = torch.from_numpy(cond48)[None]
+    cond_mel = model.flowhigh.audio_enc_dec.encode(cond_t)
+    kw = dict(std_2=1.0) if cfm_method == "independent_cfm_adaptive" else {}
+    mel = seeded(lambda: model.sample(cond=cond_t, time_steps=steps, cfm_method=cfm_method,
+                                      decode_to_audio=False, **kw))
+    wav = model.flowhigh.audio_enc_dec.decode(mel).squeeze(1)
+    cr = model.postproc.get_cutoff_index(model.postproc.stft(cond_t))
+    t_probe = torch.tensor(0.3)
+    pred = model.flowhigh.forward_with_cond_scale(noise, times=t_probe, cond=cond_mel)
+
+    np.savez_compressed(
+        OUT / f"{name}.npz",
+        cfg=json.dumps(cfg), seed=seed, sr_in=sr_in, method=method, steps=steps,
+        cfm_method=cfm_method, sigma=sigma, sd_checksum=sd_checksum(sd),
+        audio=audio, noise=noise.numpy(), cond48=cond48,
+        cond_mel=cond_mel.numpy(), mel=mel.numpy(), wav=wav.numpy(), out=out.numpy(),
+        cr=int(cr), flow_pred_t03=pred.numpy(),
+    )
+    print(f"{name}: T48={out.shape[-1]} N={n_frames} cr={cr} |wav|max={wav.abs().max():.4f} "
+          f"out[:3]={out[0, :3].tolist()}")
+
+
+def run_ops():
+    """Small operator-level vectors from the reference's own modules."""
+    fh = ref_shim.load_reference()
+    from flowhigh.models.bigvgan.alias_free_torch import Activation1d
+    from flowhigh.models.bigvgan import activations
+    from flowhigh.postprocessing import PostProcessing
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 6, 41, generator=g) * 1.5
+    alpha = torch.randn(6, generator=g) * 0.4
+    beta = torch.randn(6, generator=g) * 0.4
+    act = Activation1d(activation=activations.SnakeBeta(6, alpha_logscale=True))
+    act.act.alpha.data.copy_(alpha)
+    act.act.beta.data.copy_(beta)
+    y = act(x)
+    act2 = Activation1d(activation=activations.Snake(6, alpha_logscale=False))
+    act2.act.alpha.data.copy_(alpha.abs() + 0.5)
+    y2 = act2(x)
+    taps = act.upsample.filter.flatten()
+    pp = PostProcessing(0)
+    pred = torch.randn(1, 4999, generator=g) * 0.1
+    src = torch.randn(1, 4999, generator=g)
+    src = torch.from_numpy(__import__("scipy.signal").signal.resample_poly(src[0, ::4].numpy(), 4, 1))[None, :4999].float()
+    post = pp.post_processing(pred, src, 4999)
+    cr = pp.get_cutoff_index(pp.stft(src))
+    np.savez_compressed(OUT / "ops.npz", act_x=x.numpy(), act_alpha=alpha.numpy(), act_beta=beta.numpy(),
+                        act_snakebeta_log=y.detach().numpy(), act_snake_lin=y2.detach().numpy(),
+                        kaiser_taps=taps.numpy(), pp_pred=pred.numpy(), pp_src=src.numpy(),
+                        pp_out=post.numpy(), pp_cr=int(cr))
+    print("ops: kaiser taps", taps.tolist()[:6], "pp_cr", cr)
+
+
+if __name__ == "__main__":
+    OUT.mkdir(parents=True, exist_ok=True)
+    with torch.no_grad():
+        for name, args in CASES.items():
+            run_case(name, *args)
+        run_ops()
