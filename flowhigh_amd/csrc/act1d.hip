@@ -1,0 +1,135 @@
+// Fused anti-aliased periodic activation (HBM-bound kernel).
+//
+// Replaces Activation1d.forward of BigVGAN
+// (/root/reference/src/flowhigh/models/bigvgan/alias_free_torch/act.py:23-28):
+//   UpSample1d(2, 12)   resample.py:25-33   replicate pad 5|5, 2 * conv_transpose1d(stride 2), crop 15|15
+//   Snake / SnakeBeta   activations.py:48-59,107-120   x + inv_beta * sin^2(alpha x)
+//   DownSample1d(2, 12) filter.py:86-95     replicate pad 5|6, conv1d(stride 2)
+// The reference runs ~10 aten kernels and materialises the 2x-rate tensor three times per site;
+// here the 2x-rate samples only ever exist in LDS: one coalesced read and one coalesced write of
+// the [B, C, L] tensor per site.
+//
+// Closed forms (x index clamped to [0, L-1], z index clamped to [0, 2L-1]; f = 12 taps):
+//   z[2i]   = snake( 2 * sum_{q=-3..2} x[i+q] f_up[5-2q] )
+//   z[2i+1] = snake( 2 * sum_{q=-2..3} x[i+q] f_up[6-2q] )
+//   y[i]    = sum_{k=0..11} z[2i+k-5] f_dn[k]
+//
+// Block = 256 threads, one (group, batch, channel) row segment of TT = 506 outputs:
+//   phase 1: x[t0-6 .. t0+TT+5] -> LDS                       (518 floats, clamped indices)
+//   phase 2: each thread makes 2 (even, odd) pairs of z -> LDS   (512 pairs = i in [t0-3, t0+TT+2])
+//   phase 3: each thread makes <= 2 outputs from 7 ds_read_b64 each.
+#include "fh_common.h"
+
+namespace {
+
+constexpr int ACT_TT = 506;            // outputs per block
+constexpr int ACT_PAIRS = ACT_TT + 6;  // 512 z pairs
+constexpr int ACT_XW = ACT_TT + 12;    // 518 staged inputs
+
+__global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restrict__ groups,
+                                                    int batch, int channels, int len,
+                                                    int tiles_per_row) {
+  __shared__ float xs[ACT_XW + 2];
+  __shared__ __attribute__((aligned(8))) float zs[2 * ACT_PAIRS];
+
+  const int tile = blockIdx.x % tiles_per_row;
+  const int row = blockIdx.x / tiles_per_row;          // (g * batch + b) * channels + c
+  const int c = row % channels;
+  const int gb = row / channels;
+  const fh_act_group& G = groups[gb / batch];
+  const int b = gb % batch;
+  const size_t base = ((size_t)b * channels + c) * len;
+  const float* __restrict__ x = G.x + base;
+  float* __restrict__ y = G.y + base;
+  const float alpha = G.alpha[c];
+  const float inv_beta = G.inv_beta[c];
+  const int t0 = tile * ACT_TT;
+  const int tid = threadIdx.x;
+
+  // phase 1: clamped (replicate) input window
+  for (int j = tid; j < ACT_XW; j += 256) {
+    int t = t0 - 6 + j;
+    t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
+    xs[j] = x[t];
+  }
+  __syncthreads();
+
+  // phase 2: z pairs for i = t0 - 3 + p, p in [0, 512)
+  float fu[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) fu[k] = G.up_taps[k];
+  const int zlast = 2 * len - 1;
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int p = tid + 256 * rep;
+    const int i = t0 - 3 + p;
+    // x[i+q] is xs[p + q + 3]  (xs[j] <-> t0 - 6 + j)
+    float xv[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) xv[q] = xs[p + q];      // x[i-3 .. i+3]
+    float ze = 0.f, zo = 0.f;
+#pragma unroll
+    for (int q = -3; q <= 2; ++q) ze = fmaf(xv[q + 3], fu[5 - 2 * q], ze);
+#pragma unroll
+    for (int q = -2; q <= 3; ++q) zo = fmaf(xv[q + 3], fu[6 - 2 * q], zo);
+    ze *= 2.f;
+    zo *= 2.f;
+    float se = sinf(ze * alpha), so = sinf(zo * alpha);
+    ze = ze + inv_beta * (se * se);
+    zo = zo + inv_beta * (so * so);
+    // positions outside [0, 2L-1] are never used directly: phase 3 clamps its index instead
+    zs[2 * p] = ze;
+    zs[2 * p + 1] = zo;
+  }
+  __syncthreads();
+
+  // phase 3: y[i] = sum_k z[clamp(2i + k - 5)] f_dn[k];  z[m] is zs[m - 2 (t0 - 3)]
+  float fd[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) fd[k] = G.down_taps[k];
+  const int zbase = 2 * (t0 - 3);
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int o = tid + 256 * rep;
+    const int i = t0 + o;
+    if (o >= ACT_TT || i >= len) continue;
+    float acc = 0.f;
+    if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {
+      // interior: 14 contiguous values zs[2o .. 2o+13], taps use [1 .. 12]
+      const float2* zp = reinterpret_cast<const float2*>(zs + 2 * o);
+      float v[14];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        float2 t2 = zp[q];
+        v[2 * q] = t2.x;
+        v[2 * q + 1] = t2.y;
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc = fmaf(v[k + 1], fd[k], acc);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        int m = 2 * i + k - 5;
+        m = m < 0 ? 0 : (m > zlast ? zlast : m);
+        acc = fmaf(zs[m - zbase], fd[k], acc);
+      }
+    }
+    y[i] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int fh_sizeof_act_group(void) { return (int)sizeof(fh_act_group); }
+
+extern "C" int fh_act1d_grouped_f32(const fh_act_group* groups, int n_groups, int batch,
+                                    int channels, int len, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && channels > 0 && len > 0, "fh_act1d_grouped_f32: bad sizes");
+  const int tiles = fh_cdiv(len, ACT_TT);
+  const long long blocks = (long long)n_groups * batch * channels * tiles;
+  FH_CHECK_ARG(blocks < (1ll << 31), "fh_act1d_grouped_f32: grid too large");
+  hipLaunchKernelGGL(act1d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, groups,
+                     batch, channels, len, tiles);
+  FH_CHECK_LAUNCH("fh_act1d_grouped_f32");
+  return FH_OK;
+}

@@ -1,0 +1,47 @@
+// Shared helpers for the gfx950 kernels of libflowhigh_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/flowhigh_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void fh_set_error(const char* fmt, ...);
+
+#define FH_CHECK_ARG(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      fh_set_error(__VA_ARGS__);       \
+      return FH_E_ARG;                 \
+    }                                  \
+  } while (0)
+
+#define FH_CHECK_LAUNCH(name)                                            \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      fh_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return FH_E_LAUNCH;                                                \
+    }                                                                    \
+  } while (0)
+
+static inline int fh_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// 64-lane butterfly reductions (wave = 64 on gfx950).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}

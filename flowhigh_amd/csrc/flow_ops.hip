@@ -1,0 +1,150 @@
+// HBM-bound pointwise / reduction kernels of the FLowHigh transformer.
+//   fh_dwconv_gelu_res_f32 : ConvPositionEmbed + residual   models/transformer.py:16-46, flow.py:240
+//   fh_rmsnorm_f32         : AdaptiveRMSNorm / RMSNorm      models/transformer.py:49-88
+//   fh_qknorm_rope_f32     : MultiheadRMSNorm + RoPE        models/attend.py:144-151,179-184, pos_emb.py:53-59
+// All tensors are token-major [B*n, dim]; consecutive lanes touch consecutive features
+// (16-byte vector accesses), row reductions are 64-lane butterflies, no LDS.
+#include "fh_common.h"
+
+namespace {
+
+// thread = 4 consecutive channels; block = 64 threads (256 channels) x TOK tokens walked serially.
+constexpr int DW_TOK = 16;
+constexpr int DW_KMAX = 63;
+
+__global__ __launch_bounds__(256) void dwconv_gelu_res_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ y, int n, int dim,
+                                                              int ksz) {
+  // grid: (dim / 1024 * ..., token tiles, batch).  Each thread owns one channel quad.
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c4 >= dim) return;
+  const int b = blockIdx.z;
+  const int tok0 = blockIdx.y * DW_TOK;
+  const int half = ksz / 2;
+  const float* xb = x + (size_t)b * n * dim;
+  float* yb = y + (size_t)b * n * dim;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c4);
+  for (int t = tok0; t < tok0 + DW_TOK && t < n; ++t) {
+    f32x4 acc = bv;
+    for (int j = 0; j < ksz; ++j) {
+      int tt = t + j - half;
+      if (tt < 0 || tt >= n) continue;
+      f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (size_t)tt * dim + c4);
+      // w is [dim, ksz]: four channels -> four strided scalars (L1 resident)
+      acc[0] = fmaf(w[(c4 + 0) * ksz + j], xv[0], acc[0]);
+      acc[1] = fmaf(w[(c4 + 1) * ksz + j], xv[1], acc[1]);
+      acc[2] = fmaf(w[(c4 + 2) * ksz + j], xv[2], acc[2]);
+      acc[3] = fmaf(w[(c4 + 3) * ksz + j], xv[3], acc[3]);
+    }
+    f32x4 xc = *reinterpret_cast<const f32x4*>(xb + (size_t)t * dim + c4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = xc[e] + gelu_erf(acc[e]);
+    *reinterpret_cast<f32x4*>(yb + (size_t)t * dim + c4) = o;
+  }
+}
+
+// one wave per row; dim % 256 == 0, dim <= 4096
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      float* __restrict__ y, int rows, int dim,
+                                                      float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * dim;
+  float* yr = y + (size_t)row * dim;
+  f32x4 v[16];
+  const int nv = dim >> 8;   // float4 per lane
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i < nv) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+      ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+  }
+  ss = wave_sum(ss);
+  const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);     // F.normalize eps
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i < nv) {
+      const int c = (i * 64 + lane) * 4;
+      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      f32x4 o;
+      if (beta) {
+        f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[i][e] * inv * g[e] + bt[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[i][e] * inv * g[e];
+      }
+      *reinterpret_cast<f32x4*>(yr + c) = o;
+    }
+  }
+}
+
+// one wave per (token, head, q|k); lane = feature d of the 64-wide head
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(float* __restrict__ qkv,
+                                                          const float* __restrict__ gq,
+                                                          const float* __restrict__ gk,
+                                                          const float* __restrict__ cos_t,
+                                                          const float* __restrict__ sin_t, int n,
+                                                          int heads, long long total) {
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (item >= total) return;
+  const int which = (int)(item % 2);                 // 0 = q, 1 = k
+  const int h = (int)((item / 2) % heads);
+  const long long row = item / (2 * heads);          // b * n + pos
+  const int pos = (int)(row % n);
+  const int inner = heads * 64;
+  float* p = qkv + (size_t)row * (3 * inner) + which * inner + h * 64;
+  const float v = p[lane];
+  const float ss = wave_sum(v * v);
+  const float g = (which ? gk : gq)[h * 64 + lane];
+  // F.normalize(x) * gamma * scale  (attend.py:150): (x / max(||x||, eps)) * gamma * 8
+  const float t = v / fmaxf(sqrtf(ss), 1e-12f) * g * 8.0f;
+  const float other = __shfl_xor(t, 32, 64);         // rotate_half partner
+  const float rot = lane < 32 ? -other : other;      // cat(-x2, x1)
+  const float cs = cos_t[pos * 32 + (lane & 31)];
+  const float sn = sin_t[pos * 32 + (lane & 31)];
+  p[lane] = t * cs + rot * sn;
+}
+
+}  // namespace
+
+extern "C" int fh_dwconv_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
+                                      int batch, int n, int dim, int ksz, void* stream) {
+  FH_CHECK_ARG(x && w && bias && y && batch > 0 && n > 0, "fh_dwconv_gelu_res_f32: bad args");
+  FH_CHECK_ARG(dim % 4 == 0 && (ksz & 1) && ksz <= DW_KMAX, "fh_dwconv_gelu_res_f32: dim %d / ksz %d unsupported", dim, ksz);
+  dim3 grid(fh_cdiv(dim / 4, 256), fh_cdiv(n, DW_TOK), batch);
+  hipLaunchKernelGGL(dwconv_gelu_res_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, n,
+                     dim, ksz);
+  FH_CHECK_LAUNCH("fh_dwconv_gelu_res_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_rmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                              int rows, int dim, void* stream) {
+  FH_CHECK_ARG(x && gamma && y && rows > 0, "fh_rmsnorm_f32: bad args");
+  FH_CHECK_ARG(dim % 256 == 0 && dim <= 4096, "fh_rmsnorm_f32: dim %d unsupported", dim);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(fh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                     beta, y, rows, dim, sqrtf((float)dim));
+  FH_CHECK_LAUNCH("fh_rmsnorm_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_qknorm_rope_f32(float* qkv, const float* gq, const float* gk, const float* cos_t,
+                                  const float* sin_t, int batch, int n, int heads, void* stream) {
+  FH_CHECK_ARG(qkv && gq && gk && cos_t && sin_t && batch > 0 && n > 0 && heads > 0, "fh_qknorm_rope_f32: bad args");
+  const long long total = (long long)batch * n * heads * 2;
+  hipLaunchKernelGGL(qknorm_rope_kernel, dim3(fh_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, qkv,
+                     gq, gk, cos_t, sin_t, n, heads, total);
+  FH_CHECK_LAUNCH("fh_qknorm_rope_f32");
+  return FH_OK;
+}

@@ -1,0 +1,238 @@
+"""`FlowHighSR` -- drop-in host class for the reference's public API on MI355X.
+
+Mirrors /root/reference/src/flowhigh/flowhighsr.py:21-149 (`FlowHighSR`: ctor kwargs,
+`generate`, `set_cfm_method`, `from_local`, `from_pretrained`) and the inference half of
+/root/reference/src/flowhigh/cfm_superresolution.py:94-284 (`ConditionalFlowMatcherWrapper`:
+`sample`, `load`, `device`, `odeint_kwargs`, `sigma`, `cfm_method`).  torchdiffeq's fixed-grid
+euler / midpoint steppers (call site cfm:243) are restated in `_integrate`.
+
+Everything numerical runs in the HIP kernels of libflowhigh_hip.so; this file only moves
+tensors, picks shapes and sequences launches.  There is no CPU path: constructing the model on
+a non-CUDA device, or without the built library, raises.
+
+Extensions over the reference (all keyword-only, defaults keep reference behaviour):
+  generate(..., noise=, generator=)   explicit prior draw / CPU generator (parity hook)
+  generate_batch(clips, sr, ...)      B equal-length clips, every per-clip normalisation kept per clip
+  upsampling_method='hip'             resample_poly on the device instead of scipy on the host
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import hip
+from .flow import FlowNet
+from .frontend import LogMel, PostProcessor, Resampler
+from .tables import HOP
+from .vocoder import VOC, Vocoder, fold_weight_norm
+
+REPO_ID = "ResembleAI/FlowHigh"
+_CFM_METHODS = ("basic_cfm", "independent_cfm_adaptive", "independent_cfm_constant", "independent_cfm_mix")
+
+
+def reference_prior_draw(n_frames, n_mels=256, generator=None):
+    """What `torch.randn_like(cond)` yields in the reference on CPU (cfm_superresolution.py:220):
+    `cond` is the 'b d n -> b n d' *view* of the mel (melvoco.py:85); randn_like keeps its strides
+    and torch's CPU normal_() takes the scalar path for non-contiguous outputs, so both the fill
+    order and the values differ from a contiguous torch.randn(1, N, 256)."""
+    t = torch.empty_strided((1, n_frames, n_mels), (n_frames * n_mels, 1, n_frames))
+    return t.normal_(generator=generator)
+
+
+class FLowHigh:
+    """Device-resident weights of the vector-field net + its mel codec (the reference's
+    `FLowHigh` with `audio_enc_dec = MelVoco`, models/flow.py:54-142, models/melvoco.py:16-46)."""
+
+    def __init__(self, state_dict, vocoder_config, device="cuda", depth=2):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise hip.HipError(f"flowhigh_amd runs on MI355X only (got device '{device}'); there is no CPU path")
+        hip.lib()                                   # fail loudly if the extension is not built
+        if not torch.cuda.is_available():
+            raise hip.HipError("no HIP device visible")
+        self.device = device
+        self.vocoder_config = dict(vocoder_config)
+        missing = [k for k in ("flowhigh.to_embed.weight", VOC + "conv_pre.weight") if k not in state_dict]
+        if missing:
+            raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
+        self.net = FlowNet(state_dict, device, depth=depth)
+        self.vocoder = Vocoder(self.vocoder_config, state_dict, device)
+        self.logmel = LogMel(device)
+        self.n_mels = self.net.dim_in
+
+
+class FlowHighSR:
+    def __init__(
+        self,
+        flowhigh: FLowHigh,
+        sigma=0.,
+        ode_atol=1e-5,
+        ode_rtol=1e-5,
+        use_torchode=False,
+        cfm_method='basic_cfm',
+        torchdiffeq_ode_method='midpoint',   # [euler, midpoint]
+        torchode_method_klass=None,
+        cond_drop_prob=0.,
+        #
+        upsampling_method='scipy',
+    ):
+        if use_torchode:
+            raise NotImplementedError("the torchode adaptive solver path is out of scope (SURVEY.md 8a row 2)")
+        self.flowhigh = flowhigh
+        self.sigma = sigma
+        self.cond_drop_prob = cond_drop_prob
+        self.use_torchode = use_torchode
+        self.torchode_method_klass = torchode_method_klass
+        self.cfm_method = cfm_method
+        self.odeint_kwargs = dict(atol=ode_atol, rtol=ode_rtol, method=torchdiffeq_ode_method)
+        self.upsampling_method = upsampling_method
+        self.postproc = PostProcessor(flowhigh.device)
+        self.resampler = Resampler(flowhigh.device)
+
+    # ---- reference surface -----------------------------------------------------------------
+    @property
+    def device(self):
+        return self.flowhigh.device
+
+    def set_cfm_method(self, cfm_method):
+        self.cfm_method = cfm_method
+
+    def eval(self):
+        return self
+
+    def load(self, path, strict=True):
+        path = Path(path)
+        assert path.exists()
+        pkg = torch.load(str(path), map_location='cpu', weights_only=False)
+        self.flowhigh = FLowHigh(pkg['model'], self.flowhigh.vocoder_config, self.device)
+        return pkg
+
+    @classmethod
+    def from_local(cls, ckpt_dir, device='cuda', **kwargs) -> 'FlowHighSR':
+        ckpt_dir = Path(ckpt_dir)
+        cfg = json.loads((ckpt_dir / "bigvgan_48khz_256band.json").read_text())
+        gen = torch.load(ckpt_dir / "bigvgan_48khz_256band.pt", map_location='cpu', weights_only=False)['generator']
+        sd = {VOC + k: v for k, v in fold_weight_norm(gen).items()}            # init_vocoder.py:13-17
+        model = torch.load(ckpt_dir / "FLowHigh_basic_400k.pt", map_location='cpu', weights_only=False)['model']
+        missing = [k for k in sd if k not in model]
+        if missing:       # load_state_dict(strict=True), flowhighsr.py:135
+            raise RuntimeError(f"Missing key(s) in state_dict: {missing[:8]}{' ...' if len(missing) > 8 else ''}")
+        sd.update(model)                                                       # wrapper checkpoint wins
+        dev = device if torch.device(device).type == 'cuda' else 'cuda'        # the reference always .cuda()s
+        return cls(flowhigh=FLowHigh(sd, cfg, dev), **kwargs)
+
+    @classmethod
+    def from_pretrained(cls, device='cuda', **kwargs) -> 'FlowHighSR':
+        from huggingface_hub import hf_hub_download
+        for fpath in ["FLowHigh_basic_400k.json", "bigvgan_48khz_256band.json",
+                      "FLowHigh_basic_400k.pt", "bigvgan_48khz_256band.pt"]:
+            local_path = hf_hub_download(repo_id=REPO_ID, filename=fpath)
+        return cls.from_local(Path(local_path).parent, device, **kwargs)
+
+    # ---- host pre-step (flowhighsr.py:59-86) -----------------------------------------------------
+    def _prepare_cond(self, clips, sr, target_sampling_rate):
+        """list of 1-D arrays (equal length) -> cond [B, T48] float32 on device, peak-normalised per clip."""
+        if target_sampling_rate != 48000:
+            raise NotImplementedError("the mel codec is fixed at 48 kHz")
+        prepared = []
+        for audio in clips:
+            if isinstance(audio, torch.Tensor):
+                audio = audio.detach().cpu().numpy()
+            audio = np.asarray(audio)
+            if len(audio.shape) == 2:
+                audio = audio.squeeze(0)
+            if audio.max() > 1:
+                audio = audio / 32768.0
+            prepared.append(audio)
+        if self.upsampling_method == 'scipy':
+            import scipy.signal
+            conds = []
+            for audio in prepared:
+                cond = scipy.signal.resample_poly(audio, target_sampling_rate, sr)
+                cond = cond / np.max(np.abs(cond))
+                conds.append(torch.tensor(cond).float())
+            return torch.stack(conds).to(self.device)
+        if self.upsampling_method == 'hip':
+            x = torch.from_numpy(np.stack([a.astype(np.float32) for a in prepared])).to(self.device)
+            return self.resampler(x, sr, target_sampling_rate)
+        raise UnboundLocalError(f"cond: unsupported upsampling_method '{self.upsampling_method}'")
+
+    # ---- sampler (cfm_superresolution.py:162-284) ------------------------------------------------
+    def _draw_noise(self, batch, n_frames, generator):
+        n_mels = self.flowhigh.n_mels
+        return torch.cat([reference_prior_draw(n_frames, n_mels, generator) for _ in range(batch)], 0)
+
+    def _integrate(self, y0, cond_mel, batch, n, time_steps):
+        """Fixed-grid euler / midpoint (torchdiffeq semantics); y0, cond_mel [B*n, n_mels] on device."""
+        net = self.flowhigh.net
+        method = self.odeint_kwargs['method']
+        if method not in ('euler', 'midpoint'):
+            raise NotImplementedError(f"ode method '{method}'")
+        net.set_cond(cond_mel, batch, n)
+        t = torch.linspace(0, 1, time_steps + 1)
+        y = y0
+        bufs = [torch.empty_like(y0), torch.empty_like(y0), torch.empty_like(y0)]
+        for i in range(time_steps):
+            t0, dt = t[i], t[i + 1] - t[i]
+            out = bufs[i % 2]
+            if method == 'euler':
+                net.forward(y, float(t0), out, batch, n, alpha=float(dt), res=y)
+            else:
+                half = 0.5 * dt
+                net.forward(y, float(t0), bufs[2], batch, n, alpha=float(half), res=y)
+                net.forward(bufs[2], float(t0 + half), out, batch, n, alpha=float(dt), res=y)
+            y = out
+        return y
+
+    @torch.no_grad()
+    def sample(self, *, cond=None, cond_mask=None, time_steps=4, cond_scale=1., decode_to_audio=True,
+               std_1=None, std_2=None, mel_pp=False, cfm_method=None, noise=None, generator=None):
+        if cfm_method not in _CFM_METHODS:
+            cfm_method = self.cfm_method
+        if cfm_method in _CFM_METHODS[1:]:
+            if std_1 is None or std_2 is None:          # cfm:180-183 (resets BOTH)
+                std_1, std_2 = 1.0, self.sigma
+        if cond_scale != 1. or mel_pp or cond_mask is not None or cfm_method == 'independent_cfm_mix':
+            raise NotImplementedError("cond_scale != 1, mel_pp, masks and independent_cfm_mix: SURVEY.md 8f rank 2")
+        fh = self.flowhigh
+        cond = cond.to(self.device, torch.float32)
+        if cond.ndim == 2 or (cond.ndim == 3 and cond.shape[1] == 1):      # raw audio (cfm:91-92,185)
+            if cond.ndim == 3:
+                cond = cond.squeeze(1)
+            batch = cond.shape[0]
+            cond_mel = fh.logmel(cond)
+            n = cond_mel.shape[0] // batch
+        else:
+            batch, n, _ = cond.shape
+            cond_mel = cond.reshape(batch * n, -1).contiguous()
+        if noise is None:
+            noise = self._draw_noise(batch, n, generator)
+        noise = noise.to(self.device, torch.float32).reshape(batch * n, -1).contiguous()
+        if cfm_method == 'basic_cfm':
+            y0 = noise
+        else:
+            y0 = cond_mel * std_1 + noise * std_2
+        mel = self._integrate(y0, cond_mel, batch, n, time_steps)
+        mel = mel.view(batch, n, -1)
+        if not decode_to_audio:
+            return mel
+        return fh.vocoder.forward(mel).unsqueeze(1)           # [B, 1, hop * n]
+
+    @torch.no_grad()
+    def generate_batch(self, clips, sr, target_sampling_rate=48000, timestep=1, *, noise=None,
+                       generator=None, return_stages=False):
+        cond = self._prepare_cond(list(clips), sr, target_sampling_rate)
+        kw = dict(std_2=1.) if self.cfm_method == 'independent_cfm_adaptive' else {}
+        HR_audio = self.sample(cond=cond, time_steps=timestep, cfm_method=self.cfm_method, noise=noise,
+                               generator=generator, **kw)
+        HR_audio = HR_audio.squeeze(1)
+        out = self.postproc(HR_audio, cond, cond.size(-1), return_cr=return_stages)
+        if return_stages:
+            return out[0], dict(cond=cond, wav=HR_audio, cr=out[1])
+        return out
+
+    @torch.no_grad()
+    def generate(self, audio, sr: int, target_sampling_rate=48000, timestep=1, *, noise=None, generator=None):
+        """One clip, reference contract: returns float32 [1, T48] on the model device."""
+        return self.generate_batch([audio], sr, target_sampling_rate, timestep, noise=noise, generator=generator)

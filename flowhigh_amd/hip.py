@@ -1,0 +1,142 @@
+"""ctypes binding of libflowhigh_hip.so (the C ABI declared in include/flowhigh_hip.h).
+
+There is NO fallback: if the library is missing or a call fails this module raises.  Device
+pointers are passed as integers (`tensor.data_ptr()`), the stream as
+`torch.cuda.current_stream().cuda_stream`.
+"""
+import ctypes as C
+from pathlib import Path
+
+import torch
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libflowhigh_hip.so"
+
+CONV_MAX_TAPS = 16
+CONV_MAX_SEG = 3
+CONV_MAX_HALO = 64
+
+EPI_LINEAR, EPI_GEGLU, EPI_MAG, EPI_LOGCLAMP = 0, 1, 2, 3
+
+
+class ConvSeg(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("cin", C.c_int32), ("ntaps", C.c_int32),
+                ("off_min", C.c_int32), ("off_max", C.c_int32), ("tap_off", C.c_int32 * CONV_MAX_TAPS)]
+
+
+class ConvGroup(C.Structure):
+    _fields_ = [("seg", ConvSeg * CONV_MAX_SEG), ("bias", C.c_void_p), ("res", C.c_void_p * CONV_MAX_SEG),
+                ("out", C.c_void_p), ("nseg", C.c_int32), ("nres", C.c_int32), ("cout", C.c_int32),
+                ("cout_pad", C.c_int32), ("lin", C.c_int32), ("lout", C.c_int32), ("n_len", C.c_int32),
+                ("out_stride", C.c_int32), ("out_phase", C.c_int32), ("scale", C.c_float)]
+
+
+class ActGroup(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("alpha", C.c_void_p), ("inv_beta", C.c_void_p),
+                ("up_taps", C.c_float * 12), ("down_taps", C.c_float * 12)]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_SIGS = {
+    "fh_abi_version": [],
+    "fh_sizeof_conv_group": [],
+    "fh_sizeof_act_group": [],
+    "fh_conv_tile_m": [_I],
+    "fh_conv_tile_n": [_I],
+    "fh_conv_grouped_f32": [_P, _I, _I, _I, _I, _I, _P],
+    "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
+    "fh_gemm_f32": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P],
+    "fh_gemv_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "fh_time_fourier_f32": [_P, _F, _P, _I, _P],
+    "fh_dwconv_gelu_res_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "fh_rmsnorm_f32": [_P, _P, _P, _P, _I, _I, _P],
+    "fh_qknorm_rope_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "fh_attention_f32": [_P, _P, _I, _I, _I, _F, _P],
+    "fh_frame_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fh_spec_energy_f32": [_P, _P, _I, _I, _P],
+    "fh_cutoff_index_f32": [_P, _P, _I, _F, _P],
+    "fh_spec_splice_f32": [_P, _P, _P, _P, _I, _I, _P],
+    "fh_istft_ola_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "fh_peak_scale_f32": [_P, _P, _I, _I, _F, _P],
+    "fh_peak_abs_f32": [_P, _P, _I, _I, _P],
+    "fh_resample_poly_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+}
+EXPORTS = sorted(_SIGS) + ["fh_last_error"]
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises HipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HipError(f"{LIB_PATH} is missing: build it with `python -m flowhigh_amd.build` "
+                       "(there is no CPU fallback)")
+    L = C.CDLL(str(LIB_PATH))
+    for name, args in _SIGS.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.fh_last_error.argtypes = []
+    L.fh_last_error.restype = C.c_char_p
+    if L.fh_abi_version() != 1:
+        raise HipError("libflowhigh_hip.so ABI version mismatch")
+    if L.fh_sizeof_conv_group() != C.sizeof(ConvGroup) or L.fh_sizeof_act_group() != C.sizeof(ActGroup):
+        raise HipError("descriptor struct layout mismatch between hip.py and flowhigh_hip.h")
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise HipError(f"{what}: rc={rc}: {lib().fh_last_error().decode()}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def to_device_struct_array(structs, device):
+    """ctypes Structure list -> device uint8 tensor holding the packed array."""
+    if not structs:
+        raise ValueError("empty descriptor list")
+    arr = (type(structs[0]) * len(structs))(*structs)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+# ---- thin typed wrappers (all enqueue-only) --------------------------------------------------
+def _f32c(t, name):
+    if t is None:
+        return
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise HipError(f"{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} "
+                       f"contiguous={t.is_contiguous()} device={t.device}")
+
+
+def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, alpha=1.0, epilogue=EPI_LINEAR, lda=None,
+         ldc=None, ldr=None):
+    """C[M, N or N/2] = epi(A[M,K] @ W[N,K]^T).  W must have rows padded to a multiple of 128."""
+    for t, n in ((A, "A"), (W, "W"), (C_out, "C"), (bias, "bias"), (R, "R")):
+        _f32c(t, n)
+    if W.shape[0] % 128 or W.shape[1] != K:
+        raise HipError(f"gemm: W must be [n_pad % 128 == 0, K], got {tuple(W.shape)} K={K}")
+    lda = lda if lda is not None else A.shape[-1]
+    out_w = N // 2 if epilogue in (EPI_GEGLU, EPI_MAG) else N
+    ldc = ldc if ldc is not None else C_out.shape[-1]
+    ldr = ldr if ldr is not None else (R.shape[-1] if R is not None else 0)
+    if ldc < out_w:
+        raise HipError("gemm: output row too short")
+    check(lib().fh_gemm_f32(ptr(A), lda, ptr(W), ptr(bias), ptr(R), ldr, ptr(C_out), ldc, M, N, K,
+                            float(alpha), epilogue, stream()), "fh_gemm_f32")
+    return C_out

@@ -35,7 +35,7 @@ SYNTH_CFG = {
 }
 
 # Reduced configs for parity tests (same code path, seconds on CPU).
-TINY_CFG = dict(SYNTH_CFG, upsample_initial_channel=256)
+TINY_CFG = dict(SYNTH_CFG, upsample_initial_channel=512)
 ALT_CFG = dict(SYNTH_CFG, upsample_rates=[8, 6, 5, 2], upsample_kernel_sizes=[16, 12, 11, 4],
                upsample_initial_channel=128, resblock_kernel_sizes=[3, 5],
                resblock_dilation_sizes=[[1, 2, 4], [1, 3, 5]], activation="snake",
@@ -214,15 +214,6 @@ def lowres_clip(i, seconds, sr_in):
 
 def prior_noise(i, n_frames, n_mels=256):
     """Prior draw for clip i from the torch CPU generator (parity contract)."""
+    from .flowhighsr import reference_prior_draw
     g = torch.Generator().manual_seed(2000 + i)
     return reference_prior_draw(n_frames, n_mels, g)
-
-
-def reference_prior_draw(n_frames, n_mels=256, generator=None):
-    """What `torch.randn_like(cond)` returns in the reference (cfm_superresolution.py:220) when it
-    runs on CPU: `cond` there is the 'b d n -> b n d' *view* of the mel (melvoco.py:85), randn_like
-    keeps its strides, and torch's CPU normal_() takes its scalar (non-vectorised) path for
-    non-contiguous outputs -- so both the fill order and the values differ from a contiguous
-    `torch.randn(1, N, 256)`.  Reproduced by drawing into a tensor with the same strides."""
-    t = torch.empty_strided((1, n_frames, n_mels), (n_frames * n_mels, 1, n_frames))
-    return t.normal_(generator=generator)

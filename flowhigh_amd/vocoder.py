@@ -1,0 +1,316 @@
+"""BigVGAN generator on the HIP kernels: weight packing, launch plan, forward.
+
+Mirrors /root/reference/src/flowhigh/models/bigvgan/models.py:124-194 (BigVGAN, AMPBlock1 :21-78)
+and init_vocoder.py:8-23 (JSON config -> generator), parametric in the JSON keys
+`upsample_rates, upsample_kernel_sizes, upsample_initial_channel, num_mels, resblock,
+resblock_kernel_sizes, resblock_dilation_sizes, activation, snake_logscale`.
+
+Launch structure per stage (13 launches instead of the reference's ~1700 aten calls):
+  1 x grouped conv : ConvTranspose1d as `u` output-phase groups (each a 2-3 tap conv)
+  for m in 0..2    : act (nk groups) -> conv1 dilated (nk groups) -> act (nk groups) ->
+                     conv2 (+ residual; nk groups)   [models.py:63-72]
+  the last conv2 of the stage is ONE group with nk K-segments: it sums the three AMP blocks in
+  the accumulator and applies "/ num_kernels" (models.py:181-187) in its epilogue.
+"""
+import json
+import math
+
+import torch
+
+from . import hip
+
+VOC = "flowhigh.audio_enc_dec.vocoder."
+_TILE_PREF = [(0, 128), (1, 192), (2, 96), (3, 64), (4, 32)]
+
+
+def pick_tile_cfg(cout):
+    best = None
+    for cfg, bm in _TILE_PREF:
+        cost = -(-cout // bm) * bm
+        if best is None or cost < best[0]:
+            best = (cost, cfg, bm)
+    return best[1], best[2], best[0]
+
+
+def fold_weight_norm(sd):
+    """weight_g / weight_v -> weight (remove_weight_norm, bigvgan/models.py:196-204;
+    norm over all dims but 0, for Conv1d and ConvTranspose1d alike)."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("weight_g"):
+            base = k[:-len("weight_g")]
+            vv = sd[base + "weight_v"]
+            norm = vv.flatten(1).norm(dim=1).view(-1, *([1] * (vv.ndim - 1)))
+            out[base + "weight"] = v * vv / norm
+        elif k.endswith("weight_v"):
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+def pack_conv_weight(w, cout_pad):
+    """Conv1d weight [co, ci, k] -> [ci/8, k, cout_pad, 8] (zero padded rows)."""
+    co, ci, k = w.shape
+    if ci % 8:
+        raise ValueError(f"input channels {ci} must be a multiple of 8")
+    p = torch.zeros(ci // 8, k, cout_pad, 8, dtype=torch.float32)
+    p[:, :, :co, :] = w.float().reshape(co, ci // 8, 8, k).permute(1, 3, 0, 2)
+    return p.contiguous()
+
+
+def transposed_conv_phases(k, u):
+    """ConvTranspose1d(k, stride u, padding (k-u)//2) as u output phases:
+    out[co, u*n + r] = sum over taps j with (r + p - j) % u == 0 of x[ci, n + (r + p - j)//u] w[ci, co, j]."""
+    p = (k - u) // 2
+    phases = []
+    for r in range(u):
+        taps = [(j, (r + p - j) // u) for j in range(k) if (r + p - j) % u == 0]
+        phases.append(taps)
+    return phases
+
+
+def make_conv_seg(x, w, cin, offs):
+    s = hip.ConvSeg()
+    s.x, s.w, s.cin, s.ntaps = hip.ptr(x), hip.ptr(w), cin, len(offs)
+    if len(offs) > hip.CONV_MAX_TAPS or max(offs) - min(offs) > hip.CONV_MAX_HALO:
+        raise NotImplementedError(f"tap list {offs} exceeds kernel limits")
+    s.off_min, s.off_max = min(offs), max(offs)
+    for i, o in enumerate(offs):
+        s.tap_off[i] = o
+    return s
+
+def make_conv_group(segs, bias, res, out, cout, cpad, lin, lout, n_len, stride=1, phase=0, scale=1.0):
+    g = hip.ConvGroup()
+    for i, s in enumerate(segs):
+        g.seg[i] = s
+    g.nseg, g.nres = len(segs), len(res)
+    g.bias = hip.ptr(bias)
+    for i, r in enumerate(res):
+        g.res[i] = hip.ptr(r)
+    g.out = hip.ptr(out)
+    g.cout, g.cout_pad, g.lin, g.lout, g.n_len = cout, cpad, lin, lout, n_len
+    g.out_stride, g.out_phase, g.scale = stride, phase, scale
+    return g
+
+def make_act_group(x, y, p):
+    g = hip.ActGroup()
+    g.x, g.y, g.alpha, g.inv_beta = hip.ptr(x), hip.ptr(y), hip.ptr(p["alpha"]), hip.ptr(p["inv_beta"])
+    for i in range(12):
+        g.up_taps[i] = p["up"][i]
+        g.down_taps[i] = p["down"][i]
+    return g
+
+
+
+def conv_grouped(groups, batch, cout_pad, n_len, tile_cfg, device):
+    """Upload descriptors and enqueue one grouped conv launch (test / one-off use)."""
+    d = hip.to_device_struct_array(groups, device)
+    hip.check(hip.lib().fh_conv_grouped_f32(d.data_ptr(), len(groups), batch, cout_pad, n_len, tile_cfg,
+                                            hip.stream()), "fh_conv_grouped_f32")
+    return d
+
+
+def act1d_grouped(groups, batch, channels, length, device):
+    d = hip.to_device_struct_array(groups, device)
+    hip.check(hip.lib().fh_act1d_grouped_f32(d.data_ptr(), len(groups), batch, channels, length, hip.stream()),
+              "fh_act1d_grouped_f32")
+    return d
+
+
+class Vocoder:
+    """Device-resident BigVGAN weights + per-shape launch plans."""
+
+    def __init__(self, cfg, sd, device, prefix=VOC):
+        if isinstance(cfg, (str, bytes)) or hasattr(cfg, "read_text"):
+            cfg = json.loads(open(cfg).read())
+        self.cfg = dict(cfg)
+        if str(cfg["resblock"]) != "1":
+            raise NotImplementedError("only resblock '1' (AMPBlock1) is implemented")
+        if cfg["activation"] not in ("snake", "snakebeta"):
+            raise NotImplementedError(cfg["activation"])
+        self.device = torch.device(device)
+        self.rates = list(cfg["upsample_rates"])
+        self.up_k = list(cfg["upsample_kernel_sizes"])
+        self.c0 = int(cfg["upsample_initial_channel"])
+        self.num_mels = int(cfg["num_mels"])
+        self.ks = list(cfg["resblock_kernel_sizes"])
+        self.dil = [list(d) for d in cfg["resblock_dilation_sizes"]]
+        self.nk = len(self.ks)
+        if self.nk > hip.CONV_MAX_SEG:
+            raise NotImplementedError("more than 3 resblock kernel sizes")
+        self.nm = len(self.dil[0])
+        if any(len(d) != self.nm for d in self.dil):
+            raise NotImplementedError("ragged dilation lists")
+        self.hop = math.prod(self.rates)
+        self.chans = [self.c0 // (2 ** (i + 1)) for i in range(len(self.rates))]
+        for c in [self.num_mels, self.c0] + self.chans:
+            if c % 8:
+                raise NotImplementedError(f"channel count {c} is not a multiple of 8")
+        for u, k in zip(self.rates, self.up_k):
+            if (k - u) % 2:
+                raise NotImplementedError("upsample kernel - stride must be even")
+        g = lambda name: sd[prefix + name].detach().float().cpu()
+        dev = self.device
+        is_beta = cfg["activation"] == "snakebeta"
+        logscale = bool(cfg.get("snake_logscale", False))
+
+        def act_params(name):
+            a = g(name + "act.alpha")
+            b = g(name + "act.beta") if is_beta else a
+            if logscale:
+                a, b = torch.exp(a), torch.exp(b)
+            inv_b = 1.0 / (b + 1e-9)                 # activations.py:57,118
+            return dict(alpha=a.contiguous().to(dev), inv_beta=inv_b.contiguous().to(dev),
+                        up=g(name + "upsample.filter").flatten().tolist(),
+                        down=g(name + "downsample.lowpass.filter").flatten().tolist())
+
+        # conv_pre
+        self.pre_cfg, _, self.pre_cpad = pick_tile_cfg(self.c0)
+        self.pre_w = pack_conv_weight(g("conv_pre.weight"), self.pre_cpad).to(dev)
+        self.pre_b = g("conv_pre.bias").to(dev)
+        self.stages = []
+        for i, (u, k) in enumerate(zip(self.rates, self.up_k)):
+            c = self.chans[i]
+            tcfg, bm, cpad = pick_tile_cfg(c)
+            st = dict(c=c, cin=self.c0 // (2 ** i), u=u, k=k, tile_cfg=tcfg, cpad=cpad)
+            wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
+            st["up_b"] = g(f"ups.{i}.0.bias").to(dev)
+            st["up_phases"] = []
+            for taps in transposed_conv_phases(k, u):
+                wsel = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1)        # [cin, c, nt]
+                st["up_phases"].append(dict(w=pack_conv_weight(wsel.permute(1, 0, 2), cpad).to(dev),
+                                            offs=[o for _, o in taps]))
+            st["blocks"] = []
+            for j in range(self.nk):
+                r = i * self.nk + j
+                blk = dict(k=self.ks[j], dil=self.dil[j], c1=[], c2=[], acts=[])
+                for m in range(self.nm):
+                    for tag, lst in (("convs1", blk["c1"]), ("convs2", blk["c2"])):
+                        lst.append(dict(w=pack_conv_weight(g(f"resblocks.{r}.{tag}.{m}.weight"), cpad).to(dev),
+                                        b=g(f"resblocks.{r}.{tag}.{m}.bias").to(dev)))
+                for a in range(2 * self.nm):
+                    blk["acts"].append(act_params(f"resblocks.{r}.activations.{a}."))
+                st["blocks"].append(blk)
+            # fused last conv2: pre-summed bias
+            st["last_bias"] = sum(b["c2"][self.nm - 1]["b"] for b in st["blocks"]).contiguous()
+            self.stages.append(st)
+        self.post_act = act_params("activation_post.")
+        self.post_w = g("conv_post.weight")[0].contiguous().to(dev)      # [c_last, 7]
+        self.post_b = g("conv_post.bias").to(dev)
+        self.post_k = self.post_w.shape[-1]
+        self._plans = {}
+
+    def plan(self, batch, n_frames):
+        key = (batch, n_frames)
+        if key in self._plans:
+            return self._plans[key]
+        dev = self.device
+        B, N = batch, n_frames
+        f32 = dict(dtype=torch.float32, device=dev)
+        steps = []          # (kind, device descriptor tensor, n_groups, args...)
+        keep = []           # tensors that must stay alive
+        L = N
+
+        def conv_step(groups, cpad, n_len, tcfg):
+            d = hip.to_device_struct_array(groups, dev)
+            keep.append(d)
+            steps.append(("conv", d, len(groups), cpad, n_len, tcfg))
+
+        def act_step(groups, c, length):
+            d = hip.to_device_struct_array(groups, dev)
+            keep.append(d)
+            steps.append(("act", d, len(groups), c, length))
+
+        mel_in = torch.empty(B, self.num_mels, N, **f32)
+        pre = torch.empty(B, self.c0, N, **f32)
+        k7 = [j - 3 for j in range(7)]
+        conv_step([make_conv_group([make_conv_seg(mel_in, self.pre_w, self.num_mels, k7)], self.pre_b, [],
+                                    pre, self.c0, self.pre_cpad, N, N, N)], self.pre_cpad, N, self.pre_cfg)
+        cur = pre
+        max_elems = max(st["c"] * N * math.prod(self.rates[:i + 1]) for i, st in enumerate(self.stages))
+        nbuf = 2 + 4 * self.nk
+        pool = torch.empty(nbuf, B * max_elems, **f32)
+        keep.append(pool)
+        for i, st in enumerate(self.stages):
+            c, u, cpad, tcfg = st["c"], st["u"], st["cpad"], st["tile_cfg"]
+            lin, L = L, L * u
+            view = lambda idx: pool[idx, :B * c * L].view(B, c, L)
+            X = view(0)
+            S = view(1)
+            groups = [make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X,
+                                       c, cpad, lin, L, lin, stride=u, phase=r)
+                      for r, ph in enumerate(st["up_phases"])]
+            conv_step(groups, cpad, lin, tcfg)
+            # heavy kernel sizes first (dispatch order == launch order of the panels)
+            order = sorted(range(self.nk), key=lambda j: -st["blocks"][j]["k"])
+            T1 = [view(2 + 4 * j) for j in range(self.nk)]
+            T2 = [view(3 + 4 * j) for j in range(self.nk)]
+            Y = [[view(4 + 4 * j), view(5 + 4 * j)] for j in range(self.nk)]
+            xin = [X] * self.nk
+            for m in range(self.nm):
+                last = m == self.nm - 1
+                act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L)
+                groups = []
+                for j in order:
+                    blk = st["blocks"][j]
+                    k, d = blk["k"], blk["dil"][m]
+                    offs = [(t - (k - 1) // 2) * d for t in range(k)]
+                    groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
+                                                   blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
+                conv_step(groups, cpad, L, tcfg)
+                act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L)
+                if not last:
+                    groups = []
+                    for j in order:
+                        blk = st["blocks"][j]
+                        k = blk["k"]
+                        offs = [t - (k - 1) // 2 for t in range(k)]
+                        out = Y[j][m % 2]
+                        groups.append(make_conv_group([make_conv_seg(T1[j], blk["c2"][m]["w"], c, offs)],
+                                                       blk["c2"][m]["b"], [xin[j]], out, c, cpad, L, L, L))
+                    conv_step(groups, cpad, L, tcfg)
+                    xin = [Y[j][m % 2] for j in range(self.nk)]
+                else:
+                    segs = []
+                    for j in order:
+                        blk = st["blocks"][j]
+                        k = blk["k"]
+                        segs.append(make_conv_seg(T1[j], blk["c2"][m]["w"], c, [t - (k - 1) // 2 for t in range(k)]))
+                    conv_step([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L,
+                                                scale=1.0 / self.nk)], cpad, L, tcfg)
+            # Slot roles repeat every stage: the next up-conv reads S (slot 1) and writes the new X
+            # (slot 0); slot 1 is rewritten only by that stage's last launch, after its readers.
+            cur = S
+        c_last = self.stages[-1]["c"]
+        post_t = pool[2, :B * c_last * L].view(B, c_last, L)
+        act_step([make_act_group(cur, post_t, self.post_act)], c_last, L)
+        wav = torch.empty(B, L, **f32)
+        steps.append(("post", post_t, wav, c_last, L))
+        p = dict(steps=steps, keep=keep, mel_in=mel_in, wav=wav, B=B, N=N, L=L)
+        self._plans[key] = p
+        return p
+
+    def forward(self, mel_bnd):
+        """mel [B, N, num_mels] (token-major, as the sampler produces it) -> wav [B, hop * N]."""
+        B, N, D = mel_bnd.shape
+        p = self.plan(B, N)
+        p["mel_in"].copy_(mel_bnd.transpose(1, 2))       # 'b n d -> b d n' (melvoco.py:115); layout only
+        self.run(p)
+        return p["wav"]
+
+    def run(self, p):
+        L = hip.lib()
+        st = hip.stream()
+        B = p["B"]
+        for s in p["steps"]:
+            if s[0] == "conv":
+                _, d, ng, cpad, n_len, tcfg = s
+                hip.check(L.fh_conv_grouped_f32(d.data_ptr(), ng, B, cpad, n_len, tcfg, st), "fh_conv_grouped_f32")
+            elif s[0] == "act":
+                _, d, ng, c, length = s
+                hip.check(L.fh_act1d_grouped_f32(d.data_ptr(), ng, B, c, length, st), "fh_act1d_grouped_f32")
+            else:
+                _, x, wav, c, length = s
+                hip.check(L.fh_conv_post_tanh_f32(x.data_ptr(), self.post_w.data_ptr(), self.post_b.data_ptr(),
+                                                  wav.data_ptr(), B, c, length, self.post_k, st), "fh_conv_post_tanh_f32")

@@ -1,0 +1,222 @@
+/* flowhigh_hip.h -- C ABI of libflowhigh_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the FlowHighSR.generate() hot path of resemble-ai/flowhigh.
+ * The reference has no FFI layer: its path is stock PyTorch aten ops called from
+ * Python.  Each entry point below names the reference call
+ * site (file:line under /root/reference/src/flowhigh/) whose arithmetic it replaces.
+ * The Python host class `flowhigh_amd.FlowHighSR` binds these through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch-allocated); the
+ *     library never allocates, frees, or synchronises; every call only enqueues work
+ *     on `stream` (a hipStream_t passed as void*), so calls are graph-capturable;
+ *   - all tensors are float32, dense, layouts stated per function;
+ *   - return value: 0 = ok, negative = FH_E_* ; fh_last_error() gives the message
+ *     (thread-local, valid until the next failing call on the same thread).
+ */
+#ifndef FLOWHIGH_HIP_H
+#define FLOWHIGH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FH_OK 0
+#define FH_E_ARG (-1)     /* bad argument / unsupported shape */
+#define FH_E_LAUNCH (-2)  /* HIP launch error */
+
+#define FH_ABI_VERSION 1
+
+int fh_abi_version(void);
+const char* fh_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Grouped implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces: Conv1d / ConvTranspose1d call sites of BigVGAN,
+ *   models/bigvgan/models.py:172-194 (conv_pre, ups[i], and the convs1/convs2 of
+ *   AMPBlock1 :63-72), including "+ x" (:70) and the "xs / num_kernels" average (:187).
+ *
+ * One launch runs `n_groups` independent groups (e.g. the three AMP blocks of a stage,
+ * or the `u` output phases of a transposed conv).  A group sums `nseg` K-segments, each
+ * a (input tensor, packed weight slab, tap list) triple, into one accumulator tile:
+ *     out[b, co, n*out_stride + out_phase] =
+ *         scale * ( bias[co] + sum_r res[r][b, co, .] +
+ *                   sum_seg sum_tap sum_ci  w_seg[tap, ci, co] * x_seg[b, ci, n + tap_off[tap]] )
+ * with x read as 0 outside [0, lin).
+ *
+ * Packed weights: float [cin/8][ntaps][cout_pad][8], cout_pad = cout rounded up to the
+ * tile height of `tile_cfg` (fh_conv_tile_m), zero padded.  cin % 8 == 0.
+ * --------------------------------------------------------------------------------- */
+#define FH_CONV_MAX_TAPS 16
+#define FH_CONV_MAX_SEG 3
+#define FH_CONV_MAX_HALO 64
+
+typedef struct {
+  const float* x;      /* [B, cin, lin] */
+  const float* w;      /* packed, see above */
+  int32_t cin;
+  int32_t ntaps;
+  int32_t off_min;     /* min(tap_off) */
+  int32_t off_max;     /* max(tap_off); off_max - off_min <= FH_CONV_MAX_HALO */
+  int32_t tap_off[FH_CONV_MAX_TAPS];
+} fh_conv_seg;
+
+typedef struct {
+  fh_conv_seg seg[FH_CONV_MAX_SEG];
+  const float* bias;                 /* [cout] or NULL */
+  const float* res[FH_CONV_MAX_SEG]; /* each [B, cout, lout] or NULL */
+  float* out;                        /* [B, cout, lout] */
+  int32_t nseg;
+  int32_t nres;
+  int32_t cout;
+  int32_t cout_pad;
+  int32_t lin;
+  int32_t lout;
+  int32_t n_len;        /* number of n positions (= lout for a plain conv, lin for a transposed-conv phase) */
+  int32_t out_stride;
+  int32_t out_phase;
+  float scale;
+} fh_conv_group;
+
+int fh_sizeof_conv_group(void);
+/* tile_cfg: 0 = 128x128, 1 = 192x128, 2 = 96x256, 3 = 64x256, 4 = 32x512 (co x n) */
+int fh_conv_tile_m(int tile_cfg);
+int fh_conv_tile_n(int tile_cfg);
+/* groups: device array of n_groups descriptors; all groups share cout_pad and n_len. */
+int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch, int cout_pad,
+                        int n_len, int tile_cfg, void* stream);
+
+/* conv_post + tanh (models/bigvgan/models.py:190-192): x [B, cin, L], w [cin, ksz], bias[1]
+ * -> out [B, L] = tanh(bias + sum_ci sum_j w[ci,j] * x[b, ci, t + j - ksz/2]).  ksz odd <= 15. */
+int fh_conv_post_tanh_f32(const float* x, const float* w, const float* bias, float* out,
+                          int batch, int cin, int len, int ksz, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Anti-aliased periodic activation, fused: 2x kaiser-sinc upsample -> Snake/SnakeBeta ->
+ * 2x low-pass downsample, one read and one write of the tensor.
+ * Replaces: Activation1d.forward, models/bigvgan/alias_free_torch/act.py:23-28
+ *   (UpSample1d resample.py:25-33, SnakeBeta activations.py:107-120 / Snake :48-59,
+ *    DownSample1d -> LowPassFilter1d filter.py:86-95).
+ * Grouped like the conv: group g maps x[g] -> y[g] with its own per-channel parameters.
+ *   alpha, inv_beta: [channels] already exponentiated if log-scale;
+ *   inv_beta = 1 / (beta + 1e-9)  (or 1 / (alpha + 1e-9) for Snake).
+ *   up_taps / down_taps: the 12 filter taps stored in the checkpoint.
+ * --------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x;        /* [B, C, L] */
+  float* y;              /* [B, C, L] */
+  const float* alpha;    /* [C] */
+  const float* inv_beta; /* [C] */
+  float up_taps[12];
+  float down_taps[12];
+} fh_act_group;
+
+int fh_sizeof_act_group(void);
+int fh_act1d_grouped_f32(const fh_act_group* groups, int n_groups, int batch, int channels,
+                         int len, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM:  C[M, N] = epilogue( A[M, K] * W[N, K]^T )
+ * Replaces every nn.Linear on the path (models/flow.py:239,261; attend.py:170-171;
+ * transformer.py:98-104), torch.stft / torch.istft as DFT-by-GEMM
+ * (melvoco.py:78-79; postprocessing.py:22-23,39) and the mel projection (melvoco.py:83).
+ *   A row-major, row stride lda (floats, % 4 == 0); W row-major [n_pad, K] with
+ *   n_pad = N rounded up to 128 (rows >= N zero); K % 32 == 0.
+ * epilogue (v = acc + bias[n]):
+ *   FH_EPI_LINEAR : C[m, n] = alpha * v + (R ? R[m, n] : 0)              (ldc, ldr strides)
+ *   FH_EPI_GEGLU  : packed pairs: columns come in blocks of 64 = 32 "value" + 32 "gate";
+ *                   C[m, 32*blk + i] = gelu_erf(gate) * value            (transformer.py:92-95)
+ *   FH_EPI_MAG    : pairs (re, im): C = sqrt(re^2 + im^2 + 1e-9)         (melvoco.py:80-81)
+ *   FH_EPI_LOGCLAMP: C = log(max(v, 1e-5))                               (modules.py:31-36)
+ * --------------------------------------------------------------------------------- */
+#define FH_EPI_LINEAR 0
+#define FH_EPI_GEGLU 1
+#define FH_EPI_MAG 2
+#define FH_EPI_LOGCLAMP 3
+
+int fh_gemm_f32(const float* A, int lda, const float* W, const float* bias, const float* R,
+                int ldr, float* C, int ldc, int M, int N, int K, float alpha, int epilogue,
+                void* stream);
+
+/* y[n] = act(bias[n] + sum_k W[n, k] * x[k]),  act: 0 none, 1 SiLU.  One vector (the time
+ * embedding is the same for every clip: flow.py:208-211,242; transformer.py:81-83). */
+int fh_gemv_f32(const float* W, const float* x, const float* bias, float* y, int N, int K,
+                int act, void* stream);
+
+/* LearnedSinusoidalPosEmb (models/pos_emb.py:22-26): out[0:h] = sin(t*w*2pi), out[h:2h] = cos. */
+int fh_time_fourier_f32(const float* w, float t, float* out, int half_dim, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Transformer pointwise / reduction kernels.
+ * --------------------------------------------------------------------------------- */
+/* ConvPositionEmbed + residual (models/transformer.py:16-46, flow.py:240):
+ * y[b,n,c] = x[b,n,c] + gelu_erf(bias[c] + sum_j w[c,j] * x[b, n + j - ksz/2, c]), zero padded. */
+int fh_dwconv_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
+                           int batch, int n, int dim, int ksz, void* stream);
+
+/* AdaptiveRMSNorm / RMSNorm (transformer.py:49-88):
+ * y = x / max(||x||, 1e-12) * sqrt(dim) * gamma[c] + (beta ? beta[c] : 0); rows of `dim`. */
+int fh_rmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows,
+                   int dim, void* stream);
+
+/* MultiheadRMSNorm on q,k + rotary embedding, in place on the fused qkv buffer
+ * (attend.py:144-151,179-184; pos_emb.py:53-59).  qkv [rows = B*n, 3*heads*64];
+ * gq, gk [heads, 64]; cos_t, sin_t [n, 32] (angle table, one half).  dim_head must be 64. */
+int fh_qknorm_rope_f32(float* qkv, const float* gq, const float* gk, const float* cos_t,
+                       const float* sin_t, int batch, int n, int heads, void* stream);
+
+/* softmax(q k^T * scale) v without materialising the score matrix (attend.py:102-139).
+ * qkv as above (q | k | v along the feature axis), out [B*n, heads*64].  dim_head 64. */
+int fh_attention_f32(const float* qkv, float* out, int batch, int n, int heads, float scale,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * STFT framing, post-processing (postprocessing.py:5-41) and peak normalisation.
+ * Packed spectrum layout ("P-layout") used between the DFT GEMMs: per frame 33 blocks of
+ * 64 floats = 32 real parts then 32 imaginary parts of bins 32*blk .. 32*blk+31 (bins >= 1025
+ * are zero): width 2112.
+ * --------------------------------------------------------------------------------- */
+/* frames[b*nf + t, k] = pad(audio[b])[hop*t + k] * window[k], k < nfft.
+ * pad_mode 0: reflect (melvoco.py:74), 1: zero (torch.stft center=True, pad_mode='constant'). */
+int fh_frame_f32(const float* audio, const float* window, float* frames, int batch, int len,
+                 int n_frames, int nfft, int hop, int pad, int pad_mode, void* stream);
+
+/* energy[b, f] = sum_t |S[b, t, f]| over the first n_frames frames, f < 1025 (P-layout in). */
+int fh_spec_energy_f32(const float* spec, float* energy, int batch, int n_frames, void* stream);
+
+/* get_cutoff_index (postprocessing.py:10-16): cr[b] = max{ j in [1,1024] :
+ * cumsum(energy[b])[j] < thr * total } or 0. */
+int fh_cutoff_index_f32(const float* energy, int32_t* cr, int batch, float thr, void* stream);
+
+/* out[b,t,:] = bins < cr[b] ? src : pred   (P-layout, postprocessing.py:36-37). */
+int fh_spec_splice_f32(const float* pred, const float* src, const int32_t* cr, float* out,
+                       int batch, int n_frames, void* stream);
+
+/* Overlap-add of windowed inverse-DFT frames with window-envelope division, centre trim,
+ * zero fill (torch.istft semantics, postprocessing.py:39); also atomically tracks
+ * max|y| per clip in peak_bits[b] (float bits as uint32, must be zeroed by the caller). */
+int fh_istft_ola_f32(const float* frames, const float* window, float* y, uint32_t* peak_bits,
+                     int batch, int n_frames, int len, int nfft, int hop, void* stream);
+
+/* y[b, :] *= target / peak[b]   (postprocessing.py:40; flowhighsr.py:69). */
+int fh_peak_scale_f32(float* y, const uint32_t* peak_bits, int batch, int len, float target,
+                      void* stream);
+
+/* peak_bits[b] = bits(max_t |x[b,t]|) (caller zeroes peak_bits first). */
+int fh_peak_abs_f32(const float* x, uint32_t* peak_bits, int batch, int len, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Host pre-step on device: scipy.signal.resample_poly(x, up, down) with zero padding
+ * (flowhighsr.py:68).  taps: the scipy FIR (already multiplied by `up`), n_taps odd-centred as
+ * scipy pads it; y[b, i] = sum_j taps[j*up + (i*down + pre) % up ...] -- see resample.hip.
+ * --------------------------------------------------------------------------------- */
+int fh_resample_poly_f32(const float* x, const float* taps, float* y, int batch, int len_in,
+                         int len_out, int up, int down, int n_taps, int n_pre_remove,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWHIGH_HIP_H */

@@ -1,0 +1,115 @@
+"""GPU: FlowHighSR.generate() through the C-ABI library against (a) the golden vectors produced by
+the real reference, (b) the CPU oracle on larger seeded cases, (c) size-independent properties at
+the BASELINE.json sizes.  The bar from BASELINE.json: <= 1e-4 max-abs on the 48 kHz waveform."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import E2E_CASES, load_golden          # noqa: E402
+from flowhigh_amd import FLowHigh, FlowHighSR, synth  # noqa: E402
+from oracle import ref_cpu                            # noqa: E402
+
+TOL_WAVEFORM = 1e-4
+_MODELS = {}
+
+
+def model_for(cfg, seed, method="euler", cfm_method="basic_cfm", sigma=0.0, upsampling="scipy"):
+    key = (repr(sorted(cfg.items())), seed)
+    if key not in _MODELS:
+        sd = synth.make_state_dict(cfg, seed)
+        _MODELS[key] = (FLowHigh(sd, cfg, "cuda"), sd)
+    fh, sd = _MODELS[key]
+    m = FlowHighSR(fh, sigma=sigma, cfm_method=cfm_method, torchdiffeq_ode_method=method,
+                   upsampling_method=upsampling)
+    return m, sd
+
+
+@pytest.mark.parametrize("name", E2E_CASES)
+def test_generate_matches_reference_golden(name):
+    g = load_golden(name)
+    m, _ = model_for(g["cfg"], g["seed"], g["method"], g["cfm_method"], g["sigma"])
+    out, st = m.generate_batch([g["audio"]], g["sr_in"], 48000, g["steps"], noise=torch.from_numpy(g["noise"]),
+                               return_stages=True)
+    assert out.dtype == torch.float32 and out.is_cuda and tuple(out.shape) == g["out"].shape
+    assert int(st["cr"][0].item()) == g["cr"]                               # integer: exact
+    assert np.abs(st["wav"].cpu().numpy() - g["wav"]).max() <= TOL_WAVEFORM
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_WAVEFORM
+
+
+def test_generate_draws_reference_prior_when_noise_is_none():
+    g = load_golden("tiny_euler")
+    m, _ = model_for(g["cfg"], g["seed"], g["method"])
+    gen = torch.Generator().manual_seed(2000 + g["seed"])
+    out = m.generate(g["audio"], g["sr_in"], 48000, g["steps"], generator=gen)
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_WAVEFORM
+
+
+@pytest.mark.parametrize("sr_in,method,steps,secs", [(12000, "euler", 1, 1.0), (16000, "midpoint", 1, 0.6),
+                                                     (24000, "midpoint", 2, 0.5), (8000, "euler", 1, 0.7)])
+def test_generate_synth_cfg_vs_oracle(sr_in, method, steps, secs):
+    """Full-width vocoder (SYNTH-CFG, 1536 channels) on short clips the oracle finishes in seconds."""
+    cfg = synth.SYNTH_CFG
+    m, sd = model_for(cfg, 0, method)
+    audio = synth.lowres_clip(7, secs, sr_in)
+    n = int(round(secs * sr_in)) * (48000 // sr_in) // 480
+    noise = synth.prior_noise(7, n)
+    ref, st = ref_cpu.generate(sd, cfg, audio, sr_in, noise, steps, method, return_stages=True)
+    out, got = m.generate_batch([audio], sr_in, 48000, steps, noise=noise, return_stages=True)
+    assert int(got["cr"][0].item()) == st["cr"]
+    assert (got["wav"].cpu() - st["wav"]).abs().max().item() <= TOL_WAVEFORM
+    assert (out.cpu() - ref).abs().max().item() <= TOL_WAVEFORM
+
+
+def test_device_resampler_path_vs_oracle():
+    cfg = synth.TINY_CFG
+    m, sd = model_for(cfg, 0, "euler", upsampling="hip")
+    audio = synth.lowres_clip(3, 0.5, 12000)
+    noise = synth.prior_noise(3, 50)
+    ref = ref_cpu.generate(sd, cfg, audio, 12000, noise, 1, "euler")
+    out = m.generate(audio, 12000, 48000, 1, noise=noise)
+    assert (out.cpu() - ref).abs().max().item() <= TOL_WAVEFORM
+
+
+def test_batch_equals_single_clip_runs_bitwise():
+    """Clips are independent: a batched run must reproduce per-clip runs exactly (this is also the
+    multi-GPU sharding invariant)."""
+    cfg = synth.TINY_CFG
+    m, _ = model_for(cfg, 0, "midpoint")
+    clips = [synth.lowres_clip(i, 0.5, 16000) for i in range(3)]
+    noise = torch.cat([synth.prior_noise(i, 50) for i in range(3)], 0)
+    both = m.generate_batch(clips, 16000, 48000, 1, noise=noise)
+    for i in range(3):
+        one = m.generate(clips[i], 16000, 48000, 1, noise=noise[i:i + 1])
+        assert torch.equal(both[i:i + 1], one)
+
+
+@pytest.mark.parametrize("secs,sr_in,method,steps,B", [(10.0, 12000, "euler", 1, 1), (10.0, 16000, "midpoint", 1, 2)])
+def test_full_size_properties(secs, sr_in, method, steps, B):
+    """BASELINE.json sizes (10 s clips, SYNTH-CFG): determinism, peak normalisation, finite output,
+    and the low band of the output equals the low band of the input (the splice invariant)."""
+    cfg = synth.SYNTH_CFG
+    m, _ = model_for(cfg, 0, method, upsampling="hip")
+    clips = [synth.lowres_clip(i, secs, sr_in) for i in range(B)]
+    n = int(secs * 100)
+    noise = torch.cat([synth.prior_noise(i, n) for i in range(B)], 0)
+    out1, st = m.generate_batch(clips, sr_in, 48000, steps, noise=noise, return_stages=True)
+    out2 = m.generate_batch(clips, sr_in, 48000, steps, noise=noise)
+    assert tuple(out1.shape) == (B, int(secs * 48000))
+    assert torch.isfinite(out1).all()
+    assert torch.equal(out1, out2)
+    assert torch.allclose(out1.abs().amax(dim=1).cpu(), torch.full((B,), 0.99), atol=1e-6)
+    # splice invariant: below the cutoff bin the output spectrum is the source spectrum (up to the
+    # common peak gain): compare band-limited energies through torch.stft on the host.
+    cond = st["cond"].cpu()
+    win = torch.hann_window(2048)
+    for b in range(B):
+        cr = int(st["cr"][b].item())
+        assert 1 <= cr <= 1024
+        so = torch.stft(out1[b].cpu(), 2048, 480, 2048, win, return_complex=True)
+        sc = torch.stft(cond[b], 2048, 480, 2048, win, return_complex=True)
+        lo = slice(2, max(3, cr - 4))
+        gain = (so[lo].abs().sum() / sc[lo].abs().sum()).item()
+        err = (so[lo] - gain * sc[lo]).abs().max().item() / sc[lo].abs().max().item()
+        assert err <= 2e-3

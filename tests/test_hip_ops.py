@@ -1,0 +1,363 @@
+"""GPU: every HIP entry point against the CPU oracle (oracle/ref_cpu.py, plain torch ops) on seeded
+inputs.  Tolerances are written next to each assert; they are fp32 summation-order noise, not
+precision trade-offs (all kernels compute in exact fp32)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from flowhigh_amd import hip, synth, tables  # noqa: E402
+from flowhigh_amd import vocoder as V        # noqa: E402
+from oracle import ref_cpu                   # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------
+# grouped implicit-GEMM conv
+# ------------------------------------------------------------------------------------------
+def run_conv(x, w, bias, dilation, tile_cfg, res=None, scale=1.0):
+    B, cin, L = x.shape
+    cout, _, k = w.shape
+    bm = hip.lib().fh_conv_tile_m(tile_cfg)
+    cpad = -(-cout // bm) * bm
+    xd, out = x.to(DEV), torch.full((B, cout, L), float("nan"), device=DEV)
+    wp = V.pack_conv_weight(w, cpad).to(DEV)
+    bd = bias.to(DEV) if bias is not None else None
+    rd = [r.to(DEV) for r in (res or [])]
+    offs = [(t - (k - 1) // 2) * dilation for t in range(k)]
+    g = V.make_conv_group([V.make_conv_seg(xd, wp, cin, offs)], bd, rd, out, cout, cpad, L, L, L, scale=scale)
+    keep = V.conv_grouped([g], B, cpad, L, tile_cfg, DEV)
+    torch.cuda.synchronize()
+    del keep
+    return out.cpu()
+
+
+@pytest.mark.parametrize("tile_cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cin,cout,k,d,L", [(16, 24, 7, 3, 300), (8, 8, 3, 1, 33), (24, 200, 11, 5, 1111)])
+def test_conv_plain(tile_cfg, cin, cout, k, d, L):
+    x, w, b = rnd(2, cin, L, seed=1), rnd(cout, cin, k, seed=2, scale=0.2), rnd(cout, seed=3)
+    ref = F.conv1d(x, w, b, dilation=d, padding=(k * d - d) // 2)
+    got = run_conv(x, w, b, d, tile_cfg)
+    assert maxdiff(got, ref) <= 2e-5          # K <= 2200 fp32 products, |terms| ~ 0.2
+
+
+def test_conv_large_k_residual_scale():
+    cin = cout = 256
+    x, w, b = rnd(1, cin, 700, seed=4), rnd(cout, cin, 11, seed=5, scale=0.02), rnd(cout, seed=6)
+    r1, r2 = rnd(1, cout, 700, seed=7), rnd(1, cout, 700, seed=8)
+    ref = (F.conv1d(x, w, b, dilation=5, padding=25) + r1 + r2) * 0.5
+    got = run_conv(x, w, b, 5, 0, res=[r1, r2], scale=0.5)
+    assert maxdiff(got, ref) <= 2e-5
+
+
+def test_conv_no_bias():
+    x, w = rnd(1, 8, 100, seed=9), rnd(16, 8, 3, seed=10)
+    assert maxdiff(run_conv(x, w, None, 1, 4), F.conv1d(x, w, None, padding=1)) <= 1e-5
+
+
+@pytest.mark.parametrize("u,k", [(5, 11), (4, 8), (3, 7), (2, 4), (8, 16), (6, 12)])
+def test_conv_transpose_as_phase_groups(u, k):
+    cin, cout, L, B = 32, 16, 157, 2
+    x, wt, b = rnd(B, cin, L, seed=11), rnd(cin, cout, k, seed=12, scale=0.2), rnd(cout, seed=13)
+    ref = F.conv_transpose1d(x, wt, b, stride=u, padding=(k - u) // 2)
+    assert ref.shape[-1] == u * L
+    tile_cfg, _, cpad = V.pick_tile_cfg(cout)
+    xd, out, bd = x.to(DEV), torch.full((B, cout, u * L), float("nan"), device=DEV), b.to(DEV)
+    groups, keep = [], []
+    for r, taps in enumerate(V.transposed_conv_phases(k, u)):
+        wsel = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1).permute(1, 0, 2)
+        wp = V.pack_conv_weight(wsel, cpad).to(DEV)
+        keep.append(wp)
+        groups.append(V.make_conv_group([V.make_conv_seg(xd, wp, cin, [o for _, o in taps])], bd, [], out,
+                                        cout, cpad, L, u * L, L, stride=u, phase=r))
+    keep.append(V.conv_grouped(groups, B, cpad, L, tile_cfg, DEV))
+    torch.cuda.synchronize()
+    assert maxdiff(out, ref) <= 1e-5
+
+
+def test_conv_three_segments_fused_average():
+    """Last conv2 of a stage: one accumulator over the three AMP blocks + residuals, / 3."""
+    c, L, B = 48, 400, 2
+    ks = [11, 7, 3]
+    xs = [rnd(B, c, L, seed=20 + i) for i in range(3)]
+    ws = [rnd(c, c, k, seed=30 + i, scale=0.1) for i, k in enumerate(ks)]
+    bs = [rnd(c, seed=40 + i) for i in range(3)]
+    rs = [rnd(B, c, L, seed=50 + i) for i in range(3)]
+    ref = sum(F.conv1d(x, w, b, padding=(k - 1) // 2) + r for x, w, b, r, k in zip(xs, ws, bs, rs, ks)) / 3
+    tile_cfg, _, cpad = V.pick_tile_cfg(c)
+    out = torch.full((B, c, L), float("nan"), device=DEV)
+    xd, rd = [x.to(DEV) for x in xs], [r.to(DEV) for r in rs]
+    wp = [V.pack_conv_weight(w, cpad).to(DEV) for w in ws]
+    bsum = sum(bs).to(DEV)
+    segs = [V.make_conv_seg(xd[i], wp[i], c, [t - (k - 1) // 2 for t in range(k)]) for i, k in enumerate(ks)]
+    g = V.make_conv_group(segs, bsum, rd, out, c, cpad, L, L, L, scale=1.0 / 3)
+    keep = V.conv_grouped([g], B, cpad, L, tile_cfg, DEV)
+    torch.cuda.synchronize()
+    assert maxdiff(out, ref) <= 1e-5
+    del keep
+
+
+def test_conv_post_tanh():
+    B, c, L = 2, 24, 1000
+    x, w, b = rnd(B, c, L, seed=60), rnd(1, c, 7, seed=61, scale=0.1), rnd(1, seed=62, scale=0.1)
+    ref = torch.tanh(F.conv1d(x, w, b, padding=3)).squeeze(1)
+    out = torch.empty(B, L, device=DEV)
+    xd, wd, bd = x.to(DEV), w[0].contiguous().to(DEV), b.to(DEV)
+    hip.check(hip.lib().fh_conv_post_tanh_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(),
+                                              B, c, L, 7, hip.stream()), "conv_post")
+    assert maxdiff(out, ref) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------
+# anti-aliased activation
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L", [1, 5, 41, 506, 507, 1500])
+@pytest.mark.parametrize("kind", ["snakebeta_log", "snake_lin"])
+def test_act1d(L, kind):
+    B, C, G = 2, 6, 3
+    filt = synth.kaiser_sinc_filter()
+    xs = [rnd(B, C, L, seed=70 + g, scale=1.5) for g in range(G)]
+    groups, keep, refs = [], [], []
+    for g in range(G):
+        al, be = rnd(C, seed=80 + g, scale=0.4), rnd(C, seed=90 + g, scale=0.4)
+        if kind == "snakebeta_log":
+            h = {"activation": "snakebeta", "snake_logscale": True}
+            sd = {"a.act.alpha": al, "a.act.beta": be}
+            alpha, beta = torch.exp(al), torch.exp(be)
+        else:
+            h = {"activation": "snake", "snake_logscale": False}
+            al = al.abs() + 0.5
+            sd = {"a.act.alpha": al}
+            alpha, beta = al, al
+        sd["a.upsample.filter"] = filt
+        sd["a.downsample.lowpass.filter"] = filt
+        refs.append(ref_cpu.activation1d(sd, "a.", xs[g], h))
+        p = dict(alpha=alpha.to(DEV), inv_beta=(1.0 / (beta + 1e-9)).to(DEV), up=filt.flatten().tolist(),
+                 down=filt.flatten().tolist())
+        xd, yd = xs[g].to(DEV), torch.full((B, C, L), float("nan"), device=DEV)
+        keep += [p, xd, yd]
+        groups.append(V.make_act_group(xd, yd, p))
+    keep.append(V.act1d_grouped(groups, B, C, L, DEV))
+    torch.cuda.synchronize()
+    for g in range(G):
+        assert maxdiff(keep[3 * g + 2], refs[g]) <= 3e-6     # sinf ulp differences x 12-tap filter
+
+
+def test_act1d_golden_from_reference():
+    from conftest import load_golden
+    g = load_golden("ops")
+    x = torch.from_numpy(g["act_x"])
+    taps = g["kaiser_taps"].tolist()
+    p = dict(alpha=torch.exp(torch.from_numpy(g["act_alpha"])).to(DEV),
+             inv_beta=(1.0 / (torch.exp(torch.from_numpy(g["act_beta"])) + 1e-9)).to(DEV), up=taps, down=taps)
+    xd, yd = x.to(DEV), torch.empty_like(x, device=DEV)
+    keep = V.act1d_grouped([V.make_act_group(xd, yd, p)], x.shape[0], x.shape[1], x.shape[2], DEV)
+    torch.cuda.synchronize()
+    assert maxdiff(yd, torch.from_numpy(g["act_snakebeta_log"])) <= 3e-6
+    del keep
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM and epilogues
+# ------------------------------------------------------------------------------------------
+def pad_rows(w):
+    n = w.shape[0]
+    out = torch.zeros(-(-n // 128) * 128, w.shape[1])
+    out[:n] = w
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1024, 1024), (37, 256, 256), (4096, 2048, 512), (130, 3072, 1024)])
+def test_gemm_linear(M, N, K):
+    a, w, b, r = rnd(M, K, seed=100), rnd(N, K, seed=101, scale=K ** -0.5), rnd(N, seed=102), rnd(M, N, seed=103)
+    ref = 0.25 * F.linear(a, w, b) + r
+    out = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(a.to(DEV), pad_rows(w).to(DEV), out, M, N, K, bias=b.to(DEV), R=r.to(DEV), alpha=0.25)
+    assert maxdiff(out, ref) <= 1e-5
+    out2 = torch.empty(M, N, device=DEV)
+    hip.gemm(a.to(DEV), pad_rows(w).to(DEV), out2, M, N, K)
+    assert maxdiff(out2, F.linear(a, w)) <= 1e-5
+
+
+def test_gemm_geglu_packed():
+    from flowhigh_amd.flow import pack_geglu
+    M, K, inner = 333, 1024, 2730
+    a, w, b = rnd(M, K, seed=110), rnd(2 * inner, K, seed=111, scale=K ** -0.5), rnd(2 * inner, seed=112)
+    h = F.linear(a, w, b)
+    val, gate = h.chunk(2, dim=-1)
+    ref = F.gelu(gate) * val
+    wp, bp, ip = pack_geglu(w, b)
+    out = torch.full((M, ip), float("nan"), device=DEV)
+    hip.gemm(a.to(DEV), wp.to(DEV), out, M, 2 * ip, K, bias=bp.to(DEV), epilogue=hip.EPI_GEGLU)
+    assert ip == 2752
+    assert maxdiff(out[:, :inner], ref) <= 1e-5
+    assert out[:, inner:].abs().max().item() == 0.0        # zero padding stays exactly zero
+
+
+def test_gemm_dft_magnitude_and_logmel():
+    g = torch.Generator().manual_seed(5)
+    audio = torch.randn(2, 9600, generator=g) * 0.1
+    ref = ref_cpu.logmel(audio)                                           # [2, 20, 256]
+    from flowhigh_amd.frontend import LogMel
+    mel = LogMel(DEV)(audio.to(DEV)).view(2, 20, 256)
+    d = (mel.cpu() - ref).abs()
+    loud = ref > -8.0
+    assert d[loud].max().item() <= 1e-4      # relative fp32 DFT noise of the magnitude
+    assert d.max().item() <= 5e-3            # near the log(1e-5) clamp the reference's own FFT noise dominates
+
+
+def test_gemv_and_time_fourier():
+    N, K = 8192, 1024
+    w, x, b = rnd(N, K, seed=120, scale=K ** -0.5), rnd(K, seed=121), rnd(N, seed=122)
+    y = torch.empty(N, device=DEV)
+    L = hip.lib()
+    hip.check(L.fh_gemv_f32(w.to(DEV).data_ptr(), x.to(DEV).data_ptr(), b.to(DEV).data_ptr(), y.data_ptr(), N, K, 1,
+                            hip.stream()), "gemv")
+    assert maxdiff(y, F.silu(F.linear(x, w, b))) <= 5e-6
+    ws = rnd(512, seed=123)
+    out = torch.empty(1024, device=DEV)
+    hip.check(L.fh_time_fourier_f32(ws.to(DEV).data_ptr(), 0.3, out.data_ptr(), 512, hip.stream()), "fourier")
+    fr = torch.tensor([0.3])[:, None] * ws[None, :] * 2 * math.pi
+    assert maxdiff(out, torch.cat((fr.sin(), fr.cos()), -1)[0]) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+# transformer pieces and the whole vector field
+# ------------------------------------------------------------------------------------------
+def test_dwconv_gelu_res():
+    B, n, D, k = 2, 77, 1024, 31
+    x, w, b = rnd(B, n, D, seed=130), rnd(D, 1, k, seed=131, scale=0.2), rnd(D, seed=132)
+    ref = F.gelu(F.conv1d(x.transpose(1, 2), w, b, padding=15, groups=D)).transpose(1, 2) + x
+    y = torch.empty(B, n, D, device=DEV)
+    hip.check(hip.lib().fh_dwconv_gelu_res_f32(x.to(DEV).data_ptr(), w.reshape(D, k).contiguous().to(DEV).data_ptr(),
+                                               b.to(DEV).data_ptr(), y.data_ptr(), B, n, D, k, hip.stream()), "dwconv")
+    assert maxdiff(y, ref) <= 5e-6
+
+
+def test_rmsnorm():
+    M, D = 130, 1024
+    x, g, b = rnd(M, D, seed=140, scale=3.0), rnd(D, seed=141), rnd(D, seed=142)
+    x[5] = 0.0                                       # F.normalize eps path
+    ref = F.normalize(x, dim=-1) * 32.0 * g + b
+    y = torch.empty(M, D, device=DEV)
+    L = hip.lib()
+    hip.check(L.fh_rmsnorm_f32(x.to(DEV).data_ptr(), g.to(DEV).data_ptr(), b.to(DEV).data_ptr(), y.data_ptr(), M, D,
+                               hip.stream()), "rmsnorm")
+    assert maxdiff(y, ref) <= 5e-6
+    hip.check(L.fh_rmsnorm_f32(x.to(DEV).data_ptr(), g.to(DEV).data_ptr(), 0, y.data_ptr(), M, D, hip.stream()), "rmsnorm")
+    assert maxdiff(y, F.normalize(x, dim=-1) * 32.0 * g) <= 5e-6
+
+
+@pytest.mark.parametrize("n", [33, 1000])
+def test_attention_block(n):
+    """qk-norm + RoPE + streaming softmax attention against the oracle's attention()."""
+    B, H, D = 2, 16, 1024
+    sd = synth.make_flow_state_dict(seed=3)
+    p = "flowhigh.transformer.layers.0.3."
+    x = rnd(B, n, D, seed=150)
+    rot = ref_cpu.rotary_table(sd, n)
+    ref = ref_cpu.attention(sd, p, x, rot)
+    # HIP: qkv GEMM -> qknorm_rope -> attention -> out GEMM
+    L = hip.lib()
+    M = B * n
+    qkv = torch.empty(M, 3 * D, device=DEV)
+    hip.gemm(x.view(M, D).to(DEV), sd[p + "to_qkv.weight"].to(DEV), qkv, M, 3 * D, D)
+    cos_t, sin_t = tables.rotary_tables(sd["flowhigh.transformer.rotary_emb.inv_freq"], n)
+    gq = sd[p + "q_norm.gamma"].reshape(H, 64).contiguous().to(DEV)
+    gk = sd[p + "k_norm.gamma"].reshape(H, 64).contiguous().to(DEV)
+    cd, sn = cos_t.to(DEV), sin_t.to(DEV)
+    hip.check(L.fh_qknorm_rope_f32(qkv.data_ptr(), gq.data_ptr(), gk.data_ptr(), cd.data_ptr(), sn.data_ptr(), B, n, H,
+                                   hip.stream()), "qknorm_rope")
+    att = torch.empty(M, D, device=DEV)
+    hip.check(L.fh_attention_f32(qkv.data_ptr(), att.data_ptr(), B, n, H, 10.0, hip.stream()), "attention")
+    out = torch.empty(M, D, device=DEV)
+    hip.gemm(att, sd[p + "to_out.weight"].to(DEV), out, M, D, D)
+    assert maxdiff(out.view(B, n, D), ref) <= 2e-5       # logits up to +-640 in fp32: ~4e-5 abs on the exponent
+
+
+@pytest.mark.parametrize("B,n,t", [(1, 25, 0.0), (2, 200, 0.3)])
+def test_flow_forward(B, n, t):
+    from flowhigh_amd.flow import FlowNet
+    sd = synth.make_flow_state_dict(seed=0)
+    x, cond = rnd(B, n, 256, seed=160), rnd(B, n, 256, seed=161, scale=3.0) - 4.0
+    ref = ref_cpu.flow_forward(sd, x, cond, t)
+    net = FlowNet(sd, DEV)
+    xd, cd = x.view(B * n, 256).to(DEV), cond.view(B * n, 256).to(DEV)
+    net.set_cond(cd, B, n)
+    out = torch.empty(B * n, 256, device=DEV)
+    net.forward(xd, t, out, B, n)
+    assert maxdiff(out.view(B, n, 256), ref) <= 5e-5
+    # fused ODE axpy epilogue: out = res + alpha * v
+    out2 = torch.empty(B * n, 256, device=DEV)
+    net.forward(xd, t, out2, B, n, alpha=0.5, res=xd)
+    assert maxdiff(out2.view(B, n, 256), x + 0.5 * ref) <= 5e-5
+
+
+# ------------------------------------------------------------------------------------------
+# vocoder, post-processing, resampler
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfgname,B,N", [("TINY_CFG", 2, 25), ("ALT_CFG", 1, 20), ("SYNTH_CFG", 1, 12)])
+def test_vocoder_forward(cfgname, B, N):
+    cfg = getattr(synth, cfgname)
+    sd = synth.make_vocoder_state_dict(cfg, seed=1)
+    mel = rnd(B, N, 256, seed=170, scale=2.0) - 3.0
+    ref = ref_cpu.bigvgan_forward(sd, cfg, mel.transpose(1, 2)).squeeze(1)
+    voc = V.Vocoder(cfg, sd, DEV)
+    wav = voc.forward(mel.to(DEV))
+    assert wav.shape == ref.shape
+    assert maxdiff(wav, ref) <= 2e-5          # ~110 stacked convs, oracle fp32-vs-fp64 noise is ~1e-6
+
+
+@pytest.mark.parametrize("T", [4999, 9600, 12345])
+def test_postprocessing(T):
+    from flowhigh_amd.frontend import PostProcessor
+    import scipy.signal
+    g = torch.Generator().manual_seed(T)
+    pred = torch.randn(2, (T // 480) * 480, generator=g) * 0.1
+    low = torch.randn(2, T // 4 + 1, generator=g).numpy()
+    src = torch.from_numpy(scipy.signal.resample_poly(low, 4, 1, axis=1)[:, :T].copy()).float()
+    src = src / src.abs().amax(dim=1, keepdim=True)
+    pp = PostProcessor(DEV)
+    out, cr = pp(pred.to(DEV), src.to(DEV), T, return_cr=True)
+    for b in range(2):
+        ref, rcr = ref_cpu.post_processing(pred[b:b + 1], src[b:b + 1], T, return_cr=True)
+        assert int(cr[b].item()) == rcr                    # integer cutoff bin: exact
+        assert maxdiff(out[b:b + 1], ref) <= 2e-5
+    assert out.shape == (2, T)
+    assert torch.allclose(out.abs().amax(dim=1).cpu(), torch.full((2,), 0.99), atol=1e-6)
+
+
+def test_postprocessing_golden_from_reference():
+    from conftest import load_golden
+    from flowhigh_amd.frontend import PostProcessor
+    g = load_golden("ops")
+    out, cr = PostProcessor(DEV)(torch.from_numpy(g["pp_pred"]).to(DEV), torch.from_numpy(g["pp_src"]).to(DEV),
+                                 4999, return_cr=True)
+    assert int(cr[0].item()) == int(g["pp_cr"])
+    assert maxdiff(out, torch.from_numpy(g["pp_out"])) <= 2e-5
+
+
+@pytest.mark.parametrize("sr_in", [12000, 16000, 8000, 24000, 44100])
+def test_resample_poly(sr_in):
+    import scipy.signal
+    from flowhigh_amd.frontend import Resampler
+    x = np.stack([synth.lowres_clip(i, 0.37, sr_in) for i in range(2)])
+    ref = scipy.signal.resample_poly(x, 48000, sr_in, axis=1)
+    ref = ref / np.abs(ref).max(axis=1, keepdims=True)
+    got = Resampler(DEV)(torch.from_numpy(x).to(DEV), sr_in)
+    assert got.shape == ref.shape
+    assert maxdiff(got, torch.from_numpy(ref)) <= 2e-6
