@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+
+A "step" is one pass of FlowHighSR.generate() over one batch of synthetic clips whose low-rate
+input and prior noise are already resident in HBM (device resampler -> log-mel -> `time_step`
+vector-field evaluations -> BigVGAN -> STFT post-processing), ending with the 48 kHz waveform in HBM.
+Workload at N = 1: BASELINE.json configs[1] (B = 1, one 10 s clip, 12 -> 48 kHz, time_step = 1 euler,
+transformer 2 x 16 x 64, SYNTH-CFG BigVGAN-48k-256band; random-init weights, synthetic audio).
+For N > 1 every rank runs the same per-GPU workload on its own clips (independent clips, no
+data-path collective: weak scaling); launched by torch.distributed.run, one rank per GPU.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+SECS, SR_IN, STEPS_ODE, METHOD = 10.0, 12000, 1, "euler"
+
+
+def cpu_baseline(sd, cfg):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload:
+    one 2 s clip (1/5 of the 10 s clip), same weights, all host threads."""
+    from flowhigh_amd import synth
+    from oracle import ref_cpu
+    secs = 2.0
+    audio = synth.lowres_clip(0, secs, SR_IN)
+    noise = synth.prior_noise(0, int(secs * 100))
+    # torch's intra-op pool degrades badly past a few dozen threads on these small convs (256 threads
+    # on the GPU box's host: 50x slower than 16), so the baseline uses at most 16 threads and says so.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(16, avail))
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    ref_cpu.generate(sd, cfg, synth.lowres_clip(1, 0.25, SR_IN), SR_IN, synth.prior_noise(1, 25), STEPS_ODE, METHOD)
+    probe = time.perf_counter() - t0
+    if probe * 8 > 40.0:                    # keep the baseline leg bounded (~10-30 s of CPU work)
+        secs = 0.5
+        audio, noise = synth.lowres_clip(0, secs, SR_IN), synth.prior_noise(0, int(secs * 100))
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        ref_cpu.generate(sd, cfg, audio, SR_IN, noise, STEPS_ODE, METHOD)
+        times.append(time.perf_counter() - t0)
+    return {"value": round(secs / min(times), 4), "unit": "audio-seconds/s", "cores": threads, "kind": "port",
+            "sample": f"one {secs:g} s clip of the 10 s workload, same weights and path, best of 2, "
+                      f"{threads} torch threads of {avail} visible host CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from flowhigh_amd import FLowHigh, FlowHighSR, synth
+    cfg = synth.SYNTH_CFG
+    sd = synth.make_state_dict(cfg, 0)
+    model = FlowHighSR(FLowHigh(sd, cfg, dev), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
+    B = args.batch
+    n_frames = int(SECS * 100)
+    clips = [synth.lowres_clip(rank * B + i, SECS, SR_IN) for i in range(B)]
+    x = torch.stack([torch.from_numpy(c) for c in clips]).to(dev)
+    noise = torch.cat([synth.prior_noise(rank * B + i, n_frames) for i in range(B)], 0).to(dev).contiguous()
+
+    def step():
+        return model.generate_from_device(x, SR_IN, STEPS_ODE, noise=noise)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    voc = model.flowhigh.vocoder
+    voc.conv_timing = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events, voc.conv_timing = voc.conv_timing, None
+    assert tuple(out.shape) == (B, int(SECS * 48000)) and bool(torch.isfinite(out).all())
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    conv_ms = sum(a.elapsed_time(b) for a, b in events)            # all conv launches of all timed steps
+    n_launch = len(events)
+    flops_per_step = voc.conv_flops_per_frame() * n_frames * B
+    avg_launch_s = conv_ms / 1e3 / max(n_launch, 1)
+    flops_per_launch = flops_per_step * args.steps / max(n_launch, 1)
+    achieved = flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+
+    if rank == 0:
+        traffic = None
+        pmc = ROOT / "profiles" / "conv_hbm_bytes_per_launch.json"
+        if pmc.exists():
+            traffic = json.loads(pmc.read_text()).get("bytes_per_launch")
+        line = {
+            "metric": "48 kHz audio-seconds/sec (real-time factor), 12->48 kHz, 10 s clips",
+            "value": round(world * B * SECS * args.steps / elapsed, 3),
+            "unit": "audio-seconds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"B={B} per GPU x 10 s clip, 12->48 kHz, time_step=1 euler, transformer 2x16x64, "
+                                   "BigVGAN-48k-256band SYNTH-CFG (rates 5,4,3,2,2,2; C0 1536), random-init weights",
+                       "clips_per_gpu": B, "frames_per_clip": n_frames, "parallelism": f"clip-sharded x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all grouped conv launches of BigVGAN)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "launches_per_step": n_launch // max(args.steps, 1),
+                         "avg_launch_us": round(avg_launch_s * 1e6, 2),
+                         "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                         "conv_ms_per_step": round(conv_ms / max(args.steps, 1), 3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(sd, cfg)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,21 +4,24 @@
 // (/root/reference/src/flowhigh/models/bigvgan/models.py:63-72,172-194).
 //
 // GEMM view per group:  D[co, n] = sum_{seg} sum_{tap} sum_{ci} W[tap, ci, co] * X[ci, n + off(tap)]
-//   M = output channels, N = time positions, K = (segment, tap, input channel).
+//   M = output channels, N = time positions, K = (segment, channel chunk, tap, channel).
 // v_mfma_f32_32x32x2_f32: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
 // D reg r of lane l = D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]  (exact fp32, fma chain).
 //
 // Block = 4 waves, tile BM x BN = (32 MT WM) x (32 NT WN).  K is walked in steps of
-// (8 input channels) x (one tap):
-//   * the 8-channel input slab [8][BN + halo] is staged in LDS once per channel chunk and every
-//     tap reads it at a shifted column (the B fragment of a tap is a shifted ds_read_b32, lanes
-//     on consecutive addresses: conflict free);
-//   * the weight tile [BM][8] of that (chunk, tap) is a contiguous 32*BM-byte block of the packed
-//     weights; rows are padded to 12 floats in LDS so that one ds_read_b128 per lane (conflict
-//     free: start bank 4 (3 i mod 16)) yields the A values of four k-steps.  K order inside a chunk
-//     is permuted (k-step e pairs channels e and 4 + e); A and B use the same permutation.
-//   * both are double buffered: global loads of step i+1 are issued before the MFMAs of step i
-//     and written to the other LDS buffer after them; one barrier per step.
+// (CK input channels) x (one tap), CK = 16 (or 8 when cin % 16 != 0):
+//   * the CK-channel input slab [CK][BN + halo] is staged in LDS once per channel chunk and every
+//     tap reads it at a shifted column (the B fragment of a tap is a shifted ds_read_b32, lanes on
+//     consecutive addresses: conflict free).  Rows are fetched with raw buffer loads whose
+//     descriptor spans exactly one (batch, channel) row, so the conv's zero padding is the
+//     hardware's out-of-range-returns-0 (no per-element branches);
+//   * the weight tile [BM][CK] of a (chunk, tap) is a contiguous block of the packed weights; rows
+//     are padded to CK + 4 floats in LDS so that one ds_read_b128 per lane (conflict free) yields
+//     the A values of four k-steps.  K order inside a chunk is permuted (k-step (q, e) pairs
+//     channels 8q + e and 8q + 4 + e); A and B use the same permutation;
+//   * both are double buffered: loads of step i+1 are issued before the MFMAs of step i and
+//     written to the other LDS buffer after them; one barrier per step (CK/2 * MT * NT MFMAs per
+//     wave).  The tap offset of step i+1 is fetched (scalar) during step i.
 // Block -> work mapping is XCD aware: blocks with equal (id mod 8) share an L2; the n-tiles of one
 // (group, batch, co-tile) panel are dealt to one XCD in runs of 8, so the weight tiles they share
 // are fetched into that L2 once.
@@ -26,53 +29,88 @@
 
 namespace {
 
-constexpr int WP = 12;          // LDS pitch of a weight row (8 channels + 4 pad), floats
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT_RUN = 8;       // n-tiles of a panel that run together on one XCD
 
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, int CK>
 struct ConvCfg {
   static constexpr int BM = 32 * MT * WM;
   static constexpr int BN = 32 * NT * WN;
-  static constexpr int XW = BN + FH_CONV_MAX_HALO;     // staged columns per channel
-  static constexpr int XREG = (XW + 31) / 32;          // staging registers per thread (x slab)
-  static constexpr int WREG = (BM * 2 + 255) / 256;    // staging float4s per thread (weight tile)
-  static constexpr int LDS_FLOATS = 2 * BM * WP + 2 * 8 * XW;
+  static constexpr int WP = CK + 4;                      // LDS pitch of a weight row, floats
+  static constexpr int XW = BN + FH_CONV_MAX_HALO;       // staged columns per channel
+  static constexpr int XROWS = CK / 4;                   // rows staged by each wave
+  static constexpr int XREG = (XW + 63) / 64;            // dwords per lane per row
+  static constexpr int WF4 = BM * CK / 4;                // float4s in a weight tile
+  static constexpr int WREG = (WF4 + 255) / 256;
+  static constexpr int LDS_FLOATS = 2 * BM * WP + 2 * CK * XW;
 };
 
-template <int MT, int NT, int WM, int WN>
+// Wave-uniform values the compiler cannot prove uniform (anything loaded through a selected
+// pointer) are pinned to SGPRs with readfirstlane, so that buffer descriptors built from them
+// do not get wrapped in waterfall loops.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const float* uni(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+struct SegU {          // wave-uniform copy of the hot fields of one fh_conv_seg
+  const float* x;
+  const float* w;
+  int cin, ntaps, off_min;
+};
+__device__ __forceinline__ SegU load_seg(const fh_conv_seg* S) {
+  SegU u;
+  u.x = uni(S->x);
+  u.w = uni(S->w);
+  u.cin = uni(S->cin);
+  u.ntaps = uni(S->ntaps);
+  u.off_min = uni(S->off_min);
+  return u;
+}
+
+template <int MT, int NT, int WM, int WN, int CK>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __restrict__ groups,
                                                         int n_groups, int batch, int co_tiles,
                                                         int n_tiles) {
-  using Cfg = ConvCfg<MT, NT, WM, WN>;
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, XW = Cfg::XW, XREG = Cfg::XREG, WREG = Cfg::WREG;
-  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  using Cfg = ConvCfg<MT, NT, WM, WN, CK>;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, XW = Cfg::XW, WP = Cfg::WP;
+  constexpr int XROWS = Cfg::XROWS, XREG = Cfg::XREG, WREG = Cfg::WREG, KQ = CK / 8;
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS + FH_CONV_MAX_SEG * FH_CONV_MAX_TAPS];
   float* ws = lds;
   float* xs = lds + 2 * BM * WP;
+  int* toff = reinterpret_cast<int*>(lds + Cfg::LDS_FLOATS);   // [seg][tap] column shift of each tap
 
   // ---- block -> (panel, n tile); panels = (group, batch, co tile), heavy groups first ----
   const int panels = n_groups * batch * co_tiles;
   const int runs_per_panel = (n_tiles + NT_RUN - 1) / NT_RUN;
   const int total_runs = panels * runs_per_panel;
   const int bid = blockIdx.x;
-  const int xcd = bid & 7;
   const int slot = bid >> 3;
-  const int run = (slot / NT_RUN) * 8 + xcd;
+  const int run = (slot / NT_RUN) * 8 + (bid & 7);
   if (run >= total_runs) return;
-  const int panel = run / runs_per_panel;
-  const int ntile = (run % runs_per_panel) * NT_RUN + (slot % NT_RUN);
+  // (runtime integer divisions are done on the VALU: pin the results back to SGPRs)
+  const int panel = uni(run / runs_per_panel);
+  const int ntile = uni((run % runs_per_panel) * NT_RUN + (slot % NT_RUN));
   if (ntile >= n_tiles) return;
-  const int cot = panel % co_tiles;
-  const int gb = panel / co_tiles;
-  const int b = gb % batch;
-  const fh_conv_group& G = groups[gb / batch];
+  const int cot = uni(panel % co_tiles);
+  const int gb = uni(panel / co_tiles);
+  const int b = uni(gb % batch);
+  const fh_conv_group* __restrict__ G = groups + uni(gb / batch);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int co0 = cot * BM;
   const int n0 = ntile * BN;
+  const int lin = uni(G->lin), cout_pad = uni(G->cout_pad), nseg = uni(G->nseg);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -82,146 +120,194 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging registers
-  f32x4 wreg[WREG];
-  float xreg[XREG];
-  const int xrow = tid >> 5;      // channel row (0..7) this thread stages
-  const int xcol = tid & 31;
+  // total number of (chunk, tap) steps over all segments
+  int nsteps = 0;
+  for (int s = 0; s < nseg; ++s) nsteps += uni((G->seg[s].cin / CK) * G->seg[s].ntaps);
 
-  // ---- loaders -------------------------------------------------------------------------
-  auto load_w = [&](const fh_conv_seg& S, int chunk, int tap) {
-    const float* wp = S.w + ((size_t)(chunk * S.ntaps + tap) * G.cout_pad + co0) * 8;
+  // tap shifts relative to the staged slab, read back (LDS broadcast) one step ahead of their use
+  if (tid < FH_CONV_MAX_SEG * FH_CONV_MAX_TAPS) {
+    const fh_conv_seg* sg = &G->seg[tid / FH_CONV_MAX_TAPS];
+    toff[tid] = (tid / FH_CONV_MAX_TAPS) < nseg ? sg->tap_off[tid % FH_CONV_MAX_TAPS] - sg->off_min : 0;
+  }
+
+  u32x4 wreg[WREG];
+  unsigned xreg[XROWS][XREG];
+
+  // ---- loaders (all addresses wave-uniform base + per-lane 32-bit offset) -------------------
+  auto load_w = [&](const SegU& S, int chunk, int tap) {
+    const float* wp = uni(S.w + ((size_t)(chunk * S.ntaps + tap) * cout_pad + co0) * CK);
+    __amdgpu_buffer_rsrc_t r = make_rsrc(wp, BM * CK * 4);
 #pragma unroll
     for (int i = 0; i < WREG; ++i) {
-      int f = tid + 256 * i;
-      if (f < BM * 2) wreg[i] = *reinterpret_cast<const f32x4*>(wp + 4 * f);
+      const int f = tid + 256 * i;            // beyond the tile: out of range -> 0, never stored
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(r, f * 16, 0, 0);
     }
   };
   auto store_w = [&](int buf) {
     float* dst = ws + buf * BM * WP;
 #pragma unroll
     for (int i = 0; i < WREG; ++i) {
-      int f = tid + 256 * i;
-      if (f < BM * 2) *reinterpret_cast<f32x4*>(dst + (f >> 1) * WP + 4 * (f & 1)) = wreg[i];
+      const int f = tid + 256 * i;
+      if (f < Cfg::WF4) *reinterpret_cast<u32x4*>(dst + (f / (CK / 4)) * WP + 4 * (f % (CK / 4))) = wreg[i];
     }
   };
-  auto load_x = [&](const fh_conv_seg& S, int chunk) {
-    const float* xp = S.x + ((size_t)b * S.cin + chunk * 8 + xrow) * G.lin;
+  auto load_x = [&](const SegU& S, int chunk) {
     const int t0 = n0 + S.off_min;
-    const int width = BN + S.off_max - S.off_min;
 #pragma unroll
-    for (int i = 0; i < XREG; ++i) {
-      int j = xcol + 32 * i;
-      int t = t0 + j;
-      float v = 0.f;
-      if (j < width && t >= 0 && t < G.lin) v = xp[t];
-      xreg[i] = v;
+    for (int rr = 0; rr < XROWS; ++rr) {
+      const float* xp = uni(S.x + ((size_t)b * S.cin + chunk * CK + wave * XROWS + rr) * lin);
+      __amdgpu_buffer_rsrc_t r = make_rsrc(xp, (unsigned)lin * 4u);
+#pragma unroll
+      for (int i = 0; i < XREG; ++i)   // t < 0 wraps to a huge unsigned offset: out of range -> 0
+        xreg[rr][i] = __builtin_amdgcn_raw_buffer_load_b32(r, (t0 + lane + 64 * i) * 4, 0, 0);
     }
   };
   auto store_x = [&](int buf) {
-    float* dst = xs + buf * 8 * XW + xrow * XW;
 #pragma unroll
-    for (int i = 0; i < XREG; ++i) {
-      int j = xcol + 32 * i;
-      if (j < XW) dst[j] = xreg[i];
+    for (int rr = 0; rr < XROWS; ++rr) {
+      float* dst = xs + buf * CK * XW + (wave * XROWS + rr) * XW;
+#pragma unroll
+      for (int i = 0; i < XREG; ++i) {
+        const int j = lane + 64 * i;
+        if (j < XW) dst[j] = __uint_as_float(xreg[rr][i]);
+      }
     }
   };
 
-  // ---- prologue: first (seg 0, chunk 0, tap 0) ---------------------------------------------
-  int s = 0, c = 0, j = 0;
+  // ---- prologue ----------------------------------------------------------------------------
+  SegU S = load_seg(&G->seg[0]);          // segment of the CURRENT step
+  int s_idx = 0, c = 0, j = 0;            // (segment, chunk, tap) of the current step
   int wbuf = 0, xbuf = 0;
-  load_w(G.seg[0], 0, 0);
-  load_x(G.seg[0], 0);
+  load_w(S, 0, 0);
+  load_x(S, 0);
   store_w(0);
   store_x(0);
   __syncthreads();
+  int xoff_cur = toff[0];
 
-  while (true) {
-    const fh_conv_seg& S = G.seg[s];
-    // next step indices
-    int s2 = s, c2 = c, j2 = j + 1;
+  for (int it = 0; it < nsteps; ++it) {
+    // indices of the next step (scalar state)
+    SegU S2 = S;
+    int s2 = s_idx, c2 = c, j2 = j + 1;
     if (j2 == S.ntaps) {
       j2 = 0;
       c2 = c + 1;
-      if (c2 * 8 == S.cin) {
+      if (c2 * CK == S.cin) {
         c2 = 0;
-        s2 = s + 1;
+        s2 = s_idx + 1;
+        if (s2 < nseg) S2 = load_seg(&G->seg[s2]);
       }
     }
-    const bool has_next = s2 < G.nseg;
+    const bool has_next = it + 1 < nsteps;
+    const bool new_x = has_next && j2 == 0;
+    int xoff_next = 0;
     if (has_next) {
-      load_w(G.seg[s2], c2, j2);
-      if (j2 == 0) load_x(G.seg[s2], c2);
+      load_w(S2, c2, j2);
+      xoff_next = toff[s2 * FH_CONV_MAX_TAPS + j2];
     }
+    if (new_x) load_x(S2, c2);
 
     // ---- MFMAs of the current step ----
     {
       const float* wsb = ws + wbuf * BM * WP;
-      const float* xsb = xs + xbuf * 8 * XW;
-      f32x4 a[MT];
+      const float* xsb = xs + xbuf * CK * XW;
+      const int xoff = xoff_cur + wn * NT * 32 + l31;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        a[mt] = *reinterpret_cast<const f32x4*>(wsb + ((wm * MT + mt) * 32 + l31) * WP + 4 * lh);
-      const int xoff = S.tap_off[j] - S.off_min + wn * NT * 32 + l31;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float bf[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = xsb[(4 * lh + e) * XW + xoff + nt * 32];
+      for (int q = 0; q < KQ; ++q) {
+        f32x4 a[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
+          a[mt] = *reinterpret_cast<const f32x4*>(wsb + ((wm * MT + mt) * 32 + l31) * WP + 4 * (2 * q + lh));
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], bf[nt], acc[mt][nt], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          float bf[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = xsb[(8 * q + 4 * lh + e) * XW + xoff + nt * 32];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
       }
     }
 
-    if (!has_next) break;
-    store_w(wbuf ^ 1);
-    if (j2 == 0) store_x(xbuf ^ 1);
+    if (has_next) store_w(wbuf ^ 1);
+    if (new_x) store_x(xbuf ^ 1);
     __syncthreads();
     wbuf ^= 1;
-    if (j2 == 0) xbuf ^= 1;
-    s = s2;
+    if (new_x) xbuf ^= 1;
+    S = S2;
+    s_idx = s2;
     c = c2;
     j = j2;
+    xoff_cur = xoff_next;
   }
 
   // ---- epilogue: bias + residuals, scale, strided store -------------------------------------
-  const int nres = G.nres;
-  const float scale = G.scale;
+  const int nres = G->nres;
+  const float scale = G->scale;
+  const int cout = G->cout, lout = G->lout, n_len = G->n_len;
+  const int ostride = G->out_stride, ophase = G->out_phase;
+  const float* __restrict__ bias = G->bias;
+  const float* __restrict__ r0 = nres > 0 ? G->res[0] : nullptr;
+  const float* __restrict__ r1 = nres > 1 ? G->res[1] : nullptr;
+  const float* __restrict__ r2 = nres > 2 ? G->res[2] : nullptr;
+  float* __restrict__ out = G->out;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (co >= G.cout) continue;
-      const float bv = G.bias ? G.bias[co] : 0.f;
-      const size_t rowbase = ((size_t)b * G.cout + co) * G.lout;
+    for (int g4 = 0; g4 < 4; ++g4) {
+      // four consecutive output channels (regs 4 g4 .. 4 g4 + 3) at NT column tiles: gather the
+      // residual loads first so they are all in flight together
+      float v[4][NT];
+      size_t idx[4][NT];
+      bool ok[4][NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + (wn * NT + nt) * 32 + l31;
-        if (n >= G.n_len) continue;
-        const size_t idx = rowbase + (size_t)n * G.out_stride + G.out_phase;
-        float v = acc[mt][nt][r] + bv;
-        for (int q = 0; q < nres; ++q) v += G.res[q][idx];
-        G.out[idx] = v * scale;
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = co0 + (wm * MT + mt) * 32 + rr + 8 * g4 + 4 * lh;
+        const float bv = (bias && co < cout) ? bias[co] : 0.f;
+        const size_t rowbase = ((size_t)b * cout + co) * lout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = n0 + (wn * NT + nt) * 32 + l31;
+          ok[rr][nt] = co < cout && n < n_len;
+          idx[rr][nt] = rowbase + (size_t)n * ostride + ophase;
+          v[rr][nt] = acc[mt][nt][4 * g4 + rr] + bv;
+        }
       }
+      if (r0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            if (ok[rr][nt]) {
+              float t = r0[idx[rr][nt]];
+              if (r1) t += r1[idx[rr][nt]];
+              if (r2) t += r2[idx[rr][nt]];
+              v[rr][nt] += t;
+            }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (ok[rr][nt]) out[idx[rr][nt]] = v[rr][nt] * scale;
     }
   }
 }
 
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, int CK>
 int launch_conv(const fh_conv_group* groups, int n_groups, int batch, int cout_pad, int n_len,
                 hipStream_t stream) {
-  using Cfg = ConvCfg<MT, NT, WM, WN>;
+  using Cfg = ConvCfg<MT, NT, WM, WN, CK>;
   const int co_tiles = cout_pad / Cfg::BM;
   const int n_tiles = fh_cdiv(n_len, Cfg::BN);
   const long long panels = (long long)n_groups * batch * co_tiles;
   const long long runs = panels * fh_cdiv(n_tiles, NT_RUN);
   const long long blocks = (long long)fh_cdiv(runs, 8) * 8 * NT_RUN;
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_grouped_f32: grid too large");
-  hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, stream,
+  hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WM, WN, CK>), dim3((unsigned)blocks), dim3(256), 0, stream,
                      groups, n_groups, batch, co_tiles, n_tiles);
   FH_CHECK_LAUNCH("fh_conv_grouped_f32");
   return FH_OK;
@@ -253,45 +339,38 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __rest
   out[(size_t)b * len + t] = tanhf(acc);
 }
 
+struct TileInfo { int bm, bn; };
+constexpr TileInfo kTiles[] = {{128, 128}, {192, 128}, {96, 256}, {64, 256}, {32, 512}, {128, 64}};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
 }  // namespace
 
 extern "C" int fh_sizeof_conv_group(void) { return (int)sizeof(fh_conv_group); }
 
-extern "C" int fh_conv_tile_m(int cfg) {
-  switch (cfg) {
-    case 0: return 128;
-    case 1: return 192;
-    case 2: return 96;
-    case 3: return 64;
-    case 4: return 32;
-  }
-  return -1;
-}
-extern "C" int fh_conv_tile_n(int cfg) {
-  switch (cfg) {
-    case 0: return 128;
-    case 1: return 128;
-    case 2: return 256;
-    case 3: return 256;
-    case 4: return 512;
-  }
-  return -1;
-}
+extern "C" int fh_conv_tile_m(int cfg) { return (cfg >= 0 && cfg < kNumTiles) ? kTiles[cfg].bm : -1; }
+extern "C" int fh_conv_tile_n(int cfg) { return (cfg >= 0 && cfg < kNumTiles) ? kTiles[cfg].bn : -1; }
 
 extern "C" int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch,
-                                   int cout_pad, int n_len, int tile_cfg, void* stream) {
+                                   int cout_pad, int n_len, int tile_cfg, int ck, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && n_len > 0, "fh_conv_grouped_f32: bad sizes");
   const int bm = fh_conv_tile_m(tile_cfg);
   FH_CHECK_ARG(bm > 0, "fh_conv_grouped_f32: unknown tile_cfg %d", tile_cfg);
   FH_CHECK_ARG(cout_pad % bm == 0, "fh_conv_grouped_f32: cout_pad %d not a multiple of tile %d", cout_pad, bm);
+  FH_CHECK_ARG(ck == 8 || ck == 16, "fh_conv_grouped_f32: channel chunk must be 8 or 16 (got %d)", ck);
   hipStream_t st = (hipStream_t)stream;
+#define FH_CONV_CASE(id, MT, NT, WM, WN)                                                            \
+  case id:                                                                                          \
+    return ck == 16 ? launch_conv<MT, NT, WM, WN, 16>(groups, n_groups, batch, cout_pad, n_len, st) \
+                    : launch_conv<MT, NT, WM, WN, 8>(groups, n_groups, batch, cout_pad, n_len, st);
   switch (tile_cfg) {
-    case 0: return launch_conv<2, 2, 2, 2>(groups, n_groups, batch, cout_pad, n_len, st);
-    case 1: return launch_conv<3, 2, 2, 2>(groups, n_groups, batch, cout_pad, n_len, st);
-    case 2: return launch_conv<3, 2, 1, 4>(groups, n_groups, batch, cout_pad, n_len, st);
-    case 3: return launch_conv<2, 2, 1, 4>(groups, n_groups, batch, cout_pad, n_len, st);
-    case 4: return launch_conv<1, 4, 1, 4>(groups, n_groups, batch, cout_pad, n_len, st);
+    FH_CONV_CASE(0, 2, 2, 2, 2)
+    FH_CONV_CASE(1, 3, 2, 2, 2)
+    FH_CONV_CASE(2, 3, 2, 1, 4)
+    FH_CONV_CASE(3, 2, 2, 1, 4)
+    FH_CONV_CASE(4, 1, 4, 1, 4)
+    FH_CONV_CASE(5, 2, 1, 2, 2)
   }
+#undef FH_CONV_CASE
   return FH_E_ARG;
 }
 

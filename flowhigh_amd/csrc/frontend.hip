@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
   const int j = blockIdx.x * 256 + threadIdx.x;
   float v = 0.f;
   if (j < len) {
-    const int avail = hop * (n_frames - 1);      // samples torch.istft can reconstruct after the trim
+    const int avail = hop * (n_frames - 1) + nfft / 2;   // torch.istft zero-fills past the OLA signal's end
     if (j < avail) {
       const int p = j + nfft / 2;
       int t_hi = p / hop;

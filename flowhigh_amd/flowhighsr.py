@@ -233,6 +233,16 @@ class FlowHighSR:
         return out
 
     @torch.no_grad()
+    def generate_from_device(self, x, sr, timestep=1, *, noise):
+        """Device-resident variant (no host work, no sync; graph-capturable): x [B, T_in] float32
+        low-rate clips already in HBM (|x| <= 1), noise [B, N, n_mels] -> [B, T48].  Same
+        arithmetic as generate_batch with upsampling_method='hip'."""
+        cond = self.resampler(x, sr, 48000)
+        kw = dict(std_2=1.) if self.cfm_method == 'independent_cfm_adaptive' else {}
+        wav = self.sample(cond=cond, time_steps=timestep, cfm_method=self.cfm_method, noise=noise, **kw).squeeze(1)
+        return self.postproc(wav, cond, cond.size(-1))
+
+    @torch.no_grad()
     def generate(self, audio, sr: int, target_sampling_rate=48000, timestep=1, *, noise=None, generator=None):
         """One clip, reference contract: returns float32 [1, T48] on the model device."""
         return self.generate_batch([audio], sr, target_sampling_rate, timestep, noise=noise, generator=generator)

@@ -49,13 +49,18 @@ def fold_weight_norm(sd):
     return out
 
 
-def pack_conv_weight(w, cout_pad):
-    """Conv1d weight [co, ci, k] -> [ci/8, k, cout_pad, 8] (zero padded rows)."""
+def pick_ck(*cins):
+    """Channel chunk of the K loop: 16 when every segment allows it, else 8."""
+    return 16 if all(c % 16 == 0 for c in cins) else 8
+
+
+def pack_conv_weight(w, cout_pad, ck=8):
+    """Conv1d weight [co, ci, k] -> [ci/ck, k, cout_pad, ck] (zero padded rows)."""
     co, ci, k = w.shape
-    if ci % 8:
-        raise ValueError(f"input channels {ci} must be a multiple of 8")
-    p = torch.zeros(ci // 8, k, cout_pad, 8, dtype=torch.float32)
-    p[:, :, :co, :] = w.float().reshape(co, ci // 8, 8, k).permute(1, 3, 0, 2)
+    if ci % ck:
+        raise ValueError(f"input channels {ci} must be a multiple of {ck}")
+    p = torch.zeros(ci // ck, k, cout_pad, ck, dtype=torch.float32)
+    p[:, :, :co, :] = w.float().reshape(co, ci // ck, ck, k).permute(1, 3, 0, 2)
     return p.contiguous()
 
 
@@ -103,10 +108,10 @@ def make_act_group(x, y, p):
 
 
 
-def conv_grouped(groups, batch, cout_pad, n_len, tile_cfg, device):
+def conv_grouped(groups, batch, cout_pad, n_len, tile_cfg, device, ck=8):
     """Upload descriptors and enqueue one grouped conv launch (test / one-off use)."""
     d = hip.to_device_struct_array(groups, device)
-    hip.check(hip.lib().fh_conv_grouped_f32(d.data_ptr(), len(groups), batch, cout_pad, n_len, tile_cfg,
+    hip.check(hip.lib().fh_conv_grouped_f32(d.data_ptr(), len(groups), batch, cout_pad, n_len, tile_cfg, ck,
                                             hip.stream()), "fh_conv_grouped_f32")
     return d
 
@@ -167,19 +172,21 @@ class Vocoder:
 
         # conv_pre
         self.pre_cfg, _, self.pre_cpad = pick_tile_cfg(self.c0)
-        self.pre_w = pack_conv_weight(g("conv_pre.weight"), self.pre_cpad).to(dev)
+        self.pre_ck = pick_ck(self.num_mels)
+        self.pre_w = pack_conv_weight(g("conv_pre.weight"), self.pre_cpad, self.pre_ck).to(dev)
         self.pre_b = g("conv_pre.bias").to(dev)
         self.stages = []
         for i, (u, k) in enumerate(zip(self.rates, self.up_k)):
             c = self.chans[i]
             tcfg, bm, cpad = pick_tile_cfg(c)
-            st = dict(c=c, cin=self.c0 // (2 ** i), u=u, k=k, tile_cfg=tcfg, cpad=cpad)
+            st = dict(c=c, cin=self.c0 // (2 ** i), u=u, k=k, tile_cfg=tcfg, cpad=cpad,
+                      ck=pick_ck(c), up_ck=pick_ck(self.c0 // (2 ** i)))
             wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
             st["up_b"] = g(f"ups.{i}.0.bias").to(dev)
             st["up_phases"] = []
             for taps in transposed_conv_phases(k, u):
                 wsel = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1)        # [cin, c, nt]
-                st["up_phases"].append(dict(w=pack_conv_weight(wsel.permute(1, 0, 2), cpad).to(dev),
+                st["up_phases"].append(dict(w=pack_conv_weight(wsel.permute(1, 0, 2), cpad, st["up_ck"]).to(dev),
                                             offs=[o for _, o in taps]))
             st["blocks"] = []
             for j in range(self.nk):
@@ -187,7 +194,7 @@ class Vocoder:
                 blk = dict(k=self.ks[j], dil=self.dil[j], c1=[], c2=[], acts=[])
                 for m in range(self.nm):
                     for tag, lst in (("convs1", blk["c1"]), ("convs2", blk["c2"])):
-                        lst.append(dict(w=pack_conv_weight(g(f"resblocks.{r}.{tag}.{m}.weight"), cpad).to(dev),
+                        lst.append(dict(w=pack_conv_weight(g(f"resblocks.{r}.{tag}.{m}.weight"), cpad, st["ck"]).to(dev),
                                         b=g(f"resblocks.{r}.{tag}.{m}.bias").to(dev)))
                 for a in range(2 * self.nm):
                     blk["acts"].append(act_params(f"resblocks.{r}.activations.{a}."))
@@ -200,6 +207,18 @@ class Vocoder:
         self.post_b = g("conv_post.bias").to(dev)
         self.post_k = self.post_w.shape[-1]
         self._plans = {}
+        self.conv_timing = None
+
+    def conv_flops_per_frame(self):
+        """Algorithmic FLOPs of the MFMA conv launches per mel frame (SURVEY.md 8d formula:
+        2 * Cout * Cin * k per output sample; conv_post and the activations are not included)."""
+        f = 2.0 * self.c0 * self.num_mels * 7
+        length = 1
+        for i, st in enumerate(self.stages):
+            f += 2.0 * st["cin"] * st["c"] * st["k"] * length          # transposed conv: per INPUT sample
+            length *= st["u"]
+            f += length * st["c"] ** 2 * 2.0 * 2 * self.nm * sum(self.ks)
+        return f
 
     def plan(self, batch, n_frames):
         key = (batch, n_frames)
@@ -212,10 +231,14 @@ class Vocoder:
         keep = []           # tensors that must stay alive
         L = N
 
-        def conv_step(groups, cpad, n_len, tcfg):
+        def conv_step(groups, cpad, n_len, tcfg, ck):
+            # few-block launches (first-stage upsampler, fused stage-closing conv at short
+            # sequence lengths) switch from the 128x128 to the 128x64 tile to fill the 256 CUs
+            if tcfg == 0 and len(groups) * B * (cpad // 128) * -(-n_len // 128) < 512:
+                tcfg = 5
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
-            steps.append(("conv", d, len(groups), cpad, n_len, tcfg))
+            steps.append(("conv", d, len(groups), cpad, n_len, tcfg, ck))
 
         def act_step(groups, c, length):
             d = hip.to_device_struct_array(groups, dev)
@@ -226,7 +249,7 @@ class Vocoder:
         pre = torch.empty(B, self.c0, N, **f32)
         k7 = [j - 3 for j in range(7)]
         conv_step([make_conv_group([make_conv_seg(mel_in, self.pre_w, self.num_mels, k7)], self.pre_b, [],
-                                    pre, self.c0, self.pre_cpad, N, N, N)], self.pre_cpad, N, self.pre_cfg)
+                                    pre, self.c0, self.pre_cpad, N, N, N)], self.pre_cpad, N, self.pre_cfg, self.pre_ck)
         cur = pre
         max_elems = max(st["c"] * N * math.prod(self.rates[:i + 1]) for i, st in enumerate(self.stages))
         nbuf = 2 + 4 * self.nk
@@ -241,7 +264,7 @@ class Vocoder:
             groups = [make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X,
                                        c, cpad, lin, L, lin, stride=u, phase=r)
                       for r, ph in enumerate(st["up_phases"])]
-            conv_step(groups, cpad, lin, tcfg)
+            conv_step(groups, cpad, lin, tcfg, st["up_ck"])
             # heavy kernel sizes first (dispatch order == launch order of the panels)
             order = sorted(range(self.nk), key=lambda j: -st["blocks"][j]["k"])
             T1 = [view(2 + 4 * j) for j in range(self.nk)]
@@ -258,7 +281,7 @@ class Vocoder:
                     offs = [(t - (k - 1) // 2) * d for t in range(k)]
                     groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
                                                    blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
-                conv_step(groups, cpad, L, tcfg)
+                conv_step(groups, cpad, L, tcfg, st["ck"])
                 act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L)
                 if not last:
                     groups = []
@@ -269,7 +292,7 @@ class Vocoder:
                         out = Y[j][m % 2]
                         groups.append(make_conv_group([make_conv_seg(T1[j], blk["c2"][m]["w"], c, offs)],
                                                        blk["c2"][m]["b"], [xin[j]], out, c, cpad, L, L, L))
-                    conv_step(groups, cpad, L, tcfg)
+                    conv_step(groups, cpad, L, tcfg, st["ck"])
                     xin = [Y[j][m % 2] for j in range(self.nk)]
                 else:
                     segs = []
@@ -278,7 +301,7 @@ class Vocoder:
                         k = blk["k"]
                         segs.append(make_conv_seg(T1[j], blk["c2"][m]["w"], c, [t - (k - 1) // 2 for t in range(k)]))
                     conv_step([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L,
-                                                scale=1.0 / self.nk)], cpad, L, tcfg)
+                                                scale=1.0 / self.nk)], cpad, L, tcfg, st["ck"])
             # Slot roles repeat every stage: the next up-conv reads S (slot 1) and writes the new X
             # (slot 0); slot 1 is rewritten only by that stage's last launch, after its readers.
             cur = S
@@ -303,10 +326,17 @@ class Vocoder:
         L = hip.lib()
         st = hip.stream()
         B = p["B"]
+        timing = self.conv_timing          # optional list of (start, end) events around conv launches
         for s in p["steps"]:
             if s[0] == "conv":
-                _, d, ng, cpad, n_len, tcfg = s
-                hip.check(L.fh_conv_grouped_f32(d.data_ptr(), ng, B, cpad, n_len, tcfg, st), "fh_conv_grouped_f32")
+                _, d, ng, cpad, n_len, tcfg, ck = s
+                if timing is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                hip.check(L.fh_conv_grouped_f32(d.data_ptr(), ng, B, cpad, n_len, tcfg, ck, st), "fh_conv_grouped_f32")
+                if timing is not None:
+                    e1.record()
+                    timing.append((e0, e1))
             elif s[0] == "act":
                 _, d, ng, c, length = s
                 hip.check(L.fh_act1d_grouped_f32(d.data_ptr(), ng, B, c, length, st), "fh_act1d_grouped_f32")

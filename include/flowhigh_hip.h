@@ -46,8 +46,9 @@ const char* fh_last_error(void);
  *                   sum_seg sum_tap sum_ci  w_seg[tap, ci, co] * x_seg[b, ci, n + tap_off[tap]] )
  * with x read as 0 outside [0, lin).
  *
- * Packed weights: float [cin/8][ntaps][cout_pad][8], cout_pad = cout rounded up to the
- * tile height of `tile_cfg` (fh_conv_tile_m), zero padded.  cin % 8 == 0.
+ * Packed weights: float [cin/ck][ntaps][cout_pad][ck], ck = channel chunk (16, or 8 when some
+ * cin % 16 != 0), cout_pad = cout rounded up to the tile height of `tile_cfg` (fh_conv_tile_m),
+ * zero padded.  cin % ck == 0 for every segment.
  * --------------------------------------------------------------------------------- */
 #define FH_CONV_MAX_TAPS 16
 #define FH_CONV_MAX_SEG 3
@@ -81,12 +82,12 @@ typedef struct {
 } fh_conv_group;
 
 int fh_sizeof_conv_group(void);
-/* tile_cfg: 0 = 128x128, 1 = 192x128, 2 = 96x256, 3 = 64x256, 4 = 32x512 (co x n) */
+/* tile_cfg: 0 = 128x128, 1 = 192x128, 2 = 96x256, 3 = 64x256, 4 = 32x512, 5 = 128x64 (co x n) */
 int fh_conv_tile_m(int tile_cfg);
 int fh_conv_tile_n(int tile_cfg);
 /* groups: device array of n_groups descriptors; all groups share cout_pad and n_len. */
 int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch, int cout_pad,
-                        int n_len, int tile_cfg, void* stream);
+                        int n_len, int tile_cfg, int ck, void* stream);
 
 /* conv_post + tanh (models/bigvgan/models.py:190-192): x [B, cin, L], w [cin, ksz], bias[1]
  * -> out [B, L] = tanh(bias + sum_ci sum_j w[ci,j] * x[b, ci, t + j - ksz/2]).  ksz odd <= 15. */

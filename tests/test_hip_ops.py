@@ -29,29 +29,31 @@ def maxdiff(a, b):
 # ------------------------------------------------------------------------------------------
 # grouped implicit-GEMM conv
 # ------------------------------------------------------------------------------------------
-def run_conv(x, w, bias, dilation, tile_cfg, res=None, scale=1.0):
+def run_conv(x, w, bias, dilation, tile_cfg, res=None, scale=1.0, ck=None):
     B, cin, L = x.shape
     cout, _, k = w.shape
     bm = hip.lib().fh_conv_tile_m(tile_cfg)
     cpad = -(-cout // bm) * bm
     xd, out = x.to(DEV), torch.full((B, cout, L), float("nan"), device=DEV)
-    wp = V.pack_conv_weight(w, cpad).to(DEV)
+    ck = ck or V.pick_ck(cin)
+    wp = V.pack_conv_weight(w, cpad, ck).to(DEV)
     bd = bias.to(DEV) if bias is not None else None
     rd = [r.to(DEV) for r in (res or [])]
     offs = [(t - (k - 1) // 2) * dilation for t in range(k)]
     g = V.make_conv_group([V.make_conv_seg(xd, wp, cin, offs)], bd, rd, out, cout, cpad, L, L, L, scale=scale)
-    keep = V.conv_grouped([g], B, cpad, L, tile_cfg, DEV)
+    keep = V.conv_grouped([g], B, cpad, L, tile_cfg, DEV, ck)
     torch.cuda.synchronize()
     del keep
     return out.cpu()
 
 
-@pytest.mark.parametrize("tile_cfg", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("cin,cout,k,d,L", [(16, 24, 7, 3, 300), (8, 8, 3, 1, 33), (24, 200, 11, 5, 1111)])
-def test_conv_plain(tile_cfg, cin, cout, k, d, L):
+@pytest.mark.parametrize("tile_cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cin,cout,k,d,L,ck", [(16, 24, 7, 3, 300, 16), (16, 24, 7, 3, 300, 8), (8, 8, 3, 1, 33, 8),
+                                               (24, 200, 11, 5, 1111, 8), (48, 40, 11, 5, 1111, 16)])
+def test_conv_plain(tile_cfg, cin, cout, k, d, L, ck):
     x, w, b = rnd(2, cin, L, seed=1), rnd(cout, cin, k, seed=2, scale=0.2), rnd(cout, seed=3)
     ref = F.conv1d(x, w, b, dilation=d, padding=(k * d - d) // 2)
-    got = run_conv(x, w, b, d, tile_cfg)
+    got = run_conv(x, w, b, d, tile_cfg, ck=ck)
     assert maxdiff(got, ref) <= 2e-5          # K <= 2200 fp32 products, |terms| ~ 0.2
 
 
@@ -80,11 +82,11 @@ def test_conv_transpose_as_phase_groups(u, k):
     groups, keep = [], []
     for r, taps in enumerate(V.transposed_conv_phases(k, u)):
         wsel = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1).permute(1, 0, 2)
-        wp = V.pack_conv_weight(wsel, cpad).to(DEV)
+        wp = V.pack_conv_weight(wsel, cpad, 16).to(DEV)
         keep.append(wp)
         groups.append(V.make_conv_group([V.make_conv_seg(xd, wp, cin, [o for _, o in taps])], bd, [], out,
                                         cout, cpad, L, u * L, L, stride=u, phase=r))
-    keep.append(V.conv_grouped(groups, B, cpad, L, tile_cfg, DEV))
+    keep.append(V.conv_grouped(groups, B, cpad, L, tile_cfg, DEV, 16))
     torch.cuda.synchronize()
     assert maxdiff(out, ref) <= 1e-5
 
@@ -101,11 +103,11 @@ def test_conv_three_segments_fused_average():
     tile_cfg, _, cpad = V.pick_tile_cfg(c)
     out = torch.full((B, c, L), float("nan"), device=DEV)
     xd, rd = [x.to(DEV) for x in xs], [r.to(DEV) for r in rs]
-    wp = [V.pack_conv_weight(w, cpad).to(DEV) for w in ws]
+    wp = [V.pack_conv_weight(w, cpad, 16).to(DEV) for w in ws]
     bsum = sum(bs).to(DEV)
     segs = [V.make_conv_seg(xd[i], wp[i], c, [t - (k - 1) // 2 for t in range(k)]) for i, k in enumerate(ks)]
     g = V.make_conv_group(segs, bsum, rd, out, c, cpad, L, L, L, scale=1.0 / 3)
-    keep = V.conv_grouped([g], B, cpad, L, tile_cfg, DEV)
+    keep = V.conv_grouped([g], B, cpad, L, tile_cfg, DEV, 16)
     torch.cuda.synchronize()
     assert maxdiff(out, ref) <= 1e-5
     del keep
@@ -204,7 +206,7 @@ def test_gemm_geglu_packed():
     out = torch.full((M, ip), float("nan"), device=DEV)
     hip.gemm(a.to(DEV), wp.to(DEV), out, M, 2 * ip, K, bias=bp.to(DEV), epilogue=hip.EPI_GEGLU)
     assert ip == 2752
-    assert maxdiff(out[:, :inner], ref) <= 1e-5
+    assert maxdiff(out[:, :inner], ref) <= 5e-5       # product of two K=1024 fp32 dot products, |h| up to ~5
     assert out[:, inner:].abs().max().item() == 0.0        # zero padding stays exactly zero
 
 
@@ -225,12 +227,13 @@ def test_gemv_and_time_fourier():
     w, x, b = rnd(N, K, seed=120, scale=K ** -0.5), rnd(K, seed=121), rnd(N, seed=122)
     y = torch.empty(N, device=DEV)
     L = hip.lib()
-    hip.check(L.fh_gemv_f32(w.to(DEV).data_ptr(), x.to(DEV).data_ptr(), b.to(DEV).data_ptr(), y.data_ptr(), N, K, 1,
-                            hip.stream()), "gemv")
+    wd, xd, bd = w.to(DEV), x.to(DEV), b.to(DEV)
+    hip.check(L.fh_gemv_f32(wd.data_ptr(), xd.data_ptr(), bd.data_ptr(), y.data_ptr(), N, K, 1, hip.stream()), "gemv")
     assert maxdiff(y, F.silu(F.linear(x, w, b))) <= 5e-6
     ws = rnd(512, seed=123)
     out = torch.empty(1024, device=DEV)
-    hip.check(L.fh_time_fourier_f32(ws.to(DEV).data_ptr(), 0.3, out.data_ptr(), 512, hip.stream()), "fourier")
+    wsd = ws.to(DEV)
+    hip.check(L.fh_time_fourier_f32(wsd.data_ptr(), 0.3, out.data_ptr(), 512, hip.stream()), "fourier")
     fr = torch.tensor([0.3])[:, None] * ws[None, :] * 2 * math.pi
     assert maxdiff(out, torch.cat((fr.sin(), fr.cos()), -1)[0]) <= 1e-6
 
@@ -243,8 +246,9 @@ def test_dwconv_gelu_res():
     x, w, b = rnd(B, n, D, seed=130), rnd(D, 1, k, seed=131, scale=0.2), rnd(D, seed=132)
     ref = F.gelu(F.conv1d(x.transpose(1, 2), w, b, padding=15, groups=D)).transpose(1, 2) + x
     y = torch.empty(B, n, D, device=DEV)
-    hip.check(hip.lib().fh_dwconv_gelu_res_f32(x.to(DEV).data_ptr(), w.reshape(D, k).contiguous().to(DEV).data_ptr(),
-                                               b.to(DEV).data_ptr(), y.data_ptr(), B, n, D, k, hip.stream()), "dwconv")
+    xd, wd, bd = x.to(DEV), w.reshape(D, k).contiguous().to(DEV), b.to(DEV)
+    hip.check(hip.lib().fh_dwconv_gelu_res_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, n, D, k,
+                                               hip.stream()), "dwconv")
     assert maxdiff(y, ref) <= 5e-6
 
 
@@ -255,10 +259,10 @@ def test_rmsnorm():
     ref = F.normalize(x, dim=-1) * 32.0 * g + b
     y = torch.empty(M, D, device=DEV)
     L = hip.lib()
-    hip.check(L.fh_rmsnorm_f32(x.to(DEV).data_ptr(), g.to(DEV).data_ptr(), b.to(DEV).data_ptr(), y.data_ptr(), M, D,
-                               hip.stream()), "rmsnorm")
+    xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)          # keep alive: data_ptr() of a temporary dangles
+    hip.check(L.fh_rmsnorm_f32(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, D, hip.stream()), "rmsnorm")
     assert maxdiff(y, ref) <= 5e-6
-    hip.check(L.fh_rmsnorm_f32(x.to(DEV).data_ptr(), g.to(DEV).data_ptr(), 0, y.data_ptr(), M, D, hip.stream()), "rmsnorm")
+    hip.check(L.fh_rmsnorm_f32(xd.data_ptr(), gd.data_ptr(), 0, y.data_ptr(), M, D, hip.stream()), "rmsnorm")
     assert maxdiff(y, F.normalize(x, dim=-1) * 32.0 * g) <= 5e-6
 
 
@@ -286,7 +290,7 @@ def test_attention_block(n):
     hip.check(L.fh_attention_f32(qkv.data_ptr(), att.data_ptr(), B, n, H, 10.0, hip.stream()), "attention")
     out = torch.empty(M, D, device=DEV)
     hip.gemm(att, sd[p + "to_out.weight"].to(DEV), out, M, D, D)
-    assert maxdiff(out.view(B, n, D), ref) <= 2e-5       # logits up to +-640 in fp32: ~4e-5 abs on the exponent
+    assert maxdiff(out.view(B, n, D), ref) <= 1e-4       # logits reach +-640: one fp32 ulp there is 6e-5 in the exponent
 
 
 @pytest.mark.parametrize("B,n,t", [(1, 25, 0.0), (2, 200, 0.3)])

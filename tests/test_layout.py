@@ -33,7 +33,7 @@ def test_argument_errors_are_reported_not_crashed():
     lib = hip.lib()
     assert lib.fh_gemm_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 0, 0) == -1
     assert b"fh_gemm_f32" in lib.fh_last_error()
-    assert lib.fh_conv_grouped_f32(0, 1, 1, 128, 10, 9, 0) == -1
+    assert lib.fh_conv_grouped_f32(0, 1, 1, 128, 10, 9, 8, 0) == -1
 
 
 def test_product_never_imports_oracle():
@@ -72,7 +72,7 @@ def test_tables_agree_with_oracle_and_torch():
 def test_weight_packing_roundtrip():
     from flowhigh_amd import vocoder as V
     w = torch.arange(24 * 16 * 3, dtype=torch.float32).view(24, 16, 3)
-    p = V.pack_conv_weight(w, 32)
+    p = V.pack_conv_weight(w, 32, 8)
     assert p.shape == (2, 3, 32, 8)
     assert p[1, 2, 5, 3] == w[5, 11, 2] and p[:, :, 24:].abs().sum() == 0
     for u, k in [(5, 11), (4, 8), (3, 7), (2, 4), (8, 16)]:
