@@ -245,54 +245,74 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __r
   }
 
   // ---- epilogue: bias + residuals, scale, strided store -------------------------------------
-  const int nres = G->nres;
+  // One buffer descriptor per tensor spans this batch item's [cout, lout] slab, so rows past
+  // cout fall out of range by themselves; columns past n_len get an out-of-range offset.  Every
+  // load and store is then unconditional (no exec-mask branches) and can be issued in bulk.
+  const int nres = uni(G->nres);
   const float scale = G->scale;
-  const int cout = G->cout, lout = G->lout, n_len = G->n_len;
-  const int ostride = G->out_stride, ophase = G->out_phase;
-  const float* __restrict__ bias = G->bias;
-  const float* __restrict__ r0 = nres > 0 ? G->res[0] : nullptr;
-  const float* __restrict__ r1 = nres > 1 ? G->res[1] : nullptr;
-  const float* __restrict__ r2 = nres > 2 ? G->res[2] : nullptr;
-  float* __restrict__ out = G->out;
+  const int cout = uni(G->cout), lout = uni(G->lout), n_len = uni(G->n_len);
+  const int ostride = uni(G->out_stride), ophase = uni(G->out_phase);
+  const float* __restrict__ bias = uni(G->bias);
+  const size_t slab = (size_t)b * cout * lout;
+  const unsigned slab_bytes = (unsigned)cout * (unsigned)lout * 4u;
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(uni((const float*)G->out) + slab, slab_bytes);
+  const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? uni(G->res[0]) + slab : nullptr, nres > 0 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? uni(G->res[1]) + slab : nullptr, nres > 1 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? uni(G->res[2]) + slab : nullptr, nres > 2 ? slab_bytes : 0u);
+  unsigned coloff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + (wn * NT + nt) * 32 + l31;
+    coloff[nt] = n < n_len ? (unsigned)(n * ostride + ophase) * 4u : 0x80000000u;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      // four consecutive output channels (regs 4 g4 .. 4 g4 + 3) at NT column tiles: gather the
-      // residual loads first so they are all in flight together
       float v[4][NT];
-      size_t idx[4][NT];
-      bool ok[4][NT];
+      unsigned off[4][NT];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int co = co0 + (wm * MT + mt) * 32 + rr + 8 * g4 + 4 * lh;
+      for (int q = 0; q < 4; ++q) {
+        const int co = co0 + (wm * MT + mt) * 32 + q + 8 * g4 + 4 * lh;
         const float bv = (bias && co < cout) ? bias[co] : 0.f;
-        const size_t rowbase = ((size_t)b * cout + co) * lout;
+        const unsigned rowoff = (unsigned)co * (unsigned)lout * 4u;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const int n = n0 + (wn * NT + nt) * 32 + l31;
-          ok[rr][nt] = co < cout && n < n_len;
-          idx[rr][nt] = rowbase + (size_t)n * ostride + ophase;
-          v[rr][nt] = acc[mt][nt][4 * g4 + rr] + bv;
+          off[q][nt] = (co < cout) ? rowoff + coloff[nt] : 0x80000000u;
+          v[q][nt] = acc[mt][nt][4 * g4 + q] + bv;
         }
       }
-      if (r0) {
+      if (nres > 0) {
+        float t0[4][NT];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            if (ok[rr][nt]) {
-              float t = r0[idx[rr][nt]];
-              if (r1) t += r1[idx[rr][nt]];
-              if (r2) t += r2[idx[rr][nt]];
-              v[rr][nt] += t;
-            }
+            t0[q][nt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off[q][nt], 0, 0));
+        if (nres > 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              t0[q][nt] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off[q][nt], 0, 0));
+        }
+        if (nres > 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              t0[q][nt] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off[q][nt], 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) v[q][nt] += t0[q][nt];
       }
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          if (ok[rr][nt]) out[idx[rr][nt]] = v[rr][nt] * scale;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q][nt] * scale), ro, off[q][nt], 0, 0);
     }
   }
 }
@@ -357,6 +377,8 @@ extern "C" int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, in
   FH_CHECK_ARG(bm > 0, "fh_conv_grouped_f32: unknown tile_cfg %d", tile_cfg);
   FH_CHECK_ARG(cout_pad % bm == 0, "fh_conv_grouped_f32: cout_pad %d not a multiple of tile %d", cout_pad, bm);
   FH_CHECK_ARG(ck == 8 || ck == 16, "fh_conv_grouped_f32: channel chunk must be 8 or 16 (got %d)", ck);
+  // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cout * lout * 4 < 2^31
+  // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
   hipStream_t st = (hipStream_t)stream;
 #define FH_CONV_CASE(id, MT, NT, WM, WN)                                                            \
   case id:                                                                                          \

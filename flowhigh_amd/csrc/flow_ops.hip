@@ -9,7 +9,7 @@
 namespace {
 
 // thread = 4 consecutive channels; block = 64 threads (256 channels) x TOK tokens walked serially.
-constexpr int DW_TOK = 16;
+constexpr int DW_TOK = 2;
 constexpr int DW_KMAX = 63;
 
 __global__ __launch_bounds__(256) void dwconv_gelu_res_kernel(const float* __restrict__ x,

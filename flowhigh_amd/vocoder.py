@@ -94,6 +94,8 @@ def make_conv_group(segs, bias, res, out, cout, cpad, lin, lout, n_len, stride=1
     for i, r in enumerate(res):
         g.res[i] = hip.ptr(r)
     g.out = hip.ptr(out)
+    if cout * lout * 4 >= 2 ** 31 or lin * 4 >= 2 ** 31:
+        raise NotImplementedError("per-clip tensor exceeds the 2 GiB range of a buffer descriptor")
     g.cout, g.cout_pad, g.lin, g.lout, g.n_len = cout, cpad, lin, lout, n_len
     g.out_stride, g.out_phase, g.scale = stride, phase, scale
     return g
@@ -247,6 +249,7 @@ class Vocoder:
 
         mel_in = torch.empty(B, self.num_mels, N, **f32)
         pre = torch.empty(B, self.c0, N, **f32)
+        keep.append(pre)            # descriptors hold raw pointers: every buffer they name must outlive the plan
         k7 = [j - 3 for j in range(7)]
         conv_step([make_conv_group([make_conv_seg(mel_in, self.pre_w, self.num_mels, k7)], self.pre_b, [],
                                     pre, self.c0, self.pre_cpad, N, N, N)], self.pre_cpad, N, self.pre_cfg, self.pre_ck)
