@@ -14,10 +14,10 @@
 //   z[2i+1] = snake( 2 * sum_{q=-2..3} x[i+q] f_up[6-2q] )
 //   y[i]    = sum_{k=0..11} z[2i+k-5] f_dn[k]
 //
-// Block = 256 threads, one (group, batch, channel) row segment of TT = 506 outputs:
-//   phase 1: x[t0-6 .. t0+TT+5] -> LDS                       (518 floats, clamped indices)
-//   phase 2: each thread makes 2 (even, odd) pairs of z -> LDS   (512 pairs = i in [t0-3, t0+TT+2])
-//   phase 3: each thread makes <= 2 outputs from 7 ds_read_b64 each.
+// Block = 256 threads, one (group, batch, channel) row segment of TT = 1018 outputs:
+//   phase 1: x[t0-6 .. t0+TT+5] -> LDS                       (TT + 12 floats, clamped indices)
+//   phase 2: each thread makes 4 (even, odd) pairs of z -> LDS   (TT + 6 pairs = i in [t0-3, t0+TT+2])
+//   phase 3: each thread makes <= 4 outputs from 7 ds_read_b64 each.
 #include "fh_common.h"
 
 namespace {
@@ -44,9 +44,14 @@ __device__ __forceinline__ float sin_squared(float a) {
   return (static_cast<int>(k) & 1) ? 1.0f - s2 : s2;
 }
 
-constexpr int ACT_TT = 506;            // outputs per block
-constexpr int ACT_PAIRS = ACT_TT + 6;  // 512 z pairs
-constexpr int ACT_XW = ACT_TT + 12;    // 518 staged inputs
+// The kernel is latency bound on its global loads (each block reads its window once, up front), so
+// a block covers 4 pairs per thread: all of a thread's loads are issued back to back and ~4 KB per
+// block (x 8 resident blocks per CU) are in flight.
+constexpr int ACT_PPT = 4;                   // z pairs per thread
+constexpr int ACT_PAIRS = 256 * ACT_PPT;     // 1024 z pairs
+constexpr int ACT_TT = ACT_PAIRS - 6;        // 1018 outputs per block
+constexpr int ACT_XW = ACT_TT + 12;          // 1030 staged inputs
+constexpr int ACT_XLD = (ACT_XW + 255) / 256;
 
 __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restrict__ groups,
                                                     int batch, int channels, int len,
@@ -68,11 +73,18 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   const int t0 = tile * ACT_TT;
   const int tid = threadIdx.x;
 
-  // phase 1: clamped (replicate) input window
-  for (int j = tid; j < ACT_XW; j += 256) {
-    int t = t0 - 6 + j;
+  // phase 1: clamped (replicate) input window; loads first, LDS writes after
+  float xin[ACT_XLD];
+#pragma unroll
+  for (int i = 0; i < ACT_XLD; ++i) {
+    int t = t0 - 6 + tid + 256 * i;
     t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
-    xs[j] = x[t];
+    xin[i] = x[t];
+  }
+#pragma unroll
+  for (int i = 0; i < ACT_XLD; ++i) {
+    const int j = tid + 256 * i;
+    if (j < ACT_XW) xs[j] = xin[i];
   }
   __syncthreads();
 
@@ -82,7 +94,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   for (int k = 0; k < 12; ++k) fu[k] = G.up_taps[k];
   const int zlast = 2 * len - 1;
 #pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
+  for (int rep = 0; rep < ACT_PPT; ++rep) {
     const int p = tid + 256 * rep;          // pair index; sample i = t0 - 3 + p
     // x[i+q] is xs[p + q + 3]  (xs[j] <-> t0 - 6 + j)
     float xv[7];
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   for (int k = 0; k < 12; ++k) fd[k] = G.down_taps[k];
   const int zbase = 2 * (t0 - 3);
 #pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
+  for (int rep = 0; rep < ACT_PPT; ++rep) {
     const int o = tid + 256 * rep;
     const int i = t0 + o;
     if (o >= ACT_TT || i >= len) continue;

@@ -207,28 +207,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __r
     }
     if (new_x) load_x(S2, c2);
 
-    // ---- MFMAs of the current step ----
+    // ---- MFMAs of the current step: B fragments are fetched one k-step ahead of their MFMAs so
+    // that a wave alone on its SIMD (the tail of a launch) does not expose the LDS latency ----
     {
       const float* wsb = ws + wbuf * BM * WP;
-      const float* xsb = xs + xbuf * CK * XW;
-      const int xoff = xoff_cur + wn * NT * 32 + l31;
+      const float* xsb = xs + xbuf * CK * XW + xoff_cur + wn * NT * 32 + l31 + 4 * lh * XW;
+      f32x4 a[KQ][MT];
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        f32x4 a[MT];
+      for (int q = 0; q < KQ; ++q)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          a[mt] = *reinterpret_cast<const f32x4*>(wsb + ((wm * MT + mt) * 32 + l31) * WP + 4 * (2 * q + lh));
+          a[q][mt] = *reinterpret_cast<const f32x4*>(wsb + ((wm * MT + mt) * 32 + l31) * WP + 4 * (2 * q + lh));
+      float bf[2][NT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float bf[NT];
+      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = xsb[nt * 32];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bf[nt] = xsb[(8 * q + 4 * lh + e) * XW + xoff + nt * 32];
+      for (int ks = 0; ks < 4 * KQ; ++ks) {        // k-step ks = 4 q + e uses slab row 8 q + 4 lh + e
+        if (ks + 1 < 4 * KQ) {
+          const int q1 = (ks + 1) >> 2, e1 = (ks + 1) & 3;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], bf[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) bf[(ks + 1) & 1][nt] = xsb[(8 * q1 + e1) * XW + nt * 32];
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the look-ahead read ahead of this k-step's MFMAs
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks >> 2][mt][ks & 3], bf[ks & 1][nt],
+                                                               acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 

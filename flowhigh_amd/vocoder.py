@@ -14,6 +14,7 @@ Launch structure per stage (13 launches instead of the reference's ~1700 aten ca
 """
 import json
 import math
+import os
 
 import torch
 
@@ -21,6 +22,9 @@ from . import hip
 
 VOC = "flowhigh.audio_enc_dec.vocoder."
 _TILE_PREF = [(0, 128), (1, 192), (2, 96), (3, 64), (4, 32)]
+# experiments only: FH_CONV_TILE_OVERRIDE="0:5" runs every 128x128 launch with the 128x64 tile
+_TILE_OVERRIDE = {int(a): int(b) for a, b in
+                  (kv.split(":") for kv in os.environ.get("FH_CONV_TILE_OVERRIDE", "").split(",") if kv)}
 
 
 def pick_tile_cfg(cout):
@@ -238,6 +242,7 @@ class Vocoder:
             # sequence lengths) switch from the 128x128 to the 128x64 tile to fill the 256 CUs
             if tcfg == 0 and len(groups) * B * (cpad // 128) * -(-n_len // 128) < 512:
                 tcfg = 5
+            tcfg = _TILE_OVERRIDE.get(tcfg, tcfg)
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
             steps.append(("conv", d, len(groups), cpad, n_len, tcfg, ck))

@@ -54,7 +54,7 @@ def test_conv_plain(tile_cfg, cin, cout, k, d, L, ck):
     x, w, b = rnd(2, cin, L, seed=1), rnd(cout, cin, k, seed=2, scale=0.2), rnd(cout, seed=3)
     ref = F.conv1d(x, w, b, dilation=d, padding=(k * d - d) // 2)
     got = run_conv(x, w, b, d, tile_cfg, ck=ck)
-    assert maxdiff(got, ref) <= 2e-5          # K <= 2200 fp32 products, |terms| ~ 0.2
+    assert maxdiff(got, ref) <= 5e-5          # K <= 2200 fp32 products, |terms| ~ 0.2, |out| up to ~10
 
 
 def test_conv_large_k_residual_scale():
