@@ -32,6 +32,10 @@ namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT_RUN = 8;       // n-tiles of a panel that run together on one XCD
 
+// Debug hook (fh_debug_set_conv_trace): when set, every block appends {blockIdx | hw_id << 32,
+// start, end (100 MHz s_memrealtime ticks), K steps} to this buffer: [0] = record counter.
+__device__ unsigned long long* g_conv_trace = nullptr;
+
 template <int MT, int NT, int WM, int WN, int CK>
 struct ConvCfg {
   static constexpr int BM = 32 * MT * WM;
@@ -75,7 +79,7 @@ __device__ __forceinline__ SegU load_seg(const fh_conv_seg* S) {
 }
 
 template <int MT, int NT, int WM, int WN, int CK>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __restrict__ groups,
+__global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(const fh_conv_group* __restrict__ groups,
                                                         int n_groups, int batch, int co_tiles,
                                                         int n_tiles) {
   using Cfg = ConvCfg<MT, NT, WM, WN, CK>;
@@ -85,6 +89,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __r
   float* ws = lds;
   float* xs = lds + 2 * BM * WP;
   int* toff = reinterpret_cast<int*>(lds + Cfg::LDS_FLOATS);   // [seg][tap] column shift of each tap
+
+  unsigned long long* const trace = g_conv_trace;
+  const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // ---- block -> (panel, n tile); panels = (group, batch, co tile), heavy groups first ----
   const int panels = n_groups * batch * co_tiles;
@@ -130,11 +137,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __r
     toff[tid] = (tid / FH_CONV_MAX_TAPS) < nseg ? sg->tap_off[tid % FH_CONV_MAX_TAPS] - sg->off_min : 0;
   }
 
-  u32x4 wreg[WREG];
+  // Two register sets for weight tiles: the tile of step i+2 is requested while step i computes
+  // and is written to LDS at the end of step i+1, so a load has two full MFMA phases to land (a wave
+  // that is alone on its SIMD at the tail of a launch would otherwise stall on every tile).
+  u32x4 wregA[WREG], wregB[WREG];
   unsigned xreg[XROWS][XREG];
 
   // ---- loaders (all addresses wave-uniform base + per-lane 32-bit offset) -------------------
-  auto load_w = [&](const SegU& S, int chunk, int tap) {
+  auto load_w = [&](u32x4 (&wreg)[WREG], const SegU& S, int chunk, int tap) {
     const float* wp = uni(S.w + ((size_t)(chunk * S.ntaps + tap) * cout_pad + co0) * CK);
     __amdgpu_buffer_rsrc_t r = make_rsrc(wp, BM * CK * 4);
 #pragma unroll
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __r
       wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(r, f * 16, 0, 0);
     }
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](const u32x4 (&wreg)[WREG], int buf) {
     float* dst = ws + buf * BM * WP;
 #pragma unroll
     for (int i = 0; i < WREG; ++i) {
@@ -174,81 +184,104 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __r
     }
   };
 
+  // ---- scalar step cursors: (segment, chunk, tap) of steps it, it+1, it+2 -----------------------
+  struct Cur { int s, c, j; };
+  auto advance = [&](Cur& k, SegU& S) {
+    if (++k.j == S.ntaps) {
+      k.j = 0;
+      if (++k.c * CK == S.cin) {
+        k.c = 0;
+        if (++k.s < nseg) S = load_seg(&G->seg[k.s]);
+      }
+    }
+  };
+
   // ---- prologue ----------------------------------------------------------------------------
-  SegU S = load_seg(&G->seg[0]);          // segment of the CURRENT step
-  int s_idx = 0, c = 0, j = 0;            // (segment, chunk, tap) of the current step
+  Cur k0 = {0, 0, 0};
+  SegU S0 = load_seg(&G->seg[0]);
   int wbuf = 0, xbuf = 0;
-  load_w(S, 0, 0);
-  load_x(S, 0);
-  store_w(0);
+  load_w(wregA, S0, 0, 0);
+  load_x(S0, 0);
+  Cur k1 = k0;
+  SegU S1 = S0;
+  advance(k1, S1);
+  if (nsteps > 1) load_w(wregB, S1, k1.c, k1.j);       // tile of step 1, stored at the end of step 0
+  Cur k2 = k1;
+  SegU S2 = S1;
+  advance(k2, S2);
+  store_w(wregA, 0);
   store_x(0);
   __syncthreads();
+
+  // one K step.  LOAD: register set that receives the tile of step it+2; STORE: the set holding
+  // the tile of step it+1 (requested one step earlier).  Everything that is not an MFMA is issued
+  // in the shadow of the MFMAs of this step (pinned with sched_barrier): global prefetch after
+  // k-step 1, LDS stores of the next tiles at mid-step, so that a wave that is alone on its SIMD
+  // keeps the matrix pipe fed; only the barrier and the first fragment reads stay exposed.
   int xoff_cur = toff[0];
-
-  for (int it = 0; it < nsteps; ++it) {
-    // indices of the next step (scalar state)
-    SegU S2 = S;
-    int s2 = s_idx, c2 = c, j2 = j + 1;
-    if (j2 == S.ntaps) {
-      j2 = 0;
-      c2 = c + 1;
-      if (c2 * CK == S.cin) {
-        c2 = 0;
-        s2 = s_idx + 1;
-        if (s2 < nseg) S2 = load_seg(&G->seg[s2]);
-      }
-    }
-    const bool has_next = it + 1 < nsteps;
-    const bool new_x = has_next && j2 == 0;
+  auto step = [&](int it, u32x4 (&LOAD)[WREG], const u32x4 (&STORE)[WREG]) {
+    constexpr int KS = 4 * KQ;
+    const bool last_tap = k0.j == S0.ntaps - 1;
+    const bool more_chunks = (k0.c + 1) * CK < S0.cin || k0.s + 1 < nseg;
+    const bool flip_x = last_tap && more_chunks;
+    const float* wsb = ws + wbuf * BM * WP;
+    const float* xsb = xs + xbuf * CK * XW + xoff_cur + wn * NT * 32 + l31 + 4 * lh * XW;
+    f32x4 a[KQ][MT];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        a[q][mt] = *reinterpret_cast<const f32x4*>(wsb + ((wm * MT + mt) * 32 + l31) * WP + 4 * (2 * q + lh));
+    float bf[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = xsb[nt * 32];
     int xoff_next = 0;
-    if (has_next) {
-      load_w(S2, c2, j2);
-      xoff_next = toff[s2 * FH_CONV_MAX_TAPS + j2];
-    }
-    if (new_x) load_x(S2, c2);
-
-    // ---- MFMAs of the current step: B fragments are fetched one k-step ahead of their MFMAs so
-    // that a wave alone on its SIMD (the tail of a launch) does not expose the LDS latency ----
-    {
-      const float* wsb = ws + wbuf * BM * WP;
-      const float* xsb = xs + xbuf * CK * XW + xoff_cur + wn * NT * 32 + l31 + 4 * lh * XW;
-      f32x4 a[KQ][MT];
 #pragma unroll
-      for (int q = 0; q < KQ; ++q)
+    for (int ks = 0; ks < KS; ++ks) {            // k-step ks = 4 q + e uses slab row 8 q + 4 lh + e
+      if (ks + 1 < KS) {
+        const int q1 = (ks + 1) >> 2, e1 = (ks + 1) & 3;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          a[q][mt] = *reinterpret_cast<const f32x4*>(wsb + ((wm * MT + mt) * 32 + l31) * WP + 4 * (2 * q + lh));
-      float bf[2][NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = xsb[nt * 32];
-#pragma unroll
-      for (int ks = 0; ks < 4 * KQ; ++ks) {        // k-step ks = 4 q + e uses slab row 8 q + 4 lh + e
-        if (ks + 1 < 4 * KQ) {
-          const int q1 = (ks + 1) >> 2, e1 = (ks + 1) & 3;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bf[(ks + 1) & 1][nt] = xsb[(8 * q1 + e1) * XW + nt * 32];
-        }
-        __builtin_amdgcn_sched_barrier(0);      // keep the look-ahead read ahead of this k-step's MFMAs
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks >> 2][mt][ks & 3], bf[ks & 1][nt],
-                                                               acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int nt = 0; nt < NT; ++nt) bf[(ks + 1) & 1][nt] = xsb[(8 * q1 + e1) * XW + nt * 32];
       }
+      if (ks == 1) {                              // global prefetch
+        if (it + 2 < nsteps) load_w(LOAD, S2, k2.c, k2.j);
+        if (k0.j == 0 && more_chunks) {           // slab of the next chunk, stored after its last tap
+          if ((k0.c + 1) * CK < S0.cin) {
+            load_x(S0, k0.c + 1);
+          } else {
+            const SegU Sn = load_seg(&G->seg[k0.s + 1]);
+            load_x(Sn, 0);
+          }
+        }
+      }
+      if (ks == KS / 2) {                         // LDS stores of the tiles of step it+1
+        if (it + 1 < nsteps) store_w(STORE, wbuf ^ 1);
+        if (flip_x) store_x(xbuf ^ 1);
+      }
+      if (ks == KS - 2) xoff_next = toff[k1.s * FH_CONV_MAX_TAPS + k1.j];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks >> 2][mt][ks & 3], bf[ks & 1][nt],
+                                                             acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-
-    if (has_next) store_w(wbuf ^ 1);
-    if (new_x) store_x(xbuf ^ 1);
     __syncthreads();
     wbuf ^= 1;
-    if (new_x) xbuf ^= 1;
-    S = S2;
-    s_idx = s2;
-    c = c2;
-    j = j2;
+    if (flip_x) xbuf ^= 1;
     xoff_cur = xoff_next;
+    k0 = k1;
+    S0 = S1;
+    k1 = k2;
+    S1 = S2;
+    advance(k2, S2);
+  };
+
+  for (int it = 0; it < nsteps; it += 2) {
+    step(it, wregA, wregB);
+    if (it + 1 < nsteps) step(it + 1, wregB, wregA);
   }
 
   // ---- epilogue: bias + residuals, scale, strided store -------------------------------------
@@ -322,6 +355,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fh_conv_group* __r
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q][nt] * scale), ro, off[q][nt], 0, 0);
     }
   }
+  if (trace && tid == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned long long slot = atomicAdd(trace, 1ull);
+    unsigned long long* r = trace + 1 + 4 * slot;
+    r[0] = (unsigned long long)blockIdx.x | ((unsigned long long)(hw & 0xffffff) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
+    r[1] = t_start;
+    r[2] = __builtin_amdgcn_s_memrealtime();
+    r[3] = (unsigned long long)nsteps;
+  }
 }
 
 template <int MT, int NT, int WM, int WN, int CK>
@@ -373,6 +418,16 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 }  // namespace
 
 extern "C" int fh_sizeof_conv_group(void) { return (int)sizeof(fh_conv_group); }
+
+extern "C" int fh_debug_set_conv_trace(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_conv_trace), &p, sizeof(p));
+  if (e != hipSuccess) {
+    fh_set_error("fh_debug_set_conv_trace: %s", hipGetErrorString(e));
+    return FH_E_LAUNCH;
+  }
+  return FH_OK;
+}
 
 extern "C" int fh_conv_tile_m(int cfg) { return (cfg >= 0 && cfg < kNumTiles) ? kTiles[cfg].bm : -1; }
 extern "C" int fh_conv_tile_n(int cfg) { return (cfg >= 0 && cfg < kNumTiles) ? kTiles[cfg].bn : -1; }

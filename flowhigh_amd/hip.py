@@ -47,6 +47,7 @@ _SIGS = {
     "fh_conv_tile_m": [_I],
     "fh_conv_tile_n": [_I],
     "fh_conv_grouped_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
+    "fh_debug_set_conv_trace": [_P],
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
     "fh_gemm_f32": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P],

@@ -214,6 +214,8 @@ class Vocoder:
         self.post_k = self.post_w.shape[-1]
         self._plans = {}
         self.conv_timing = None
+        self.chain_streams = os.environ.get("FH_VOCODER_STREAMS", "0") == "1"
+        self._side = None
 
     def conv_flops_per_frame(self):
         """Algorithmic FLOPs of the MFMA conv launches per mel frame (SURVEY.md 8d formula:
@@ -237,7 +239,7 @@ class Vocoder:
         keep = []           # tensors that must stay alive
         L = N
 
-        def conv_step(groups, cpad, n_len, tcfg, ck):
+        def conv_step(groups, cpad, n_len, tcfg, ck, sink=None):
             # few-block launches (first-stage upsampler, fused stage-closing conv at short
             # sequence lengths) switch from the 128x128 to the 128x64 tile to fill the 256 CUs
             if tcfg == 0 and len(groups) * B * (cpad // 128) * -(-n_len // 128) < 512:
@@ -245,12 +247,12 @@ class Vocoder:
             tcfg = _TILE_OVERRIDE.get(tcfg, tcfg)
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
-            steps.append(("conv", d, len(groups), cpad, n_len, tcfg, ck))
+            (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck))
 
-        def act_step(groups, c, length):
+        def act_step(groups, c, length, sink=None):
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
-            steps.append(("act", d, len(groups), c, length))
+            (sink if sink is not None else steps).append(("act", d, len(groups), c, length))
 
         mel_in = torch.empty(B, self.num_mels, N, **f32)
         pre = torch.empty(B, self.c0, N, **f32)
@@ -279,30 +281,54 @@ class Vocoder:
             T2 = [view(3 + 4 * j) for j in range(self.nk)]
             Y = [[view(4 + 4 * j), view(5 + 4 * j)] for j in range(self.nk)]
             xin = [X] * self.nk
+            chains = [[] for _ in range(self.nk)] if self.chain_streams else None
             for m in range(self.nm):
                 last = m == self.nm - 1
-                act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L)
-                groups = []
-                for j in order:
-                    blk = st["blocks"][j]
-                    k, d = blk["k"], blk["dil"][m]
-                    offs = [(t - (k - 1) // 2) * d for t in range(k)]
-                    groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
-                                                   blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
-                conv_step(groups, cpad, L, tcfg, st["ck"])
-                act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L)
-                if not last:
+                if chains is not None:
+                    # one launch sequence per AMP block, each on its own stream (run()): the three
+                    # chains are independent until the stage-closing conv, so the tail of one chain's
+                    # conv overlaps the others' kernels instead of idling the chip
+                    for j in order:
+                        blk = st["blocks"][j]
+                        k, d = blk["k"], blk["dil"][m]
+                        act_step([make_act_group(xin[j], T1[j], blk["acts"][2 * m])], c, L, chains[j])
+                        conv_step([make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c,
+                                                                  [(t - (k - 1) // 2) * d for t in range(k)])],
+                                                   blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L)],
+                                  cpad, L, tcfg, st["ck"], chains[j])
+                        act_step([make_act_group(T2[j], T1[j], blk["acts"][2 * m + 1])], c, L, chains[j])
+                        if not last:
+                            conv_step([make_conv_group([make_conv_seg(T1[j], blk["c2"][m]["w"], c,
+                                                                      [t - (k - 1) // 2 for t in range(k)])],
+                                                       blk["c2"][m]["b"], [xin[j]], Y[j][m % 2], c, cpad, L, L, L)],
+                                      cpad, L, tcfg, st["ck"], chains[j])
+                    if not last:
+                        xin = [Y[j][m % 2] for j in range(self.nk)]
+                    else:
+                        steps.append(("fork", [chains[j] for j in order]))
+                else:
+                    act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L)
                     groups = []
                     for j in order:
                         blk = st["blocks"][j]
-                        k = blk["k"]
-                        offs = [t - (k - 1) // 2 for t in range(k)]
-                        out = Y[j][m % 2]
-                        groups.append(make_conv_group([make_conv_seg(T1[j], blk["c2"][m]["w"], c, offs)],
-                                                       blk["c2"][m]["b"], [xin[j]], out, c, cpad, L, L, L))
+                        k, d = blk["k"], blk["dil"][m]
+                        offs = [(t - (k - 1) // 2) * d for t in range(k)]
+                        groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
+                                                       blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
                     conv_step(groups, cpad, L, tcfg, st["ck"])
-                    xin = [Y[j][m % 2] for j in range(self.nk)]
-                else:
+                    act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L)
+                    if not last:
+                        groups = []
+                        for j in order:
+                            blk = st["blocks"][j]
+                            k = blk["k"]
+                            offs = [t - (k - 1) // 2 for t in range(k)]
+                            out = Y[j][m % 2]
+                            groups.append(make_conv_group([make_conv_seg(T1[j], blk["c2"][m]["w"], c, offs)],
+                                                           blk["c2"][m]["b"], [xin[j]], out, c, cpad, L, L, L))
+                        conv_step(groups, cpad, L, tcfg, st["ck"])
+                        xin = [Y[j][m % 2] for j in range(self.nk)]
+                if last:
                     segs = []
                     for j in order:
                         blk = st["blocks"][j]
@@ -331,24 +357,45 @@ class Vocoder:
         return p["wav"]
 
     def run(self, p):
+        self._run_steps(p["steps"], p["B"], hip.stream())
+
+    def _launch(self, s, B, st):
         L = hip.lib()
-        st = hip.stream()
-        B = p["B"]
-        timing = self.conv_timing          # optional list of (start, end) events around conv launches
-        for s in p["steps"]:
-            if s[0] == "conv":
-                _, d, ng, cpad, n_len, tcfg, ck = s
-                if timing is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                hip.check(L.fh_conv_grouped_f32(d.data_ptr(), ng, B, cpad, n_len, tcfg, ck, st), "fh_conv_grouped_f32")
-                if timing is not None:
-                    e1.record()
-                    timing.append((e0, e1))
-            elif s[0] == "act":
-                _, d, ng, c, length = s
-                hip.check(L.fh_act1d_grouped_f32(d.data_ptr(), ng, B, c, length, st), "fh_act1d_grouped_f32")
-            else:
-                _, x, wav, c, length = s
-                hip.check(L.fh_conv_post_tanh_f32(x.data_ptr(), self.post_w.data_ptr(), self.post_b.data_ptr(),
-                                                  wav.data_ptr(), B, c, length, self.post_k, st), "fh_conv_post_tanh_f32")
+        if s[0] == "conv":
+            _, d, ng, cpad, n_len, tcfg, ck = s
+            timing = self.conv_timing          # optional list of (start, end) events around conv launches
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            hip.check(L.fh_conv_grouped_f32(d.data_ptr(), ng, B, cpad, n_len, tcfg, ck, st), "fh_conv_grouped_f32")
+            if timing is not None:
+                e1.record()
+                timing.append((e0, e1))
+        elif s[0] == "act":
+            _, d, ng, c, length = s
+            hip.check(L.fh_act1d_grouped_f32(d.data_ptr(), ng, B, c, length, st), "fh_act1d_grouped_f32")
+        else:
+            _, x, wav, c, length = s
+            hip.check(L.fh_conv_post_tanh_f32(x.data_ptr(), self.post_w.data_ptr(), self.post_b.data_ptr(),
+                                              wav.data_ptr(), B, c, length, self.post_k, st), "fh_conv_post_tanh_f32")
+
+    def _run_steps(self, steps, B, st):
+        for s in steps:
+            if s[0] != "fork":
+                self._launch(s, B, st)
+                continue
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.nk)]
+                self._ev = [torch.cuda.Event() for _ in range(self.nk + 1)]
+            self._ev[0].record(main)
+            for j, chain in enumerate(s[1]):
+                side = self._side[j]
+                side.wait_event(self._ev[0])
+                with torch.cuda.stream(side):
+                    h = side.cuda_stream
+                    for cs in chain:
+                        self._launch(cs, B, h)
+                self._ev[j + 1].record(side)
+            for j in range(len(s[1])):
+                main.wait_event(self._ev[j + 1])

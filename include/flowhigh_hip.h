@@ -89,6 +89,11 @@ int fh_conv_tile_n(int tile_cfg);
 int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch, int cout_pad,
                         int n_len, int tile_cfg, int ck, void* stream);
 
+/* Debug: per-block timeline of the conv kernel.  buf = device array of uint64, buf[0] = record
+ * counter (zero it), then 4 words per block {blockIdx | hw_id << 32 | xcc << 56, start, end
+ * (100 MHz ticks), K steps}; NULL switches tracing off.  Synchronous (hipMemcpyToSymbol). */
+int fh_debug_set_conv_trace(void* buf);
+
 /* conv_post + tanh (models/bigvgan/models.py:190-192): x [B, cin, L], w [cin, ksz], bias[1]
  * -> out [B, L] = tanh(bias + sum_ci sum_j w[ci,j] * x[b, ci, t + j - ksz/2]).  ksz odd <= 15. */
 int fh_conv_post_tanh_f32(const float* x, const float* w, const float* bias, float* out,
