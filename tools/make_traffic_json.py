@@ -1,0 +1,20 @@
+"""profiles/conv_hbm_bytes_per_launch.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+of `bench.py --steps 1 --warmup 1`.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM):
+counters are in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled."""
+import csv, glob, json, sys
+fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+def total(d, name):
+    f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == name and 'conv_mfma_kernel' in r['Kernel_Name']:
+            tot += float(r['Counter_Value']); n += 1
+    return tot, n
+fs, n1 = total(fetch_dir, 'FETCH_SIZE')
+ws, n2 = total(write_dir, 'WRITE_SIZE')
+assert n1 == n2 and n1 > 0
+per = (2.0 * fs + ws) * 1024.0 / n1
+json.dump({"bytes_per_launch": round(per), "launches": n1, "fetch_kb_raw": fs, "write_kb": ws,
+           "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches, conv_mfma_kernel dispatches only"},
+          open(out, 'w'), indent=1)
+print(open(out).read())
