@@ -15,49 +15,60 @@
 //   y[i]    = sum_{k=0..11} z[2i+k-5] f_dn[k]
 //
 // Block = 256 threads, one (group, batch, channel) row segment of TT = 1018 outputs:
-//   phase 1: x[t0-6 .. t0+TT+5] -> LDS                       (TT + 12 floats, clamped indices)
-//   phase 2: each thread makes 4 (even, odd) pairs of z -> LDS   (TT + 6 pairs = i in [t0-3, t0+TT+2])
-//   phase 3: each thread makes <= 4 outputs from 7 ds_read_b64 each.
+//   phase 1: x[t0-6 .. t0+TT+5] -> LDS                         (TT + 12 floats, clamped indices)
+//   phase 2: thread t makes the 4 consecutive (even, odd) pairs 4t .. 4t+3 of z -> LDS
+//   phase 3: thread t makes the 4 consecutive outputs 4t .. 4t+3 and stores them as one 16-byte vector.
+// Every LDS access is a 16-byte vector; the filter and snake arithmetic of phase 2 is on the
+// packed-fp32 VALU (v_pk_fma_f32).  (A persistent, software-prefetching variant measured slower.)
 #include "fh_common.h"
 
 namespace {
 
-// sin^2(a) without libm's sinf (the activation is VALU-bound on it: two calls per sample at the 2x
-// rate).  Cody-Waite reduction by pi/2 in three fused steps (exact products for |k| < 2^15), then the
-// odd Taylor polynomial of sin to r^9 on |r| <= pi/4 (truncation 2e-9) and sin^2 = s^2 for even k,
-// 1 - s^2 for odd k.  Absolute error <= ~2e-7, the same size as squaring a 1-ulp sinf.
-__device__ __forceinline__ float sin_squared(float a) {
-  if (fabsf(a) >= 32768.f) {            // never reached by sane activations; keeps the result exact-ish
-    const float s = sinf(a);
-    return s * s;
-  }
-  const float k = rintf(a * 0.63661977236758134308f);
-  float r = fmaf(k, -1.5703125f, a);
-  r = fmaf(k, -4.837512969970703125e-4f, r);
-  r = fmaf(k, -7.549789948768648e-8f, r);
-  const float r2 = r * r;
-  float p = fmaf(r2, 2.7557314297e-06f, -1.9841270114e-04f);
-  p = fmaf(r2, p, 8.3333337680e-03f);
-  p = fmaf(r2, p, -1.6666667163e-01f);
-  const float s = fmaf(r * r2, p, r);
-  const float s2 = s * s;
-  return (static_cast<int>(k) & 1) ? 1.0f - s2 : s2;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// sin^2(a) without libm's sinf, two values at a time.  Cody-Waite reduction by pi/2 in three fused
+// steps (exact products for |k| < 2^15), then the odd Taylor polynomial of sin to r^9 on
+// |r| <= pi/4 (truncation 2e-9); sin^2 = s^2 for even k, 1 - s^2 for odd k.  Absolute error
+// <= 1.2e-7 (checked on the host against float64 over |a| < 3e4), the same size as squaring a
+// 1-ulp sinf.  |a| >= 32768 is patched by the caller.
+__device__ __forceinline__ f32x2 sin_squared2(f32x2 a) {
+  const f32x2 t = a * 0.63661977236758134308f;
+  const f32x2 k = {rintf(t[0]), rintf(t[1])};
+  f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-1.5703125f), a);
+  r = __builtin_elementwise_fma(k, (f32x2)(-4.837512969970703125e-4f), r);
+  r = __builtin_elementwise_fma(k, (f32x2)(-7.549789948768648e-8f), r);
+  const f32x2 r2 = r * r;
+  f32x2 p = __builtin_elementwise_fma(r2, (f32x2)(2.7557314297e-06f), (f32x2)(-1.9841270114e-04f));
+  p = __builtin_elementwise_fma(r2, p, (f32x2)(8.3333337680e-03f));
+  p = __builtin_elementwise_fma(r2, p, (f32x2)(-1.6666667163e-01f));
+  const f32x2 s = __builtin_elementwise_fma(r * r2, p, r);
+  const f32x2 s2 = s * s;
+  f32x2 o;
+  o[0] = (static_cast<int>(k[0]) & 1) ? 1.0f - s2[0] : s2[0];
+  o[1] = (static_cast<int>(k[1]) & 1) ? 1.0f - s2[1] : s2[1];
+  return o;
 }
 
-// The kernel is latency bound on its global loads (each block reads its window once, up front), so
-// a block covers 4 pairs per thread: all of a thread's loads are issued back to back and ~4 KB per
-// block (x 8 resident blocks per CU) are in flight.
-constexpr int ACT_PPT = 4;                   // z pairs per thread
+__device__ __noinline__ float sin_squared_slow(float a) {   // huge arguments only (never in practice)
+  const float s = sinf(a);
+  return s * s;
+}
+
+constexpr int ACT_PPT = 4;                   // z pairs (and outputs) per thread, consecutive
 constexpr int ACT_PAIRS = 256 * ACT_PPT;     // 1024 z pairs
-constexpr int ACT_TT = ACT_PAIRS - 6;        // 1018 outputs per block
+constexpr int ACT_TT = ACT_PAIRS - 6;        // 1018 outputs per tile
 constexpr int ACT_XW = ACT_TT + 12;          // 1030 staged inputs
 constexpr int ACT_XLD = (ACT_XW + 255) / 256;
+constexpr int ACT_XS = ACT_PAIRS + 16;       // staged row incl. slack for whole-vector reads
 
+// One block = one (group, batch, channel, tile).  Thread t owns pairs 4t .. 4t+3 and outputs
+// 4t .. 4t+3, so every LDS access is a whole 16-byte vector (3 reads per 4 pairs, 5 reads per 4
+// outputs instead of 7 scalar / 7 8-byte reads each) and the result is stored 16 bytes per lane.
 __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restrict__ groups,
                                                     int batch, int channels, int len,
                                                     int tiles_per_row) {
-  __shared__ float xs[ACT_XW + 2];
-  __shared__ __attribute__((aligned(8))) float zs[2 * ACT_PAIRS];
+  __shared__ __attribute__((aligned(16))) float xs[ACT_XS];
+  __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
 
   const int tile = blockIdx.x % tiles_per_row;
   const int row = blockIdx.x / tiles_per_row;          // (g * batch + b) * channels + c
@@ -72,8 +83,9 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   const float inv_beta = G.inv_beta[c];
   const int t0 = tile * ACT_TT;
   const int tid = threadIdx.x;
+  const int zlast = 2 * len - 1;
 
-  // phase 1: clamped (replicate) input window; loads first, LDS writes after
+  // phase 1: clamped (replicate) input window; all loads first, LDS writes after
   float xin[ACT_XLD];
 #pragma unroll
   for (int i = 0; i < ACT_XLD; ++i) {
@@ -84,61 +96,69 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
 #pragma unroll
   for (int i = 0; i < ACT_XLD; ++i) {
     const int j = tid + 256 * i;
-    if (j < ACT_XW) xs[j] = xin[i];
+    if (j < ACT_XS) xs[j] = xin[i];
   }
   __syncthreads();
 
-  // phase 2: z pairs for i = t0 - 3 + p, p in [0, 512)
-  float fu[12];
+  // phase 2: pairs p = 4 tid + r (sample i = t0 - 3 + p); x[i+q] is xs[p + q + 3], q in [-3, 3]
+  f32x2 fu2[7];             // taps of x[i-3 .. i+3] for (z[2i], z[2i+1]); the unused end tap is 0
 #pragma unroll
-  for (int k = 0; k < 12; ++k) fu[k] = G.up_taps[k];
-  const int zlast = 2 * len - 1;
+  for (int q = -3; q <= 3; ++q) {
+    fu2[q + 3][0] = q <= 2 ? G.up_taps[5 - 2 * q] : 0.f;
+    fu2[q + 3][1] = q >= -2 ? G.up_taps[6 - 2 * q] : 0.f;
+  }
+  {
+    float xv[12];
 #pragma unroll
-  for (int rep = 0; rep < ACT_PPT; ++rep) {
-    const int p = tid + 256 * rep;          // pair index; sample i = t0 - 3 + p
-    // x[i+q] is xs[p + q + 3]  (xs[j] <-> t0 - 6 + j)
-    float xv[7];
+    for (int v = 0; v < 3; ++v) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(xs + 4 * tid + 4 * v);
+      xv[4 * v] = t4[0]; xv[4 * v + 1] = t4[1]; xv[4 * v + 2] = t4[2]; xv[4 * v + 3] = t4[3];
+    }
+    f32x2 zout[ACT_PPT];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) xv[q] = xs[p + q];      // x[i-3 .. i+3]
-    float ze = 0.f, zo = 0.f;
+    for (int r = 0; r < ACT_PPT; ++r) {
+      f32x2 z = {0.f, 0.f};
 #pragma unroll
-    for (int q = -3; q <= 2; ++q) ze = fmaf(xv[q + 3], fu[5 - 2 * q], ze);
-#pragma unroll
-    for (int q = -2; q <= 3; ++q) zo = fmaf(xv[q + 3], fu[6 - 2 * q], zo);
-    ze *= 2.f;
-    zo *= 2.f;
-    ze = ze + inv_beta * sin_squared(ze * alpha);
-    zo = zo + inv_beta * sin_squared(zo * alpha);
+      for (int q = 0; q < 7; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + q]), fu2[q], z);
+      z = z * 2.f;
+      const f32x2 arg = z * alpha;
+      f32x2 s2 = sin_squared2(arg);
+      if (__builtin_expect(fabsf(arg[0]) >= 32768.f || fabsf(arg[1]) >= 32768.f, 0)) {
+        s2[0] = sin_squared_slow(arg[0]);
+        s2[1] = sin_squared_slow(arg[1]);
+      }
+      zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2, z);
+    }
     // positions outside [0, 2L-1] are never used directly: phase 3 clamps its index instead
-    zs[2 * p] = ze;
-    zs[2 * p + 1] = zo;
+    f32x4* zw = reinterpret_cast<f32x4*>(zs + 8 * tid);
+    zw[0] = (f32x4){zout[0][0], zout[0][1], zout[1][0], zout[1][1]};
+    zw[1] = (f32x4){zout[2][0], zout[2][1], zout[3][0], zout[3][1]};
   }
   __syncthreads();
 
-  // phase 3: y[i] = sum_k z[clamp(2i + k - 5)] f_dn[k];  z[m] is zs[m - 2 (t0 - 3)]
+  // phase 3: outputs o = 4 tid + r, y[i] = sum_k z[clamp(2i + k - 5)] f_dn[k]; z[m] is zs[m - 2 (t0 - 3)]
   float fd[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) fd[k] = G.down_taps[k];
+  const int o0 = 4 * tid;
+  const int i0 = t0 + o0;
+  if (o0 >= ACT_TT || i0 >= len) return;
+  float zv[20];              // zs[2 o0 .. 2 o0 + 19]
+#pragma unroll
+  for (int v = 0; v < 5; ++v) {
+    const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 8 * tid + 4 * v);
+    zv[4 * v] = t4[0]; zv[4 * v + 1] = t4[1]; zv[4 * v + 2] = t4[2]; zv[4 * v + 3] = t4[3];
+  }
+  float out[ACT_PPT];
   const int zbase = 2 * (t0 - 3);
 #pragma unroll
-  for (int rep = 0; rep < ACT_PPT; ++rep) {
-    const int o = tid + 256 * rep;
-    const int i = t0 + o;
-    if (o >= ACT_TT || i >= len) continue;
+  for (int r = 0; r < ACT_PPT; ++r) {
+    const int i = i0 + r;
     float acc = 0.f;
-    if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {
-      // interior: 14 contiguous values zs[2o .. 2o+13], taps use [1 .. 12]
-      const float2* zp = reinterpret_cast<const float2*>(zs + 2 * o);
-      float v[14];
+    if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {          // interior: taps on zs[2o + 1 .. 2o + 12]
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        float2 t2 = zp[q];
-        v[2 * q] = t2.x;
-        v[2 * q + 1] = t2.y;
-      }
-#pragma unroll
-      for (int k = 0; k < 12; ++k) acc = fmaf(v[k + 1], fd[k], acc);
-    } else {
+      for (int k = 0; k < 12; ++k) acc = fmaf(zv[2 * r + 1 + k], fd[k], acc);
+    } else if (i < len) {
 #pragma unroll
       for (int k = 0; k < 12; ++k) {
         int m = 2 * i + k - 5;
@@ -146,7 +166,15 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
         acc = fmaf(zs[m - zbase], fd[k], acc);
       }
     }
-    y[i] = acc;
+    out[r] = acc;
+  }
+  const bool full = o0 + 3 < ACT_TT && i0 + 3 < len;
+  if (full && (((size_t)(y + i0)) & 15) == 0) {
+    *reinterpret_cast<f32x4*>(y + i0) = (f32x4){out[0], out[1], out[2], out[3]};
+  } else {
+#pragma unroll
+    for (int r = 0; r < ACT_PPT; ++r)
+      if (o0 + r < ACT_TT && i0 + r < len) y[i0 + r] = out[r];
   }
 }
 

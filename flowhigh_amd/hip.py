@@ -9,7 +9,8 @@ from pathlib import Path
 
 import torch
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "libflowhigh_hip.so"
+import os
+LIB_PATH = Path(os.environ.get("FH_LIB_PATH", Path(__file__).resolve().parent / "lib" / "libflowhigh_hip.so"))
 
 CONV_MAX_TAPS = 16
 CONV_MAX_SEG = 3

@@ -113,3 +113,33 @@ def test_full_size_properties(secs, sr_in, method, steps, B):
         gain = (so[lo].abs().sum() / sc[lo].abs().sum()).item()
         err = (so[lo] - gain * sc[lo]).abs().max().item() / sc[lo].abs().max().item()
         assert err <= 2e-2      # an iSTFT of a spliced STFT is only approximately consistent at the band edge
+
+
+def test_from_local_reads_reference_checkpoint_files(tmp_path):
+    """from_local: vocoder JSON + generator .pt with weight_g/weight_v + wrapper .pt['model']
+    (flowhighsr.py:110-137, init_vocoder.py:8-23), defaults midpoint like the reference."""
+    g = load_golden("tiny_ragged_16k")                       # a midpoint case
+    synth.write_checkpoint_dir(tmp_path, g["cfg"], g["seed"], weight_norm=True)
+    m = FlowHighSR.from_local(tmp_path, "cuda")
+    assert m.odeint_kwargs["method"] == "midpoint" and m.cfm_method == "basic_cfm"
+    out = m.generate(g["audio"], g["sr_in"], 48000, g["steps"], noise=torch.from_numpy(g["noise"]))
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_WAVEFORM
+    # missing key -> RuntimeError like load_state_dict(strict=True)
+    import torch as _t
+    ck = _t.load(tmp_path / "FLowHigh_basic_400k.pt", weights_only=False)
+    ck["model"].pop("flowhigh.audio_enc_dec.vocoder.conv_post.bias")
+    _t.save(ck, tmp_path / "FLowHigh_basic_400k.pt")
+    with pytest.raises(RuntimeError):
+        FlowHighSR.from_local(tmp_path, "cuda")
+
+
+def test_unsupported_options_raise():
+    m, _ = model_for(synth.TINY_CFG, 0)
+    audio = synth.lowres_clip(0, 0.3, 12000)
+    with pytest.raises(NotImplementedError):
+        m.sample(cond=torch.zeros(1, 4800), cond_scale=2.0)
+    m.upsampling_method = "soxr"
+    with pytest.raises(UnboundLocalError):
+        m.generate(audio, 12000)
+    with pytest.raises(NotImplementedError):
+        FlowHighSR(m.flowhigh, use_torchode=True)

@@ -47,3 +47,13 @@ def classes(li):
         print(f"   launch {li}: nsteps {ns:5d} blocks {m.sum():4d} start mean {st.mean():7.1f} (max {st.max():7.1f})  end mean {en.mean():7.1f} min {en.min():7.1f} max {en.max():7.1f}  dur mean {(en-st).mean():7.1f}")
 for li in (2, 9, 16, 30):
     classes(li)
+
+# which block ids share a CU (launch 2)
+a_, b_ = cuts[2], cuts[3]
+bid = (rec[a_:b_, 0] & 0xffffffff)
+from collections import defaultdict
+m = defaultdict(list)
+for i in range(b_ - a_):
+    m[int(cuid[a_ + i])].append(int(bid[i]))
+for k in list(sorted(m))[:12]:
+    print("   CU", k, sorted(m[k]))
