@@ -65,25 +65,58 @@ __global__ __launch_bounds__(256) void spec_energy_kernel(const float* __restric
 
 // torch.cumsum on CPU accumulates float32 input in double and rounds every prefix to float;
 // the threshold product is a float32 multiply (postprocessing.py:11-12).
-__global__ void cutoff_kernel(const float* __restrict__ energy, int32_t* __restrict__ cr, float thr) {
+__global__ void cutoff_kernel(const float* __restrict__ energy, int32_t* __restrict__ cr, int nbins,
+                              float thr) {
   __shared__ float cum[1025];
   const int b = blockIdx.x;
   if (threadIdx.x == 0) {
     double c = 0.0;
-    for (int f = 0; f < 1025; ++f) {
-      c += (double)energy[b * 1025 + f];
+    for (int f = 0; f < nbins; ++f) {
+      c += (double)energy[b * nbins + f];
       cum[f] = (float)c;
     }
-    const float limit = cum[1024] * thr;
+    const float limit = cum[nbins - 1] * thr;
     int res = 0;
-    for (int i = 1; i < 1025; ++i) {
-      if (cum[1025 - i] < limit) {
-        res = 1025 - i;
+    for (int i = 1; i < nbins; ++i) {
+      if (cum[nbins - i] < limit) {
+        res = nbins - i;
         break;
       }
     }
     cr[b] = res;
   }
+}
+
+// energy[b, d] = sum_n exp(mel[b, n, d])   (locate_cutoff_freq on exp(mel), cfm_superresolution.py:134-159)
+__global__ __launch_bounds__(256) void mel_energy_kernel(const float* __restrict__ mel,
+                                                         float* __restrict__ energy, int n, int d) {
+  const int b = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= d) return;
+  const float* m = mel + (size_t)b * n * d + col;
+  double acc = 0.0;
+  for (int t = 0; t < n; ++t) acc += (double)expf(m[(size_t)t * d]);
+  energy[b * d + col] = (float)acc;
+}
+
+// out[b, n, d] = d < cut[b] ? low : high      (mel_replace_ops, cfm_superresolution.py:146-152)
+__global__ __launch_bounds__(256) void mel_splice_kernel(const float* __restrict__ low,
+                                                         const float* __restrict__ high,
+                                                         const int32_t* __restrict__ cut,
+                                                         float* __restrict__ out, int n, int d) {
+  const int b = blockIdx.y;
+  const size_t per = (size_t)n * d;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per) return;
+  const size_t g = (size_t)b * per + i;
+  out[g] = (int)(i % d) < cut[b] ? low[g] : high[g];
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float a,
+                                                    const float* __restrict__ y, float bcoef,
+                                                    float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = x[i] * a + y[i] * bcoef;      // cond * std_1 + epsilon * std_2 (cfm:226-236)
 }
 
 __global__ __launch_bounds__(256) void splice_kernel(const float* __restrict__ pred,
@@ -212,11 +245,36 @@ extern "C" int fh_spec_energy_f32(const float* spec, float* energy, int batch, i
   return FH_OK;
 }
 
-extern "C" int fh_cutoff_index_f32(const float* energy, int32_t* cr, int batch, float thr,
+extern "C" int fh_cutoff_index_f32(const float* energy, int32_t* cr, int batch, int nbins, float thr,
                                    void* stream) {
-  FH_CHECK_ARG(energy && cr && batch > 0, "fh_cutoff_index_f32: bad args");
-  hipLaunchKernelGGL(cutoff_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, energy, cr, thr);
+  FH_CHECK_ARG(energy && cr && batch > 0 && nbins > 1 && nbins <= 1025, "fh_cutoff_index_f32: bad args");
+  hipLaunchKernelGGL(cutoff_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, energy, cr, nbins, thr);
   FH_CHECK_LAUNCH("fh_cutoff_index_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_mel_energy_f32(const float* mel, float* energy, int batch, int n, int d, void* stream) {
+  FH_CHECK_ARG(mel && energy && batch > 0 && n > 0 && d > 0, "fh_mel_energy_f32: bad args");
+  hipLaunchKernelGGL(mel_energy_kernel, dim3(fh_cdiv(d, 256), batch), dim3(256), 0, (hipStream_t)stream, mel,
+                     energy, n, d);
+  FH_CHECK_LAUNCH("fh_mel_energy_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_mel_splice_f32(const float* low, const float* high, const int32_t* cut, float* out,
+                                 int batch, int n, int d, void* stream) {
+  FH_CHECK_ARG(low && high && cut && out && batch > 0 && n > 0 && d > 0, "fh_mel_splice_f32: bad args");
+  hipLaunchKernelGGL(mel_splice_kernel, dim3(fh_cdiv((long long)n * d, 256), batch), dim3(256), 0,
+                     (hipStream_t)stream, low, high, cut, out, n, d);
+  FH_CHECK_LAUNCH("fh_mel_splice_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_axpby_f32(const float* x, float a, const float* y, float b, float* out, long long n,
+                            void* stream) {
+  FH_CHECK_ARG(x && y && out && n > 0, "fh_axpby_f32: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, a, y, b, out, n);
+  FH_CHECK_LAUNCH("fh_axpby_f32");
   return FH_OK;
 }
 

@@ -67,6 +67,8 @@ class FlowNet:
         self.w_x = _pad_rows(w_embed[:, :self.dim_in]).to(dev)
         self.w_c = _pad_rows(w_embed[:, self.dim_in:]).to(dev)
         self.b_embed = g("to_embed.bias").to(dev)
+        self.null_cond = g("null_cond").reshape(1, -1).contiguous().to(dev)
+        self._e_null = None
         dw = g("conv_embed.dw_conv1d.0.weight")
         self.dw_k = dw.shape[-1]
         self.dw_w = dw.reshape(self.dim, self.dw_k).contiguous().to(dev)
@@ -121,13 +123,21 @@ class FlowNet:
         ws = self.workspace(batch, n)
         hip.gemm(cond, self.w_c, ws["e_cond"], batch * n, self.dim, self.dim_in, bias=self.b_embed)
 
-    def forward(self, x, t, out, batch, n, alpha=1.0, res=None):
-        """out = alpha * v(x, t) + res  with v the vector field; x/out/res [B*n, dim_in]."""
+    def forward(self, x, t, out, batch, n, alpha=1.0, res=None, null_cond=False):
+        """out = alpha * v(x, t) + res  with v the vector field; x/out/res [B*n, dim_in].
+        null_cond=True evaluates v with every frame's condition replaced by `null_cond`
+        (the cond_drop_prob = 1 pass of forward_with_cond_scale, flow.py:174-178,222-230)."""
         L, st = hip.lib(), hip.stream()
         ws = self.workspace(batch, n)
         M, D = batch * n, self.dim
         h, h2, a, att, qkv = ws["h"], ws["h2"], ws["a"], ws["att"], ws["qkv"]
-        hip.gemm(x, self.w_x, h, M, D, self.dim_in, R=ws["e_cond"])
+        if null_cond:
+            if self._e_null is None:            # null_cond @ W_c^T + b: one row, broadcast with ldr = 0
+                self._e_null = torch.empty(1, D, dtype=torch.float32, device=self.device)
+                hip.gemm(self.null_cond, self.w_c, self._e_null, 1, D, self.dim_in, bias=self.b_embed)
+            hip.gemm(x, self.w_x, h, M, D, self.dim_in, R=self._e_null, ldr=0)
+        else:
+            hip.gemm(x, self.w_x, h, M, D, self.dim_in, R=ws["e_cond"])
         hip.check(L.fh_dwconv_gelu_res_f32(h.data_ptr(), self.dw_w.data_ptr(), self.dw_b.data_ptr(),
                                            h2.data_ptr(), batch, n, D, self.dw_k, st), "fh_dwconv_gelu_res_f32")
         hip.check(L.fh_time_fourier_f32(self.sinu_w.data_ptr(), float(t), ws["four"].data_ptr(), D // 2, st),

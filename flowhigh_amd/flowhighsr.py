@@ -12,6 +12,7 @@ a non-CUDA device, or without the built library, raises.
 
 Extensions over the reference (all keyword-only, defaults keep reference behaviour):
   generate(..., noise=, generator=)   explicit prior draw / CPU generator (parity hook)
+  sample(..., cond_scale=, mel_pp=)    as in the reference, evaluated on the device (no python bin loops)
   generate_batch(clips, sr, ...)      B equal-length clips, every per-clip normalisation kept per clip
   upsampling_method='hip'             resample_poly on the device instead of scipy on the host
 """
@@ -163,8 +164,10 @@ class FlowHighSR:
         n_mels = self.flowhigh.n_mels
         return torch.cat([reference_prior_draw(n_frames, n_mels, generator) for _ in range(batch)], 0)
 
-    def _integrate(self, y0, cond_mel, batch, n, time_steps):
-        """Fixed-grid euler / midpoint (torchdiffeq semantics); y0, cond_mel [B*n, n_mels] on device."""
+    def _integrate(self, y0, cond_mel, batch, n, time_steps, cond_scale=1.):
+        """Fixed-grid euler / midpoint (torchdiffeq semantics); y0, cond_mel [B*n, n_mels] on device.
+        Every update `out = base + h * v(x, t)` is the epilogue of the last GEMM of the vector field;
+        with classifier-free guidance v = null + s (cond - null) it is two chained epilogues."""
         net = self.flowhigh.net
         method = self.odeint_kwargs['method']
         if method not in ('euler', 'midpoint'):
@@ -172,18 +175,42 @@ class FlowHighSR:
         net.set_cond(cond_mel, batch, n)
         t = torch.linspace(0, 1, time_steps + 1)
         y = y0
-        bufs = [torch.empty_like(y0), torch.empty_like(y0), torch.empty_like(y0)]
+        bufs = [torch.empty_like(y0) for _ in range(4)]
+
+        def axpy_field(x, tt, out, h, base):           # out = base + h * v(x, tt)
+            if cond_scale == 1.:
+                net.forward(x, tt, out, batch, n, alpha=h, res=base)
+            else:
+                net.forward(x, tt, bufs[3], batch, n, alpha=h * (1. - cond_scale), res=base, null_cond=True)
+                net.forward(x, tt, out, batch, n, alpha=h * cond_scale, res=bufs[3])
+
         for i in range(time_steps):
             t0, dt = t[i], t[i + 1] - t[i]
             out = bufs[i % 2]
             if method == 'euler':
-                net.forward(y, float(t0), out, batch, n, alpha=float(dt), res=y)
+                axpy_field(y, float(t0), out, float(dt), y)
             else:
                 half = 0.5 * dt
-                net.forward(y, float(t0), bufs[2], batch, n, alpha=float(half), res=y)
-                net.forward(bufs[2], float(t0 + half), out, batch, n, alpha=float(dt), res=y)
+                axpy_field(y, float(t0), bufs[2], float(half), y)
+                axpy_field(bufs[2], float(t0 + half), out, float(dt), y)
             y = out
         return y
+
+    def mel_cutoff_bins(self, cond_mel, batch, n):
+        """Device version of mel_cutoff_bins (cfm:134-159): int32 [B], no host loop, no sync."""
+        L, st = hip.lib(), hip.stream()
+        d = cond_mel.shape[-1]
+        energy = torch.empty(batch, d, dtype=torch.float32, device=self.device)
+        cut = torch.empty(batch, dtype=torch.int32, device=self.device)
+        hip.check(L.fh_mel_energy_f32(cond_mel.data_ptr(), energy.data_ptr(), batch, n, d, st), "fh_mel_energy_f32")
+        hip.check(L.fh_cutoff_index_f32(energy.data_ptr(), cut.data_ptr(), batch, d, 0.9995, st), "fh_cutoff_index_f32")
+        return cut
+
+    def _mel_replace(self, high, low, cut, batch, n):
+        out = torch.empty_like(high)
+        hip.check(hip.lib().fh_mel_splice_f32(low.data_ptr(), high.data_ptr(), cut.data_ptr(), out.data_ptr(), batch, n,
+                                              high.shape[-1], hip.stream()), "fh_mel_splice_f32")
+        return out
 
     @torch.no_grad()
     def sample(self, *, cond=None, cond_mask=None, time_steps=4, cond_scale=1., decode_to_audio=True,
@@ -193,8 +220,8 @@ class FlowHighSR:
         if cfm_method in _CFM_METHODS[1:]:
             if std_1 is None or std_2 is None:          # cfm:180-183 (resets BOTH)
                 std_1, std_2 = 1.0, self.sigma
-        if cond_scale != 1. or mel_pp or cond_mask is not None or cfm_method == 'independent_cfm_mix':
-            raise NotImplementedError("cond_scale != 1, mel_pp, masks and independent_cfm_mix: SURVEY.md 8f rank 2")
+        if cond_mask is not None:
+            raise NotImplementedError("cond_mask is a training-time option (SURVEY.md 8a row 2)")
         fh = self.flowhigh
         cond = cond.to(self.device, torch.float32)
         if cond.ndim == 2 or (cond.ndim == 3 and cond.shape[1] == 1):      # raw audio (cfm:91-92,185)
@@ -209,11 +236,20 @@ class FlowHighSR:
         if noise is None:
             noise = self._draw_noise(batch, n, generator)
         noise = noise.to(self.device, torch.float32).reshape(batch * n, -1).contiguous()
+        cut = None
         if cfm_method == 'basic_cfm':
             y0 = noise
         else:
-            y0 = cond_mel * std_1 + noise * std_2
-        mel = self._integrate(y0, cond_mel, batch, n, time_steps)
+            y0 = torch.empty_like(noise)                                    # cond * std_1 + eps * std_2
+            hip.check(hip.lib().fh_axpby_f32(cond_mel.data_ptr(), float(std_1), noise.data_ptr(), float(std_2),
+                                             y0.data_ptr(), y0.numel(), hip.stream()), "fh_axpby_f32")
+            if cfm_method == 'independent_cfm_mix':                         # cfm:231-237
+                cut = self.mel_cutoff_bins(cond_mel, batch, n)
+                y0 = self._mel_replace(noise, y0, cut, batch, n)
+        mel = self._integrate(y0, cond_mel, batch, n, time_steps, float(cond_scale))
+        if mel_pp:                                                          # cfm:278-279
+            cut = cut if cut is not None else self.mel_cutoff_bins(cond_mel, batch, n)
+            mel = self._mel_replace(mel, cond_mel, cut, batch, n)
         mel = mel.view(batch, n, -1)
         if not decode_to_audio:
             return mel

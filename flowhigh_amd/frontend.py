@@ -84,7 +84,7 @@ class PostProcessor:
                                      N_FFT // 2, 1, st), "fh_frame_f32")
             hip.gemm(w["frames"], self.c["w_fwd"], spec, B * F, P_WIDTH, N_FFT)
         hip.check(L.fh_spec_energy_f32(w["ss"].data_ptr(), w["energy"].data_ptr(), B, F, st), "fh_spec_energy_f32")
-        hip.check(L.fh_cutoff_index_f32(w["energy"].data_ptr(), w["cr"].data_ptr(), B, 0.99, st), "fh_cutoff_index_f32")
+        hip.check(L.fh_cutoff_index_f32(w["energy"].data_ptr(), w["cr"].data_ptr(), B, 1025, 0.99, st), "fh_cutoff_index_f32")
         hip.check(L.fh_spec_splice_f32(w["sp"].data_ptr(), w["ss"].data_ptr(), w["cr"].data_ptr(),
                                        w["sp"].data_ptr(), B, F, st), "fh_spec_splice_f32")
         hip.gemm(w["sp"], self.c["w_inv"], w["frames"], B * F, N_FFT, P_WIDTH)

@@ -60,7 +60,10 @@ _SIGS = {
     "fh_attention_f32": [_P, _P, _I, _I, _I, _F, _P],
     "fh_frame_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fh_spec_energy_f32": [_P, _P, _I, _I, _P],
-    "fh_cutoff_index_f32": [_P, _P, _I, _F, _P],
+    "fh_cutoff_index_f32": [_P, _P, _I, _I, _F, _P],
+    "fh_mel_energy_f32": [_P, _P, _I, _I, _I, _P],
+    "fh_mel_splice_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "fh_axpby_f32": [_P, _F, _P, _F, _P, C.c_longlong, _P],
     "fh_spec_splice_f32": [_P, _P, _P, _P, _I, _I, _P],
     "fh_istft_ola_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "fh_peak_scale_f32": [_P, _P, _I, _I, _F, _P],

@@ -148,7 +148,7 @@ def make_flow_state_dict(seed=0, dim=1024, dim_in=256, depth=2, heads=16, dim_he
         if bias:
             sd[name + ".bias"] = _uniform(name + ".bias", (out_f,), b, seed) + bias_mean
 
-    sd[FH + "null_cond"] = torch.zeros(dim_in)
+    sd[FH + "null_cond"] = _normal(FH + "null_cond", (dim_in,), 0.5, seed)   # zeros in the reference init
     sd[FH + "sinu_pos_emb.0.weights"] = _normal(FH + "sinu_pos_emb.0.weights", (dim // 2,), 1.0, seed)
     lin(FH + "sinu_pos_emb.1", dim, dim)
     lin(FH + "to_embed", dim, dim_in * 2)

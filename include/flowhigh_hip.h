@@ -192,9 +192,19 @@ int fh_frame_f32(const float* audio, const float* window, float* frames, int bat
 /* energy[b, f] = sum_t |S[b, t, f]| over the first n_frames frames, f < 1025 (P-layout in). */
 int fh_spec_energy_f32(const float* spec, float* energy, int batch, int n_frames, void* stream);
 
-/* get_cutoff_index (postprocessing.py:10-16): cr[b] = max{ j in [1,1024] :
- * cumsum(energy[b])[j] < thr * total } or 0. */
-int fh_cutoff_index_f32(const float* energy, int32_t* cr, int batch, float thr, void* stream);
+/* get_cutoff_index (postprocessing.py:10-16) / find_cutoff (cfm_superresolution.py:135-140):
+ * cr[b] = max{ j in [1, nbins-1] : cumsum(energy[b])[j] < thr * total } or 0; energy [B, nbins]. */
+int fh_cutoff_index_f32(const float* energy, int32_t* cr, int batch, int nbins, float thr,
+                        void* stream);
+
+/* Sampler options of cfm_superresolution.py: mel-domain cutoff energy (:134-159, input to
+ * fh_cutoff_index_f32 with thr 0.9995), low-band replacement mel_replace_ops (:146-152), and the
+ * independent_cfm_* prior cond * std_1 + eps * std_2 (:226-236).  mel tensors are [B, n, d]. */
+int fh_mel_energy_f32(const float* mel, float* energy, int batch, int n, int d, void* stream);
+int fh_mel_splice_f32(const float* low, const float* high, const int32_t* cut, float* out, int batch,
+                      int n, int d, void* stream);
+int fh_axpby_f32(const float* x, float a, const float* y, float b, float* out, long long n,
+                 void* stream);
 
 /* out[b,t,:] = bins < cr[b] ? src : pred   (P-layout, postprocessing.py:36-37). */
 int fh_spec_splice_f32(const float* pred, const float* src, const int32_t* cr, float* out,

@@ -31,6 +31,7 @@ CASES = {
     "alt_midpoint": (synth.ALT_CFG, 1, 0.2, 8000, "midpoint", 2, "basic_cfm", 0.0, False),
     "tiny_adaptive_i16": (synth.TINY_CFG, 2, 0.15, 24000, "euler", 2, "independent_cfm_adaptive", 1e-4, True),
     "tiny_ragged_16k": (synth.TINY_CFG, 3, 0.2017, 16000, "midpoint", 1, "basic_cfm", 0.0, False),
+    "tiny_mix": (synth.TINY_CFG, 4, 0.18, 12000, "euler", 1, "independent_cfm_mix", 0.05, False),
 }
 
 
@@ -69,6 +70,10 @@ def run_case(name, cfg, seed, seconds, sr_in, method, steps, cfm_method, sigma, 
     cr = model.postproc.get_cutoff_index(model.postproc.stft(cond_t))
     t_probe = torch.tensor(0.3)
     pred = model.flowhigh.forward_with_cond_scale(noise, times=t_probe, cond=cond_mel)
+    # sampler options that generate() never sets (sample() kwargs): CFG scale and mel post-processing
+    mel_opts = seeded(lambda: model.sample(cond=cond_t, time_steps=steps, cfm_method=cfm_method, cond_scale=1.3,
+                                           mel_pp=True, decode_to_audio=False, **kw))
+    cutoff_bins = model.mel_cutoff_bins(cond_mel)
 
     np.savez_compressed(
         OUT / f"{name}.npz",
@@ -76,7 +81,8 @@ def run_case(name, cfg, seed, seconds, sr_in, method, steps, cfm_method, sigma, 
         cfm_method=cfm_method, sigma=sigma, sd_checksum=sd_checksum(sd),
         audio=audio, noise=noise.numpy(), cond48=cond48,
         cond_mel=cond_mel.numpy(), mel=mel.numpy(), wav=wav.numpy(), out=out.numpy(),
-        cr=int(cr), flow_pred_t03=pred.numpy(),
+        cr=int(cr), flow_pred_t03=pred.numpy(), mel_cfg13_melpp=mel_opts.numpy(),
+        mel_cutoff_bins=np.asarray(cutoff_bins, dtype=np.int32),
     )
     print(f"{name}: T48={out.shape[-1]} N={n_frames} cr={cr} |wav|max={wav.abs().max():.4f} "
           f"out[:3]={out[0, :3].tolist()}")

@@ -183,12 +183,39 @@ def odeint_fixed(fn, y0, t, method):
     return y
 
 
+def mel_cutoff_bins(cond_mel, percentile=0.9995):
+    """cfm_superresolution.py:134-144,154-159: per clip, cumulative energy of exp(mel) over the mel
+    bins, summed over time; the python scan is kept verbatim in meaning."""
+    cuts = []
+    for i in range(cond_mel.size(0)):
+        energy = torch.cumsum(torch.sum(torch.abs(torch.exp(cond_mel[i])), dim=0), dim=0)
+        thr = energy[-1] * percentile
+        cut = 0
+        for k in range(1, energy.shape[0]):
+            if energy[-k] < thr:
+                cut = energy.shape[0] - k
+                break
+        cuts.append(cut)
+    return cuts
+
+
+def mel_replace(high, low, cuts):
+    """cfm_superresolution.py:146-152: bins >= cut from `high`, bins < cut from `low`."""
+    out = torch.zeros_like(high)
+    for i, c in enumerate(cuts):
+        out[i][..., c:] = high[i][..., c:]
+        out[i][..., :c] = low[i][..., :c]
+    return out
+
+
 def prior(cond_mel, noise, cfm_method="basic_cfm", std_1=1.0, std_2=0.0):
-    """cfm_superresolution.py:219-237 (independent_cfm_mix is not covered)."""
+    """cfm_superresolution.py:219-237."""
     if cfm_method == "basic_cfm":
         return noise
     if cfm_method in ("independent_cfm_adaptive", "independent_cfm_constant"):
         return cond_mel * std_1 + noise * std_2
+    if cfm_method == "independent_cfm_mix":
+        return mel_replace(noise, cond_mel * std_1 + noise * std_2, mel_cutoff_bins(cond_mel))
     raise NotImplementedError(cfm_method)
 
 
@@ -309,14 +336,28 @@ def post_processing(pred, src, length, return_cr=False):
 # ----------------------------------------------------------------------------
 # whole path                          flowhighsr.py:51-102 + cfm:162-284
 # ----------------------------------------------------------------------------
+def vector_field(sd, y, cond_mel, t, depth=2, cond_scale=1.0):
+    """flow.py:165-178 forward_with_cond_scale: classifier-free guidance against the null condition."""
+    logits = flow_forward(sd, y, cond_mel, t, depth)
+    if cond_scale == 1.0:
+        return logits
+    null = sd[FH + "null_cond"].to(cond_mel.dtype).expand_as(cond_mel)
+    null_logits = flow_forward(sd, y, null, t, depth)
+    return null_logits + (logits - null_logits) * cond_scale
+
+
 @torch.no_grad()
 def sample(sd, h, cond48, noise, time_steps=1, method="euler", cfm_method="basic_cfm",
-           sigma=0.0, depth=2, return_stages=False):
+           sigma=0.0, depth=2, return_stages=False, cond_scale=1.0, mel_pp=False, decode=True):
     """cond48 [B,T] (48 kHz, peak-normalised), noise [B,N,256] -> waveform [B,1,480N]."""
     cond_mel = logmel(cond48)
     y0 = prior(cond_mel, noise, cfm_method, 1.0, sigma)
     t = torch.linspace(0, 1, time_steps + 1, dtype=cond48.dtype)
-    mel = odeint_fixed(lambda tt, y: flow_forward(sd, y, cond_mel, tt, depth), y0, t, method)
+    mel = odeint_fixed(lambda tt, y: vector_field(sd, y, cond_mel, tt, depth, cond_scale), y0, t, method)
+    if mel_pp:                                                        # cfm:278-279
+        mel = mel_replace(mel, cond_mel, mel_cutoff_bins(cond_mel))
+    if not decode:
+        return mel
     wav = bigvgan_forward(sd, h, mel.transpose(1, 2))
     if return_stages:
         return wav, {"cond_mel": cond_mel, "mel": mel}

@@ -38,4 +38,4 @@ def load_golden(name):
     return d
 
 
-E2E_CASES = ["tiny_euler", "alt_midpoint", "tiny_adaptive_i16", "tiny_ragged_16k"]
+E2E_CASES = ["tiny_euler", "alt_midpoint", "tiny_adaptive_i16", "tiny_ragged_16k", "tiny_mix"]

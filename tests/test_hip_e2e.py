@@ -143,3 +143,19 @@ def test_unsupported_options_raise():
         m.generate(audio, 12000)
     with pytest.raises(NotImplementedError):
         FlowHighSR(m.flowhigh, use_torchode=True)
+
+
+@pytest.mark.parametrize("name", ["tiny_euler", "alt_midpoint", "tiny_mix"])
+def test_sampler_options_match_reference_golden(name):
+    """sample(cond_scale=1.3, mel_pp=True): classifier-free guidance against null_cond and the mel
+    low-band replacement, both evaluated on the device (vectors produced by the reference)."""
+    g = load_golden(name)
+    m, _ = model_for(g["cfg"], g["seed"], g["method"], g["cfm_method"], g["sigma"])
+    cond = torch.from_numpy(g["cond48"])[None]
+    kw = dict(std_2=1.) if g["cfm_method"] == "independent_cfm_adaptive" else {}
+    mel = m.sample(cond=cond, time_steps=g["steps"], cfm_method=g["cfm_method"], cond_scale=1.3, mel_pp=True,
+                   decode_to_audio=False, noise=torch.from_numpy(g["noise"]), **kw)
+    assert np.abs(mel.cpu().numpy() - g["mel_cfg13_melpp"]).max() <= 2e-4      # |mel| ~ 10, two fp32 transformer passes
+    n = g["cond_mel"].shape[1]
+    cut = m.mel_cutoff_bins(torch.from_numpy(g["cond_mel"]).cuda().reshape(n, -1).contiguous(), 1, n)
+    assert cut.cpu().tolist() == g["mel_cutoff_bins"].tolist()

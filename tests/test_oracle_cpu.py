@@ -34,6 +34,18 @@ def test_oracle_matches_reference_golden(name):
     assert np.abs(out.numpy() - g["out"]).max() <= 2e-6      # tolerance: fp32 thread-order noise
 
 
+@pytest.mark.parametrize("name", ["tiny_euler", "alt_midpoint", "tiny_mix"])
+def test_oracle_sampler_options(name):
+    """cond_scale != 1 (classifier-free guidance against null_cond) and mel_pp=True."""
+    g = load_golden(name)
+    sd = state_dict(g["cfg"], g["seed"])
+    cond = torch.from_numpy(g["cond48"])[None]
+    assert ref_cpu.mel_cutoff_bins(torch.from_numpy(g["cond_mel"])) == g["mel_cutoff_bins"].tolist()
+    mel = ref_cpu.sample(sd, g["cfg"], cond, torch.from_numpy(g["noise"]), g["steps"], g["method"], g["cfm_method"],
+                         g["sigma"], cond_scale=1.3, mel_pp=True, decode=False)
+    assert np.abs(mel.numpy() - g["mel_cfg13_melpp"]).max() <= 3e-5
+
+
 @pytest.mark.parametrize("name", ["tiny_euler", "alt_midpoint"])
 def test_oracle_flow_forward(name):
     g = load_golden(name)
