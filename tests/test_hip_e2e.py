@@ -137,7 +137,7 @@ def test_unsupported_options_raise():
     m, _ = model_for(synth.TINY_CFG, 0)
     audio = synth.lowres_clip(0, 0.3, 12000)
     with pytest.raises(NotImplementedError):
-        m.sample(cond=torch.zeros(1, 4800), cond_scale=2.0)
+        m.sample(cond=torch.zeros(1, 4800), cond_mask=torch.ones(1, 10, dtype=torch.bool))
     m.upsampling_method = "soxr"
     with pytest.raises(UnboundLocalError):
         m.generate(audio, 12000)
