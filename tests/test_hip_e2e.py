@@ -159,3 +159,17 @@ def test_sampler_options_match_reference_golden(name):
     n = g["cond_mel"].shape[1]
     cut = m.mel_cutoff_bins(torch.from_numpy(g["cond_mel"]).cuda().reshape(n, -1).contiguous(), 1, n)
     assert cut.cpu().tolist() == g["mel_cutoff_bins"].tolist()
+
+
+def test_baseline_config5_long_clip_multi_nfe():
+    """BASELINE.json configs[4] shape: 30 s clips, 24 -> 48 kHz, time_step = 4 midpoint (8 NFE,
+    N = 3000 frames, attention over 3000 keys), B = 2 here: finite, deterministic, peak-normalised."""
+    cfg = synth.SYNTH_CFG
+    m, _ = model_for(cfg, 0, "midpoint", upsampling="hip")
+    clips = [synth.lowres_clip(20 + i, 30.0, 24000) for i in range(2)]
+    noise = torch.cat([synth.prior_noise(20 + i, 3000) for i in range(2)], 0)
+    out1 = m.generate_batch(clips, 24000, 48000, 4, noise=noise)
+    out2 = m.generate_batch(clips, 24000, 48000, 4, noise=noise)
+    assert tuple(out1.shape) == (2, 1440000) and torch.isfinite(out1).all()
+    assert torch.equal(out1, out2)
+    assert torch.allclose(out1.abs().amax(dim=1).cpu(), torch.full((2,), 0.99), atol=1e-6)
