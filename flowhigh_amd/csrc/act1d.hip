@@ -14,8 +14,8 @@
 //   z[2i+1] = snake( 2 * sum_{q=-2..3} x[i+q] f_up[6-2q] )
 //   y[i]    = sum_{k=0..11} z[2i+k-5] f_dn[k]
 //
-// Block = 256 threads, one (group, batch, channel) row segment of TT = 1018 outputs:
-//   phase 1: x[t0-6 .. t0+TT+5] -> LDS                         (TT + 12 floats, clamped indices)
+// Block = 256 threads, one (group, batch, channel) row segment of TT = 256 PPT - 8 outputs:
+//   phase 1: x[t0-8 .. t0+TT+7] -> LDS                         (258 float4, clamped indices)
 //   phase 2: thread t makes the 4 consecutive (even, odd) pairs 4t .. 4t+3 of z -> LDS
 //   phase 3: thread t makes the 4 consecutive outputs 4t .. 4t+3 and stores them as one 16-byte vector.
 // Every LDS access is a 16-byte vector; the filter and snake arithmetic of phase 2 is on the
@@ -55,19 +55,18 @@ __device__ __noinline__ float sin_squared_slow(float a) {   // huge arguments on
 }
 
 constexpr int ACT_PPT = 4;                   // z pairs (and outputs) per thread, consecutive
-constexpr int ACT_PAIRS = 256 * ACT_PPT;     // 1024 z pairs
-constexpr int ACT_TT = ACT_PAIRS - 6;        // 1018 outputs per tile
-constexpr int ACT_XW = ACT_TT + 12;          // 1030 staged inputs
-constexpr int ACT_XLD = (ACT_XW + 255) / 256;
-constexpr int ACT_XS = ACT_PAIRS + 16;       // staged row incl. slack for whole-vector reads
+constexpr int ACT_PAIRS = 256 * ACT_PPT;     // z pairs of a tile: samples i = t0 - 4 + p
+constexpr int ACT_TT = ACT_PAIRS - 8;        // outputs per tile (multiple of 8: tiles start 16-byte aligned)
+constexpr int ACT_XS = ACT_TT + 16;          // staged inputs x[t0-8 .. t0+TT+7]
+constexpr int ACT_XF4 = ACT_XS / 4;          // ... as float4s
 
 // One block = one (group, batch, channel, tile).  Thread t owns pairs 4t .. 4t+3 and outputs
-// 4t .. 4t+3, so every LDS access is a whole 16-byte vector (3 reads per 4 pairs, 5 reads per 4
-// outputs instead of 7 scalar / 7 8-byte reads each) and the result is stored 16 bytes per lane.
+// 4t .. 4t+3: every LDS access is a 16-byte vector, and when rows are 16-byte aligned
+// (len % 4 == 0) so is every global access -- 4-byte-per-lane loads ran this kernel at 2.5 TB/s.
 __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restrict__ groups,
                                                     int batch, int channels, int len,
                                                     int tiles_per_row) {
-  __shared__ __attribute__((aligned(16))) float xs[ACT_XS];
+  __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
 
   const int tile = blockIdx.x % tiles_per_row;
@@ -84,23 +83,30 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   const int t0 = tile * ACT_TT;
   const int tid = threadIdx.x;
   const int zlast = 2 * len - 1;
+  const bool vec = (len & 3) == 0 && ((((size_t)G.x) | ((size_t)G.y)) & 15) == 0;
 
-  // phase 1: clamped (replicate) input window; all loads first, LDS writes after
-  float xin[ACT_XLD];
+  // phase 1: xs[j] = x[clamp(t0 - 8 + j)], j < XS; thread t stages float4 #t, #256+t, ...
 #pragma unroll
-  for (int i = 0; i < ACT_XLD; ++i) {
-    int t = t0 - 6 + tid + 256 * i;
-    t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
-    xin[i] = x[t];
-  }
+  for (int rep = 0; rep < (ACT_XF4 + 255) / 256; ++rep) {
+    const int f = tid + 256 * rep;
+    if (f >= ACT_XF4) break;
+    const int t = t0 - 8 + 4 * f;
+    f32x4 v;
+    if (vec && t >= 0 && t + 3 < len) {
+      v = *reinterpret_cast<const f32x4*>(x + t);
+    } else {
 #pragma unroll
-  for (int i = 0; i < ACT_XLD; ++i) {
-    const int j = tid + 256 * i;
-    if (j < ACT_XS) xs[j] = xin[i];
+      for (int e = 0; e < 4; ++e) {
+        int tt = t + e;
+        tt = tt < 0 ? 0 : (tt > len - 1 ? len - 1 : tt);
+        v[e] = x[tt];
+      }
+    }
+    *reinterpret_cast<f32x4*>(xs + 4 * f) = v;
   }
   __syncthreads();
 
-  // phase 2: pairs p = 4 tid + r (sample i = t0 - 3 + p); x[i+q] is xs[p + q + 3], q in [-3, 3]
+  // phase 2: pairs p = PPT tid + r, sample i = t0 - 4 + p; x[i+q] is xs[p + q + 4], q in [-3, 3]
   f32x2 fu2[7];             // taps of x[i-3 .. i+3] for (z[2i], z[2i+1]); the unused end tap is 0
 #pragma unroll
   for (int q = -3; q <= 3; ++q) {
@@ -108,10 +114,10 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
     fu2[q + 3][1] = q >= -2 ? G.up_taps[6 - 2 * q] : 0.f;
   }
   {
-    float xv[12];
+    float xv[ACT_PPT + 8];  // xs[PPT tid .. PPT tid + PPT + 7]; pair r uses xv[r + 1 .. r + 7]
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      const f32x4 t4 = *reinterpret_cast<const f32x4*>(xs + 4 * tid + 4 * v);
+    for (int v = 0; v < ACT_PPT / 4 + 2; ++v) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(xs + ACT_PPT * tid + 4 * v);
       xv[4 * v] = t4[0]; xv[4 * v + 1] = t4[1]; xv[4 * v + 2] = t4[2]; xv[4 * v + 3] = t4[3];
     }
     f32x2 zout[ACT_PPT];
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
     for (int r = 0; r < ACT_PPT; ++r) {
       f32x2 z = {0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 7; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + q]), fu2[q], z);
+      for (int q = 0; q < 7; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + 1 + q]), fu2[q], z);
       z = z * 2.f;
       const f32x2 arg = z * alpha;
       f32x2 s2 = sin_squared2(arg);
@@ -130,34 +136,36 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
       zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2, z);
     }
     // positions outside [0, 2L-1] are never used directly: phase 3 clamps its index instead
-    f32x4* zw = reinterpret_cast<f32x4*>(zs + 8 * tid);
-    zw[0] = (f32x4){zout[0][0], zout[0][1], zout[1][0], zout[1][1]};
-    zw[1] = (f32x4){zout[2][0], zout[2][1], zout[3][0], zout[3][1]};
+    f32x4* zw = reinterpret_cast<f32x4*>(zs + 2 * ACT_PPT * tid);
+#pragma unroll
+    for (int v = 0; v < ACT_PPT / 2; ++v)
+      zw[v] = (f32x4){zout[2 * v][0], zout[2 * v][1], zout[2 * v + 1][0], zout[2 * v + 1][1]};
   }
   __syncthreads();
 
-  // phase 3: outputs o = 4 tid + r, y[i] = sum_k z[clamp(2i + k - 5)] f_dn[k]; z[m] is zs[m - 2 (t0 - 3)]
+  // phase 3: outputs o = 4 tid + r (i = t0 + o); z[m] is zs[m - 2 (t0 - 4)], so
+  //          y[i] = sum_k zs[2 o + 3 + k] f_dn[k]  (interior) -- taps on zs[8 tid + 2 r + 3 ..]
   float fd[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) fd[k] = G.down_taps[k];
-  const int o0 = 4 * tid;
+  const int o0 = ACT_PPT * tid;
   const int i0 = t0 + o0;
   if (o0 >= ACT_TT || i0 >= len) return;
-  float zv[20];              // zs[2 o0 .. 2 o0 + 19]
+  float zv[2 * ACT_PPT + 16];   // zs[2 PPT tid .. + 2 PPT + 15]
 #pragma unroll
-  for (int v = 0; v < 5; ++v) {
-    const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 8 * tid + 4 * v);
+  for (int v = 0; v < ACT_PPT / 2 + 4; ++v) {
+    const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 2 * ACT_PPT * tid + 4 * v);
     zv[4 * v] = t4[0]; zv[4 * v + 1] = t4[1]; zv[4 * v + 2] = t4[2]; zv[4 * v + 3] = t4[3];
   }
   float out[ACT_PPT];
-  const int zbase = 2 * (t0 - 3);
+  const int zbase = 2 * (t0 - 4);
 #pragma unroll
   for (int r = 0; r < ACT_PPT; ++r) {
     const int i = i0 + r;
     float acc = 0.f;
-    if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {          // interior: taps on zs[2o + 1 .. 2o + 12]
+    if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {
 #pragma unroll
-      for (int k = 0; k < 12; ++k) acc = fmaf(zv[2 * r + 1 + k], fd[k], acc);
+      for (int k = 0; k < 12; ++k) acc = fmaf(zv[2 * r + 3 + k], fd[k], acc);
     } else if (i < len) {
 #pragma unroll
       for (int k = 0; k < 12; ++k) {
@@ -168,13 +176,15 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
     }
     out[r] = acc;
   }
-  const bool full = o0 + 3 < ACT_TT && i0 + 3 < len;
-  if (full && (((size_t)(y + i0)) & 15) == 0) {
-    *reinterpret_cast<f32x4*>(y + i0) = (f32x4){out[0], out[1], out[2], out[3]};
-  } else {
 #pragma unroll
-    for (int r = 0; r < ACT_PPT; ++r)
-      if (o0 + r < ACT_TT && i0 + r < len) y[i0 + r] = out[r];
+  for (int v = 0; v < ACT_PPT / 4; ++v) {   // o0 + PPT - 1 < TT always holds for o0 < TT (TT % PPT == 0)
+    if (vec && i0 + 4 * v + 3 < len) {
+      *reinterpret_cast<f32x4*>(y + i0 + 4 * v) = (f32x4){out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+    } else {
+#pragma unroll
+      for (int r = 4 * v; r < 4 * v + 4; ++r)
+        if (i0 + r < len) y[i0 + r] = out[r];
+    }
   }
 }
 
