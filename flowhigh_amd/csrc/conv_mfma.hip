@@ -253,11 +253,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bf[(ks + 1) & 1][nt] = xsb[(8 * q1 + e1) * XW + nt * 32];
       }
-#if defined(FH_ABLATE) && FH_ABLATE == 3
-      if (false) {
-#else
       if (ks == 1) {                              // global prefetch
-#endif
         if (it + 2 < nsteps) load_w(LOAD, S2, k2.c, k2.j);
         if (k0.j == 0 && more_chunks) {           // slab of the next chunk, stored after its last tap
           if ((k0.c + 1) * CK < S0.cin) {
@@ -268,12 +264,10 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
           }
         }
       }
-#if !defined(FH_ABLATE) || FH_ABLATE != 2
       if (ks == KS / 2) {                         // LDS stores of the tiles of step it+1
         if (it + 1 < nsteps) store_w(STORE, wbuf ^ 1);
         if (flip_x) store_x(xbuf ^ 1);
       }
-#endif
       if (ks == KS - 2) xoff_next = toff[k1.s * FH_CONV_MAX_TAPS + k1.j];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -284,9 +278,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
                                                              acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-#if !defined(FH_ABLATE) || FH_ABLATE != 1
     __syncthreads();
-#endif
     wbuf ^= 1;
     if (flip_x) xbuf ^= 1;
     xoff_cur = xoff_next;

@@ -65,26 +65,40 @@ __global__ __launch_bounds__(256) void spec_energy_kernel(const float* __restric
 
 // torch.cumsum on CPU accumulates float32 input in double and rounds every prefix to float;
 // the threshold product is a float32 multiply (postprocessing.py:11-12).
-__global__ void cutoff_kernel(const float* __restrict__ energy, int32_t* __restrict__ cr, int nbins,
-                              float thr) {
-  __shared__ float cum[1025];
-  const int b = blockIdx.x;
-  if (threadIdx.x == 0) {
-    double c = 0.0;
-    for (int f = 0; f < nbins; ++f) {
-      c += (double)energy[b * nbins + f];
-      cum[f] = (float)c;
-    }
-    const float limit = cum[nbins - 1] * thr;
-    int res = 0;
-    for (int i = 1; i < nbins; ++i) {
-      if (cum[nbins - i] < limit) {
-        res = nbins - i;
-        break;
-      }
-    }
-    cr[b] = res;
+__global__ __launch_bounds__(64) void cutoff_kernel(const float* __restrict__ energy, int32_t* __restrict__ cr,
+                                                    int nbins, float thr) {
+  // One wave per clip: lane l owns the contiguous chunk [l * per, (l + 1) * per) of the bins; chunk
+  // sums are scanned across lanes in double, then every prefix is rounded to float exactly where the
+  // sequential double accumulation of torch.cumsum would round it (same values up to 1e-16 relative).
+  __shared__ float cum[1088];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int per = (nbins + 63) / 64;
+  const int f0 = lane * per;
+  double local = 0.0;
+  for (int f = f0; f < f0 + per && f < nbins; ++f) local += (double)energy[b * nbins + f];
+  double incl = local;                              // inclusive scan of the chunk sums
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
+  double c = incl - local;
+  for (int f = f0; f < f0 + per && f < nbins; ++f) {
+    c += (double)energy[b * nbins + f];
+    cum[f] = (float)c;
+  }
+  __syncthreads();
+  const float limit = cum[nbins - 1] * thr;
+  // largest j in [1, nbins - 1] with cum[j] < limit, else 0
+  int best = 0;
+  for (int f = f0; f < f0 + per && f < nbins; ++f)
+    if (f >= 1 && cum[f] < limit) best = f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int other = __shfl_xor(best, o, 64);
+    best = other > best ? other : best;
+  }
+  if (lane == 0) cr[b] = best;
 }
 
 // energy[b, d] = sum_n exp(mel[b, n, d])   (locate_cutoff_freq on exp(mel), cfm_superresolution.py:134-159)

@@ -12,8 +12,8 @@
 // 8q + e and 8q + 4 + e).  Global loads of tile i+1 are issued into registers before the MFMAs of
 // tile i (register prefetch), LDS is single buffered, two barriers per tile.
 //
-// Tile variants: 128 x 128 (wave 64 x 64) and 64 x 128 (wave 32 x 64) -- the latter keeps more
-// CUs busy at M = N_frames ~ 1000.  N is tiled by 128 in both, W is padded to a multiple of 128 rows.
+// Tile variants: 128 x 128 (wave 64 x 64), 64 x 128 (wave 32 x 64) and 64 x 64 (wave 32 x 32) -- the
+// smaller ones keep more CUs busy at M = N_frames ~ 1000.  W is padded to a multiple of 128 rows.
 #include "fh_common.h"
 
 namespace {
@@ -26,14 +26,14 @@ __device__ __forceinline__ float epi_pair(float first, float second, int mode) {
   return sqrtf(first * first + second * second + 1e-9f);
 }
 
-template <int MT>   // wave tile = (32 MT) x 64, block tile = (64 MT) x 128
+template <int MT, int NT>   // wave tile = (32 MT) x (32 NT), block tile = (64 MT) x (64 NT)
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda,
                                                    const float* __restrict__ W,
                                                    const float* __restrict__ bias,
                                                    const float* __restrict__ R, int ldr,
                                                    float* __restrict__ C, int ldc, int M, int N,
                                                    int K, float alpha, int mode, int m_tiles) {
-  constexpr int BM = 64 * MT, BN = 128, NT = 2;
+  constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr int AREG = BM * 8 / 256;   // float4 per thread for the A tile
   constexpr int WREGS = BN * 8 / 256;  // float4 per thread for the W tile
   __shared__ __attribute__((aligned(16))) float As[BM * LP];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     const int blk = (n0 >> 6) + wn;                 // packed block index
     const int n_out = blk * 32 + l31;
     const int n_first = n0 + wn * 64 + l31;         // packed column of `first`
-    if (n_first < N) {
+    if (NT == 2 && n_first < N) {
       const float b1 = bias ? bias[n_first] : 0.f;
       const float b2 = bias ? bias[n_first + 32] : 0.f;
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m >= M) continue;
-          C[(size_t)m * ldc + n_out] = epi_pair(acc[mt][0][r] + b1, acc[mt][1][r] + b2, mode);
+          C[(size_t)m * ldc + n_out] = epi_pair(acc[mt][0][r] + b1, acc[mt][NT - 1][r] + b2, mode);
         }
     }
   }
@@ -207,20 +207,25 @@ extern "C" int fh_gemm_f32(const float* A, int lda, const float* W, const float*
   FH_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "fh_gemm_f32: unknown epilogue %d", epilogue);
   if (epilogue == FH_EPI_GEGLU || epilogue == FH_EPI_MAG)
     FH_CHECK_ARG(N % 64 == 0, "fh_gemm_f32: pair epilogue needs N %% 64 == 0");
-  const int n_tiles = fh_cdiv(N, 128);
   hipStream_t st = (hipStream_t)stream;
-  // small problems: 64-row tiles to fill the chip
-  const bool small = (long long)fh_cdiv(M, 128) * n_tiles < 512;
-  if (small) {
+  const bool plain = epilogue == FH_EPI_LINEAR || epilogue == FH_EPI_LOGCLAMP;
+  const long long t128 = (long long)fh_cdiv(M, 128) * fh_cdiv(N, 128);
+  const long long t64x128 = (long long)fh_cdiv(M, 64) * fh_cdiv(N, 128);
+  if (plain && t64x128 < 200) {
+    // few tiles (M = frames ~ 1000, N = 1024): 64 x 64 tiles put a block on every CU
     const int m_tiles = fh_cdiv(M, 64);
-    const int blocks = fh_cdiv((long long)m_tiles * n_tiles, 8) * 8;
-    // pad n range so that every block has a valid (or out-of-range -> early exit) tile
-    hipLaunchKernelGGL(gemm_kernel<1>, dim3(blocks), dim3(256), 0, st, A, lda, W, bias, R, ldr, C, ldc,
+    const int blocks = fh_cdiv((long long)m_tiles * fh_cdiv(N, 64), 8) * 8;
+    hipLaunchKernelGGL((gemm_kernel<1, 1>), dim3(blocks), dim3(256), 0, st, A, lda, W, bias, R, ldr, C, ldc,
+                       M, N, K, alpha, epilogue, m_tiles);
+  } else if (t128 < 512) {
+    const int m_tiles = fh_cdiv(M, 64);
+    const int blocks = fh_cdiv((long long)m_tiles * fh_cdiv(N, 128), 8) * 8;
+    hipLaunchKernelGGL((gemm_kernel<1, 2>), dim3(blocks), dim3(256), 0, st, A, lda, W, bias, R, ldr, C, ldc,
                        M, N, K, alpha, epilogue, m_tiles);
   } else {
     const int m_tiles = fh_cdiv(M, 128);
-    const int blocks = fh_cdiv((long long)m_tiles * n_tiles, 8) * 8;
-    hipLaunchKernelGGL(gemm_kernel<2>, dim3(blocks), dim3(256), 0, st, A, lda, W, bias, R, ldr, C, ldc,
+    const int blocks = fh_cdiv((long long)m_tiles * fh_cdiv(N, 128), 8) * 8;
+    hipLaunchKernelGGL((gemm_kernel<2, 2>), dim3(blocks), dim3(256), 0, st, A, lda, W, bias, R, ldr, C, ldc,
                        M, N, K, alpha, epilogue, m_tiles);
   }
   FH_CHECK_LAUNCH("fh_gemm_f32");
