@@ -173,3 +173,19 @@ def test_baseline_config5_long_clip_multi_nfe():
     assert tuple(out1.shape) == (2, 1440000) and torch.isfinite(out1).all()
     assert torch.equal(out1, out2)
     assert torch.allclose(out1.abs().amax(dim=1).cpu(), torch.full((2,), 0.99), atol=1e-6)
+
+
+@pytest.mark.parametrize("secs,sr_in,B", [(0.05, 12000, 1), (0.113, 16000, 3), (0.31, 8000, 2)])
+def test_short_and_odd_length_clips_vs_oracle(secs, sr_in, B):
+    """Few-frame clips, lengths that are not multiples of the hop, the vector width or the tile sizes."""
+    cfg = synth.TINY_CFG
+    m, sd = model_for(cfg, 0, "euler")
+    clips = [synth.lowres_clip(40 + i, secs, sr_in) for i in range(B)]
+    t48 = len(clips[0]) * (48000 // sr_in)
+    n = t48 // 480
+    noise = torch.cat([synth.prior_noise(40 + i, n) for i in range(B)], 0)
+    out = m.generate_batch(clips, sr_in, 48000, 1, noise=noise)
+    assert tuple(out.shape) == (B, t48)
+    for i in range(B):
+        ref = ref_cpu.generate(sd, cfg, clips[i], sr_in, noise[i:i + 1], 1, "euler")
+        assert (out[i:i + 1].cpu() - ref).abs().max().item() <= TOL_WAVEFORM
