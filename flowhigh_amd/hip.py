@@ -5,11 +5,12 @@ pointers are passed as integers (`tensor.data_ptr()`), the stream as
 `torch.cuda.current_stream().cuda_stream`.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 import torch
 
-import os
+# FH_LIB_PATH: load another build of the same ABI (used for A/B experiments only)
 LIB_PATH = Path(os.environ.get("FH_LIB_PATH", Path(__file__).resolve().parent / "lib" / "libflowhigh_hip.so"))
 
 CONV_MAX_TAPS = 16
