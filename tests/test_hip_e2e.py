@@ -189,3 +189,18 @@ def test_short_and_odd_length_clips_vs_oracle(secs, sr_in, B):
     for i in range(B):
         ref = ref_cpu.generate(sd, cfg, clips[i], sr_in, noise[i:i + 1], 1, "euler")
         assert (out[i:i + 1].cpu() - ref).abs().max().item() <= TOL_WAVEFORM
+
+
+def test_baseline_config_full_size_vs_oracle():
+    """BASELINE.json configs[1] at its real size (one 10 s clip, 12 -> 48 kHz, euler x 1, full-width
+    SYNTH-CFG vocoder) against the CPU oracle (~20 s of host time on 16 threads)."""
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 0 else 16))
+    cfg = synth.SYNTH_CFG
+    m, sd = model_for(cfg, 0, "euler")
+    audio = synth.lowres_clip(0, 10.0, 12000)
+    noise = synth.prior_noise(0, 1000)
+    out, st = m.generate_batch([audio], 12000, 48000, 1, noise=noise, return_stages=True)
+    ref, rs = ref_cpu.generate(sd, cfg, audio, 12000, noise, 1, "euler", return_stages=True)
+    assert int(st["cr"][0].item()) == rs["cr"]
+    assert (st["wav"].cpu() - rs["wav"]).abs().max().item() <= TOL_WAVEFORM
+    assert (out.cpu() - ref).abs().max().item() <= TOL_WAVEFORM
