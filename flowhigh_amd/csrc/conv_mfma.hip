@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __rest
 }
 
 struct TileInfo { int bm, bn; };
-constexpr TileInfo kTiles[] = {{128, 128}, {192, 128}, {96, 256}, {64, 256}, {32, 512}, {128, 64}};
+constexpr TileInfo kTiles[] = {{128, 128}, {192, 128}, {96, 256}, {64, 256}, {32, 512}, {128, 64}, {96, 128}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 }  // namespace
@@ -463,6 +463,7 @@ extern "C" int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, in
     FH_CONV_CASE(3, 2, 2, 1, 4)
     FH_CONV_CASE(4, 1, 4, 1, 4)
     FH_CONV_CASE(5, 2, 1, 2, 2)
+    FH_CONV_CASE(6, 3, 1, 1, 4)
   }
 #undef FH_CONV_CASE
   return FH_E_ARG;

@@ -22,7 +22,7 @@ from . import hip
 
 VOC = "flowhigh.audio_enc_dec.vocoder."
 # preference order among equal padded heights: tiles that keep 3 blocks per CU resident first
-_TILE_PREF = [(0, 128), (3, 64), (1, 192), (2, 96), (4, 32)]
+_TILE_PREF = [(0, 128), (6, 96), (3, 64), (1, 192), (2, 96), (4, 32)]
 # experiments only: FH_CONV_TILE_OVERRIDE="0:5" runs every 128x128 launch with the 128x64 tile
 _TILE_OVERRIDE = {int(a): int(b) for a, b in
                   (kv.split(":") for kv in os.environ.get("FH_CONV_TILE_OVERRIDE", "").split(",") if kv)}

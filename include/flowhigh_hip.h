@@ -82,7 +82,7 @@ typedef struct {
 } fh_conv_group;
 
 int fh_sizeof_conv_group(void);
-/* tile_cfg: 0 = 128x128, 1 = 192x128, 2 = 96x256, 3 = 64x256, 4 = 32x512, 5 = 128x64 (co x n) */
+/* tile_cfg: 0 = 128x128, 1 = 192x128, 2 = 96x256, 3 = 64x256, 4 = 32x512, 5 = 128x64, 6 = 96x128 (co x n) */
 int fh_conv_tile_m(int tile_cfg);
 int fh_conv_tile_n(int tile_cfg);
 /* groups: device array of n_groups descriptors; all groups share cout_pad and n_len. */
