@@ -8,40 +8,59 @@
 
 namespace {
 
-// thread = 4 consecutive channels; block = 64 threads (256 channels) x TOK tokens walked serially.
-constexpr int DW_TOK = 2;
+// Block = 128 channels x 32 tokens.  The x slab [32 + ksz - 1][128] is staged in LDS once (every
+// element is used by ksz outputs); thread = (channel quad, token lane) makes 4 tokens x 4 channels
+// with 16-byte LDS reads; weights are read as [ksz][dim] (transposed on the host) so that a tap is
+// one coalesced 16-byte load per thread.
+constexpr int DW_TOK = 32;
+constexpr int DW_CH = 128;
 constexpr int DW_KMAX = 63;
 
 __global__ __launch_bounds__(256) void dwconv_gelu_res_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ wt,
                                                               const float* __restrict__ bias,
                                                               float* __restrict__ y, int n, int dim,
                                                               int ksz) {
-  // grid: (dim / 1024 * ..., token tiles, batch).  Each thread owns one channel quad.
-  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c4 >= dim) return;
-  const int b = blockIdx.z;
+  extern __shared__ __attribute__((aligned(16))) float xs[];     // [DW_TOK + ksz - 1][DW_CH]
+  const int c0 = blockIdx.x * DW_CH;
   const int tok0 = blockIdx.y * DW_TOK;
+  const int b = blockIdx.z;
   const int half = ksz / 2;
+  const int rows = DW_TOK + ksz - 1;
   const float* xb = x + (size_t)b * n * dim;
   float* yb = y + (size_t)b * n * dim;
+  const int tid = threadIdx.x;
+  // stage: 32 threads per row (128 channels = 32 float4), 8 rows per pass; zero outside [0, n)
+  for (int r = tid >> 5; r < rows; r += 8) {
+    const int t = tok0 + r - half;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t >= 0 && t < n) v = *reinterpret_cast<const f32x4*>(xb + (size_t)t * dim + c0 + 4 * (tid & 31));
+    *reinterpret_cast<f32x4*>(xs + r * DW_CH + 4 * (tid & 31)) = v;
+  }
+  __syncthreads();
+  const int cq = tid & 31, tl = tid >> 5;            // channel quad, token lane: tokens tl, tl + 8, ...
+  const int c4 = c0 + 4 * cq;
   const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c4);
-  for (int t = tok0; t < tok0 + DW_TOK && t < n; ++t) {
-    f32x4 acc = bv;
-    for (int j = 0; j < ksz; ++j) {
-      int tt = t + j - half;
-      if (tt < 0 || tt >= n) continue;
-      f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (size_t)tt * dim + c4);
-      // w is [dim, ksz]: four channels -> four strided scalars (L1 resident)
-      acc[0] = fmaf(w[(c4 + 0) * ksz + j], xv[0], acc[0]);
-      acc[1] = fmaf(w[(c4 + 1) * ksz + j], xv[1], acc[1]);
-      acc[2] = fmaf(w[(c4 + 2) * ksz + j], xv[2], acc[2]);
-      acc[3] = fmaf(w[(c4 + 3) * ksz + j], xv[3], acc[3]);
+  f32x4 acc[4] = {bv, bv, bv, bv};
+  for (int j = 0; j < ksz; ++j) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wt + (size_t)j * dim + c4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (tl + 8 * q + j) * DW_CH + 4 * cq);
+      acc[q][0] = fmaf(w4[0], xv[0], acc[q][0]);
+      acc[q][1] = fmaf(w4[1], xv[1], acc[q][1]);
+      acc[q][2] = fmaf(w4[2], xv[2], acc[q][2]);
+      acc[q][3] = fmaf(w4[3], xv[3], acc[q][3]);
     }
-    f32x4 xc = *reinterpret_cast<const f32x4*>(xb + (size_t)t * dim + c4);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = tok0 + tl + 8 * q;
+    if (t >= n) continue;
+    const f32x4 xc = *reinterpret_cast<const f32x4*>(xs + (tl + 8 * q + half) * DW_CH + 4 * cq);
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = xc[e] + gelu_erf(acc[e]);
+    for (int e = 0; e < 4; ++e) o[e] = xc[e] + gelu_erf(acc[q][e]);
     *reinterpret_cast<f32x4*>(yb + (size_t)t * dim + c4) = o;
   }
 }
@@ -121,9 +140,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(float* __restrict__ qk
 extern "C" int fh_dwconv_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
                                       int batch, int n, int dim, int ksz, void* stream) {
   FH_CHECK_ARG(x && w && bias && y && batch > 0 && n > 0, "fh_dwconv_gelu_res_f32: bad args");
-  FH_CHECK_ARG(dim % 4 == 0 && (ksz & 1) && ksz <= DW_KMAX, "fh_dwconv_gelu_res_f32: dim %d / ksz %d unsupported", dim, ksz);
-  dim3 grid(fh_cdiv(dim / 4, 256), fh_cdiv(n, DW_TOK), batch);
-  hipLaunchKernelGGL(dwconv_gelu_res_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, n,
+  FH_CHECK_ARG(dim % DW_CH == 0 && (ksz & 1) && ksz <= DW_KMAX, "fh_dwconv_gelu_res_f32: dim %d / ksz %d unsupported", dim, ksz);
+  dim3 grid(dim / DW_CH, fh_cdiv(n, DW_TOK), batch);
+  const size_t lds = (size_t)(DW_TOK + ksz - 1) * DW_CH * sizeof(float);
+  hipLaunchKernelGGL(dwconv_gelu_res_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, n,
                      dim, ksz);
   FH_CHECK_LAUNCH("fh_dwconv_gelu_res_f32");
   return FH_OK;

@@ -71,7 +71,7 @@ class FlowNet:
         self._e_null = None
         dw = g("conv_embed.dw_conv1d.0.weight")
         self.dw_k = dw.shape[-1]
-        self.dw_w = dw.reshape(self.dim, self.dw_k).contiguous().to(dev)
+        self.dw_w = dw.reshape(self.dim, self.dw_k).t().contiguous().to(dev)       # [ksz, dim], tap-major
         self.dw_b = g("conv_embed.dw_conv1d.0.bias").to(dev)
         self.sinu_w = g("sinu_pos_emb.0.weights").to(dev)
         self.t_w = g("sinu_pos_emb.1.weight").contiguous().to(dev)
@@ -100,7 +100,7 @@ class FlowNet:
         self.final_gamma = g("transformer.final_norm.gamma").to(dev)
         self.w_pred = _pad_rows(g("to_pred.weight")).to(dev)
         self.inv_freq = g("transformer.rotary_emb.inv_freq")
-        self._ws = {}
+        self._ws = hip.ShapeCache()
 
     def workspace(self, batch, n):
         key = (batch, n)

@@ -34,7 +34,7 @@ class LogMel:
     def __init__(self, device):
         self.device = torch.device(device)
         self.c = _Const.get(device)
-        self._ws = {}
+        self._ws = hip.ShapeCache()
 
     def __call__(self, audio):
         """audio [B, T] on device -> log-mel [B*N, 256] (token-major rows), N = T // 480."""
@@ -61,7 +61,7 @@ class PostProcessor:
     def __init__(self, device):
         self.device = torch.device(device)
         self.c = _Const.get(device)
-        self._ws = {}
+        self._ws = hip.ShapeCache()
 
     def __call__(self, pred, src, length, return_cr=False):
         """pred [B, Tp], src [B, T] -> [B, length]; per-clip cutoff, splice, iSTFT, 0.99 peak."""

@@ -99,6 +99,27 @@ def lib():
     return L
 
 
+class ShapeCache(dict):
+    """Per-shape workspaces / launch plans, bounded: a service that sees many clip lengths must not
+    accumulate a 645 MB vocoder workspace for each of them.  Evicts the least recently used entry
+    (its device memory returns to torch's caching allocator; in-flight kernels are safe because
+    the allocator reuses memory in stream order)."""
+
+    def __init__(self, max_entries=6):
+        super().__init__()
+        self.max_entries = max_entries
+
+    def __getitem__(self, key):
+        v = super().pop(key)
+        super().__setitem__(key, v)            # most recently used last
+        return v
+
+    def __setitem__(self, key, value):
+        if key not in self and len(self) >= self.max_entries:
+            super().pop(next(iter(self)))
+        super().__setitem__(key, value)
+
+
 def check(rc, what=""):
     if rc != 0:
         raise HipError(f"{what}: rc={rc}: {lib().fh_last_error().decode()}")

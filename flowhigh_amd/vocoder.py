@@ -213,7 +213,7 @@ class Vocoder:
         self.post_w = g("conv_post.weight")[0].contiguous().to(dev)      # [c_last, 7]
         self.post_b = g("conv_post.bias").to(dev)
         self.post_k = self.post_w.shape[-1]
-        self._plans = {}
+        self._plans = hip.ShapeCache()
         self.conv_timing = None
         self.chain_streams = os.environ.get("FH_VOCODER_STREAMS", "0") == "1"
         self._side = None

@@ -158,7 +158,8 @@ int fh_time_fourier_f32(const float* w, float t, float* out, int half_dim, void*
  * Transformer pointwise / reduction kernels.
  * --------------------------------------------------------------------------------- */
 /* ConvPositionEmbed + residual (models/transformer.py:16-46, flow.py:240):
- * y[b,n,c] = x[b,n,c] + gelu_erf(bias[c] + sum_j w[c,j] * x[b, n + j - ksz/2, c]), zero padded. */
+ * y[b,n,c] = x[b,n,c] + gelu_erf(bias[c] + sum_j w[c,j] * x[b, n + j - ksz/2, c]), zero padded.
+ * w is passed TRANSPOSED, [ksz, dim] (tap-major), dim % 128 == 0. */
 int fh_dwconv_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
                            int batch, int n, int dim, int ksz, void* stream);
 

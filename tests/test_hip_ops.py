@@ -246,7 +246,7 @@ def test_dwconv_gelu_res():
     x, w, b = rnd(B, n, D, seed=130), rnd(D, 1, k, seed=131, scale=0.2), rnd(D, seed=132)
     ref = F.gelu(F.conv1d(x.transpose(1, 2), w, b, padding=15, groups=D)).transpose(1, 2) + x
     y = torch.empty(B, n, D, device=DEV)
-    xd, wd, bd = x.to(DEV), w.reshape(D, k).contiguous().to(DEV), b.to(DEV)
+    xd, wd, bd = x.to(DEV), w.reshape(D, k).t().contiguous().to(DEV), b.to(DEV)      # weights tap-major [k, D]
     hip.check(hip.lib().fh_dwconv_gelu_res_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, n, D, k,
                                                hip.stream()), "dwconv")
     assert maxdiff(y, ref) <= 5e-6
