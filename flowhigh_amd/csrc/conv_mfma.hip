@@ -29,7 +29,6 @@
 
 namespace {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT_RUN = 8;       // n-tiles of a panel that run together on one XCD
 
 // Debug hook (fh_debug_set_conv_trace): when set, every block appends {blockIdx | hw_id << 32,
@@ -48,20 +47,6 @@ struct ConvCfg {
   static constexpr int WREG = (WF4 + 255) / 256;
   static constexpr int LDS_FLOATS = 2 * BM * WP + 2 * CK * XW;
 };
-
-// Wave-uniform values the compiler cannot prove uniform (anything loaded through a selected
-// pointer) are pinned to SGPRs with readfirstlane, so that buffer descriptors built from them
-// do not get wrapped in waterfall loops.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ const float* uni(const float* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const float*)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
 
 struct SegU {          // wave-uniform copy of the hot fields of one fh_conv_seg
   const float* x;

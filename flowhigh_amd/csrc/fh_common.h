@@ -28,6 +28,22 @@ void fh_set_error(const char* fmt, ...);
     }                                                                    \
   } while (0)
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Wave-uniform values the compiler cannot prove uniform (anything loaded through a selected
+// pointer) are pinned to SGPRs with readfirstlane, so that buffer descriptors built from them
+// do not get wrapped in waterfall loops.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const float* uni(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
 static inline int fh_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // 64-lane butterfly reductions (wave = 64 on gfx950).

@@ -32,6 +32,17 @@ class ConvGroup(C.Structure):
                 ("out_stride", C.c_int32), ("out_phase", C.c_int32), ("scale", C.c_float)]
 
 
+class WinoSeg(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("u", C.c_void_p), ("cin", C.c_int32), ("ngrp", C.c_int32),
+                ("center", C.c_int32), ("pad_", C.c_int32)]
+
+
+class WinoGroup(C.Structure):
+    _fields_ = [("seg", WinoSeg * CONV_MAX_SEG), ("bias", C.c_void_p), ("res", C.c_void_p * CONV_MAX_SEG),
+                ("out", C.c_void_p), ("nseg", C.c_int32), ("nres", C.c_int32), ("cout", C.c_int32),
+                ("cout_pad", C.c_int32), ("len", C.c_int32), ("scale", C.c_float)]
+
+
 class ActGroup(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("alpha", C.c_void_p), ("inv_beta", C.c_void_p),
                 ("up_taps", C.c_float * 12), ("down_taps", C.c_float * 12)]
@@ -49,6 +60,8 @@ _SIGS = {
     "fh_conv_tile_m": [_I],
     "fh_conv_tile_n": [_I],
     "fh_conv_grouped_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
+    "fh_sizeof_wino_group": [],
+    "fh_conv_wino_f32": [_P, _I, _I, _I, _I, _I, _P],
     "fh_debug_set_conv_trace": [_P],
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
@@ -93,7 +106,8 @@ def lib():
     L.fh_last_error.restype = C.c_char_p
     if L.fh_abi_version() != 1:
         raise HipError("libflowhigh_hip.so ABI version mismatch")
-    if L.fh_sizeof_conv_group() != C.sizeof(ConvGroup) or L.fh_sizeof_act_group() != C.sizeof(ActGroup):
+    if L.fh_sizeof_conv_group() != C.sizeof(ConvGroup) or L.fh_sizeof_act_group() != C.sizeof(ActGroup) \
+            or L.fh_sizeof_wino_group() != C.sizeof(WinoGroup):
         raise HipError("descriptor struct layout mismatch between hip.py and flowhigh_hip.h")
     _lib = L
     return L

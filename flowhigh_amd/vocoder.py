@@ -115,6 +115,59 @@ def make_act_group(x, y, p):
 
 
 
+# Winograd F(4,3) weight transform G (6 x 3); interpolation points 0, +-1, +-2, inf
+_WINO_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+           [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
+WINO_BM = 64
+
+
+def pack_wino_weight(w, cout_pad):
+    """Conv1d weight [co, ci, k] -> transformed [ci/16, G, 6, cout_pad, 16], G = ceil(k/3):
+    u[c, g, xi, co, :] = sum_j G[xi][j] w[co, 16c:16c+16, 3g + j] (float64 on the host, taps past k = 0)."""
+    co, ci, k = w.shape
+    if ci % 16:
+        raise ValueError(f"input channels {ci} must be a multiple of 16")
+    ng = -(-k // 3)
+    wp = torch.zeros(co, ci, 3 * ng, dtype=torch.float64)
+    wp[:, :, :k] = w.double()
+    gm = torch.tensor(_WINO_G, dtype=torch.float64)
+    u = torch.einsum("xj,ocgj->gxoc", gm, wp.view(co, ci, ng, 3))                 # [G, 6, co, ci]
+    u = u.reshape(ng, 6, co, ci // 16, 16).permute(3, 0, 1, 2, 4)                # [ci/16, G, 6, co, 16]
+    p = torch.zeros(ci // 16, ng, 6, cout_pad, 16, dtype=torch.float32)
+    p[:, :, :, :co, :] = u.float()
+    return p.contiguous()
+
+
+def make_wino_seg(x, u, cin, k):
+    s = hip.WinoSeg()
+    s.x, s.u, s.cin, s.ngrp, s.center = hip.ptr(x), hip.ptr(u), cin, -(-k // 3), (k - 1) // 2
+    return s
+
+
+def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0):
+    g = hip.WinoGroup()
+    # the kernel walks the segments in one pass per tap-group count, largest first
+    for i, s in enumerate(sorted(segs, key=lambda s: -s.ngrp)):
+        g.seg[i] = s
+    g.nseg, g.nres = len(segs), len(res)
+    g.bias = hip.ptr(bias)
+    for i, r in enumerate(res):
+        g.res[i] = hip.ptr(r)
+    g.out = hip.ptr(out)
+    if max(cout, max(s.cin for s in segs)) * length * 4 >= 2 ** 31:
+        raise NotImplementedError("per-clip tensor exceeds the 2 GiB range of a buffer descriptor")
+    g.cout, g.cout_pad, g.len, g.scale = cout, cpad, length, scale
+    return g
+
+
+def conv_wino(groups, batch, cout_pad, length, dilation, device):
+    """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
+    d = hip.to_device_struct_array(groups, device)
+    hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
+                                         hip.stream()), "fh_conv_wino_f32")
+    return d
+
+
 def conv_grouped(groups, batch, cout_pad, n_len, tile_cfg, device, ck=8):
     """Upload descriptors and enqueue one grouped conv launch (test / one-off use)."""
     d = hip.to_device_struct_array(groups, device)
@@ -248,7 +301,9 @@ class Vocoder:
             tcfg = _TILE_OVERRIDE.get(tcfg, tcfg)
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
-            (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck))
+            flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * B
+                        for g in groups for i in range(g.nseg))
+            (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
         def act_step(groups, c, length, sink=None):
             d = hip.to_device_struct_array(groups, dev)
@@ -363,7 +418,7 @@ class Vocoder:
     def _launch(self, s, B, st):
         L = hip.lib()
         if s[0] == "conv":
-            _, d, ng, cpad, n_len, tcfg, ck = s
+            _, d, ng, cpad, n_len, tcfg, ck, _flops = s
             timing = self.conv_timing          # optional list of (start, end) events around conv launches
             if timing is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -89,6 +89,45 @@ int fh_conv_tile_n(int tile_cfg);
 int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch, int cout_pad,
                         int n_len, int tile_cfg, int ck, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * The same Conv1d call sites (models/bigvgan/models.py:63-72, "same"-padded, stride 1, square
+ * cin x cout residual-stack convs) evaluated with the Winograd minimal-filtering identity
+ * F(4,3): the k taps are walked in groups of 3 and every group of 4 outputs costs 6 instead of
+ * 12 multiply-adds per (cin, cout) pair.  Exact in exact arithmetic; in fp32 the end-to-end
+ * difference to the direct form is ~1e-6 (tools/winograd_numerics.py).
+ *   out[b, co, n] = scale * (bias[co] + sum_res res[b, co, n]
+ *                            + sum_seg sum_ci sum_{j<k} w[co, ci, j] * x[b, ci, n + (j - center) * dilation])
+ * u = host-transformed weights (flowhigh_amd/vocoder.py: pack_wino_weight):
+ *   [cin/16][ngrp][6][cout_pad][16], u[., g, xi, co, .] = sum_j G[xi][j] * w[co, ., 3g + j]
+ *   (taps past k are zero), cout_pad % 64 == 0, cin % 16 == 0.
+ */
+typedef struct {
+  const float* x;      /* [B, cin, len] */
+  const float* u;
+  int32_t cin;
+  int32_t ngrp;        /* ceil(k / 3) */
+  int32_t center;      /* (k - 1) / 2 */
+  int32_t pad_;
+} fh_wino_seg;
+
+typedef struct {
+  fh_wino_seg seg[FH_CONV_MAX_SEG];
+  const float* bias;                 /* [cout] or NULL */
+  const float* res[FH_CONV_MAX_SEG]; /* each [B, cout, len] or NULL */
+  float* out;                        /* [B, cout, len] */
+  int32_t nseg;
+  int32_t nres;
+  int32_t cout;
+  int32_t cout_pad;
+  int32_t len;
+  float scale;
+} fh_wino_group;
+
+int fh_sizeof_wino_group(void);
+/* groups: device array; all groups share cout_pad, len and the dilation. */
+int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
+                     int dilation, void* stream);
+
 /* Debug: per-block timeline of the conv kernel.  buf = device array of uint64, buf[0] = record
  * counter (zero it), then 4 words per block {blockIdx | hw_id << 32 | xcc << 56, start, end
  * (100 MHz ticks), K steps}; NULL switches tracing off.  Synchronous (hipMemcpyToSymbol). */

@@ -1,0 +1,35 @@
+"""Per-launch table of the vocoder's conv launches: tile, blocks, algorithmic GFLOP, us, TFLOP/s.
+Run on the GPU box: python tools/conv_layers.py [batch] [frames]"""
+import sys, torch
+sys.path.insert(0, '.')
+from flowhigh_amd import synth
+from flowhigh_amd.vocoder import Vocoder
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+TILES = {0: (128, 128), 1: (192, 128), 2: (96, 256), 3: (64, 256), 4: (32, 512), 5: (128, 64), 6: (96, 128)}
+cfg = synth.SYNTH_CFG
+voc = Vocoder(cfg, synth.make_state_dict(cfg, 0), 'cuda:0')
+p = voc.plan(B, N)
+convs = [s for s in p['steps'] if s[0] == 'conv']
+for _ in range(3):
+    voc.run(p)
+torch.cuda.synchronize()
+acc = [0.0] * len(convs)
+R = 10
+for _ in range(R):
+    voc.conv_timing = []
+    voc.run(p)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(voc.conv_timing):
+        acc[i] += a.elapsed_time(b) * 1e3 / R
+voc.conv_timing = None
+tot_f = tot_t = 0.0
+print(f"{'#':>3} {'tile':>8} {'grp':>3} {'cpad':>5} {'n_len':>7} {'blocks':>6} {'GFLOP':>8} {'us':>8} {'TF/s':>7}")
+for i, s in enumerate(convs):
+    _, d, ng, cpad, n_len, tcfg, ck, fl = s
+    bm, bn = TILES[tcfg]
+    blocks = ng * B * (cpad // bm) * -(-n_len // bn)
+    tot_f += fl; tot_t += acc[i]
+    print(f"{i:3d} {bm:>4}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
+print(f"total {tot_f/1e9:.1f} GFLOP {tot_t/1e3:.3f} ms {tot_f/tot_t/1e6:.1f} TF/s")
