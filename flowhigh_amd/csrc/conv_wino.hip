@@ -391,7 +391,28 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   }
 }
 
+// out = ((a + b) + c) * scale, 4 elements per thread (the reference's xs += ...; xs / n order)
+__global__ __launch_bounds__(256) void mean_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                                   const f32x4* __restrict__ c, f32x4* __restrict__ out,
+                                                   long long n4, float scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = a[i] + b[i];
+  if (c) v += c[i];
+  out[i] = v * scale;
+}
+
 }  // namespace
+
+extern "C" int fh_mean_f32(const float* a, const float* b, const float* c, float* out, long long n, float scale,
+                           void* stream) {
+  FH_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0, "fh_mean_f32: bad args (n must be a multiple of 4)");
+  FH_CHECK_ARG(((((size_t)a) | ((size_t)b) | ((size_t)c) | ((size_t)out)) & 15) == 0, "fh_mean_f32: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(mean_kernel, dim3(fh_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)a, (const f32x4*)b, (const f32x4*)c, (f32x4*)out, n / 4, scale);
+  FH_CHECK_LAUNCH("fh_mean_f32");
+  return FH_OK;
+}
 
 extern "C" int fh_debug_set_wino_trace(void* buf) {
   unsigned long long* p = (unsigned long long*)buf;
@@ -404,13 +425,6 @@ extern "C" int fh_debug_set_wino_trace(void* buf) {
 }
 
 extern "C" int fh_sizeof_wino_group(void) { return (int)sizeof(fh_wino_group); }
-
-extern "C" int fh_debug_wino_occupancy(void) {
-  int n = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wino_kernel, W_THREADS, W_LDS_FLOATS * 4) != hipSuccess)
-    return -1;
-  return n;
-}
 
 extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad,
                                 int len, int dilation, void* stream) {

@@ -28,6 +28,18 @@ _TILE_OVERRIDE = {int(a): int(b) for a, b in
                   (kv.split(":") for kv in os.environ.get("FH_CONV_TILE_OVERRIDE", "").split(",") if kv)}
 
 
+def use_wino(c, d):
+    """Residual-stack convs [c -> c, dilation d] that run as Winograd F(4,3) (conv_wino.hip) instead of the
+    direct implicit GEMM: measured faster (tools/wino_bench.py) for c >= FH_WINO_MIN_C (default 192) at every
+    dilation, and for the undilated convs of the channel counts in FH_WINO_D1_C (default 48, where the direct
+    kernel pads 48 -> 64 rows).  FH_WINO=0 switches the path off."""
+    if os.environ.get("FH_WINO", "1") == "0" or c % 16:
+        return False
+    if c >= int(os.environ.get("FH_WINO_MIN_C", "192")):
+        return True
+    return d == 1 and c in [int(v) for v in os.environ.get("FH_WINO_D1_C", "48").split(",") if v]
+
+
 def pick_tile_cfg(cout):
     best = None
     for cfg, bm in _TILE_PREF:
@@ -115,6 +127,8 @@ def make_act_group(x, y, p):
 
 
 
+# stage-closing conv (3 K segments in one group): fused only when it yields at least this many blocks
+_WINO_FUSE_MIN_BLOCKS = int(os.environ.get("FH_WINO_FUSE_MIN_BLOCKS", "200"))
 # Winograd F(4,3) weight transform G (6 x 3); interpolation points 0, +-1, +-2, inf
 _WINO_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
            [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
@@ -240,7 +254,7 @@ class Vocoder:
             c = self.chans[i]
             tcfg, bm, cpad = pick_tile_cfg(c)
             st = dict(c=c, cin=self.c0 // (2 ** i), u=u, k=k, tile_cfg=tcfg, cpad=cpad,
-                      ck=pick_ck(c), up_ck=pick_ck(self.c0 // (2 ** i)))
+                      ck=pick_ck(c), up_ck=pick_ck(self.c0 // (2 ** i)), wpad=-(-c // WINO_BM) * WINO_BM)
             wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
             st["up_b"] = g(f"ups.{i}.0.bias").to(dev)
             st["up_phases"] = []
@@ -253,9 +267,16 @@ class Vocoder:
                 r = i * self.nk + j
                 blk = dict(k=self.ks[j], dil=self.dil[j], c1=[], c2=[], acts=[])
                 for m in range(self.nm):
-                    for tag, lst in (("convs1", blk["c1"]), ("convs2", blk["c2"])):
-                        lst.append(dict(w=pack_conv_weight(g(f"resblocks.{r}.{tag}.{m}.weight"), cpad, st["ck"]).to(dev),
-                                        b=g(f"resblocks.{r}.{tag}.{m}.bias").to(dev)))
+                    for tag, lst, d in (("convs1", blk["c1"], self.dil[j][m]), ("convs2", blk["c2"], 1)):
+                        w = g(f"resblocks.{r}.{tag}.{m}.weight")
+                        ent = dict(b=g(f"resblocks.{r}.{tag}.{m}.bias").to(dev))
+                        # convs1[m] of the nk blocks share one launch: Winograd only if they share the dilation
+                        same_d = tag == "convs2" or all(self.dil[jj][m] == d for jj in range(self.nk))
+                        if use_wino(c, d) and same_d:
+                            ent["u"] = pack_wino_weight(w, st["wpad"]).to(dev)
+                        else:
+                            ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
+                        lst.append(ent)
                 for a in range(2 * self.nm):
                     blk["acts"].append(act_params(f"resblocks.{r}.activations.{a}."))
                 st["blocks"].append(blk)
@@ -305,6 +326,27 @@ class Vocoder:
                         for g in groups for i in range(g.nseg))
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
+        def wino_step(groups, wpad, length, dil, sink=None):
+            d = hip.to_device_struct_array(groups, dev)
+            keep.append(d)
+            flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
+                        for g in groups for i in range(g.nseg))
+            (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops))
+
+        def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None):
+            """One launch of the same conv position in the nk AMP blocks (one group per block)."""
+            if all("u" in e for e in ents):
+                wino_step([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i])], biases[i],
+                                           res[i], outs[i], c, wpad, L) for i in range(len(ents))],
+                          wpad, L, dil, sink)
+            else:
+                groups = []
+                for i, e in enumerate(ents):
+                    offs = [(t - (ks[i] - 1) // 2) * dil for t in range(ks[i])]
+                    groups.append(make_conv_group([make_conv_seg(xs_in[i], e["w"], c, offs)], biases[i], res[i],
+                                                  outs[i], c, cpad, L, L, L))
+                conv_step(groups, cpad, L, tcfg, ck, sink)
+
         def act_step(groups, c, length, sink=None):
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
@@ -348,50 +390,62 @@ class Vocoder:
                         blk = st["blocks"][j]
                         k, d = blk["k"], blk["dil"][m]
                         act_step([make_act_group(xin[j], T1[j], blk["acts"][2 * m])], c, L, chains[j])
-                        conv_step([make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c,
-                                                                  [(t - (k - 1) // 2) * d for t in range(k)])],
-                                                   blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L)],
-                                  cpad, L, tcfg, st["ck"], chains[j])
+                        res_conv([blk["c1"][m]], [T1[j]], [k], d, [T2[j]], [blk["c1"][m]["b"]], [[]],
+                                 c, cpad, st["wpad"], L, tcfg, st["ck"], chains[j])
                         act_step([make_act_group(T2[j], T1[j], blk["acts"][2 * m + 1])], c, L, chains[j])
                         if not last:
-                            conv_step([make_conv_group([make_conv_seg(T1[j], blk["c2"][m]["w"], c,
-                                                                      [t - (k - 1) // 2 for t in range(k)])],
-                                                       blk["c2"][m]["b"], [xin[j]], Y[j][m % 2], c, cpad, L, L, L)],
-                                      cpad, L, tcfg, st["ck"], chains[j])
+                            res_conv([blk["c2"][m]], [T1[j]], [k], 1, [Y[j][m % 2]], [blk["c2"][m]["b"]], [[xin[j]]],
+                                     c, cpad, st["wpad"], L, tcfg, st["ck"], chains[j])
                     if not last:
                         xin = [Y[j][m % 2] for j in range(self.nk)]
                     else:
                         steps.append(("fork", [chains[j] for j in order]))
                 else:
                     act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L)
-                    groups = []
-                    for j in order:
-                        blk = st["blocks"][j]
-                        k, d = blk["k"], blk["dil"][m]
-                        offs = [(t - (k - 1) // 2) * d for t in range(k)]
-                        groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
-                                                       blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
-                    conv_step(groups, cpad, L, tcfg, st["ck"])
-                    act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L)
-                    if not last:
+                    blks = [st["blocks"][j] for j in order]
+                    d1 = blks[0]["dil"][m]
+                    if all(b_["dil"][m] == d1 for b_ in blks):
+                        res_conv([b_["c1"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], d1,
+                                 [T2[j] for j in order], [b_["c1"][m]["b"] for b_ in blks], [[] for _ in blks],
+                                 c, cpad, st["wpad"], L, tcfg, st["ck"])
+                    else:               # mixed dilations: one direct launch, per-group tap offsets
                         groups = []
                         for j in order:
                             blk = st["blocks"][j]
-                            k = blk["k"]
-                            offs = [t - (k - 1) // 2 for t in range(k)]
-                            out = Y[j][m % 2]
-                            groups.append(make_conv_group([make_conv_seg(T1[j], blk["c2"][m]["w"], c, offs)],
-                                                           blk["c2"][m]["b"], [xin[j]], out, c, cpad, L, L, L))
+                            k, d = blk["k"], blk["dil"][m]
+                            offs = [(t - (k - 1) // 2) * d for t in range(k)]
+                            groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
+                                                           blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
                         conv_step(groups, cpad, L, tcfg, st["ck"])
+                    act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L)
+                    if not last:
+                        res_conv([b_["c2"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], 1,
+                                 [Y[j][m % 2] for j in order], [b_["c2"][m]["b"] for b_ in blks],
+                                 [[xin[j]] for j in order], c, cpad, st["wpad"], L, tcfg, st["ck"])
                         xin = [Y[j][m % 2] for j in range(self.nk)]
                 if last:
-                    segs = []
-                    for j in order:
-                        blk = st["blocks"][j]
-                        k = blk["k"]
-                        segs.append(make_conv_seg(T1[j], blk["c2"][m]["w"], c, [t - (k - 1) // 2 for t in range(k)]))
-                    conv_step([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L,
-                                                scale=1.0 / self.nk)], cpad, L, tcfg, st["ck"])
+                    ents = [st["blocks"][j]["c2"][m] for j in order]
+                    fused_blocks = B * (st["wpad"] // WINO_BM) * -(-L // 512)
+                    if all("u" in e for e in ents) and fused_blocks < _WINO_FUSE_MIN_BLOCKS and self.nk in (2, 3):
+                        # one group = too few blocks for 256 CUs: run the nk convs as groups and average after
+                        res_conv(ents, [T1[j] for j in order], [st["blocks"][j]["k"] for j in order], 1,
+                                 [Y[j][m % 2] for j in order], [e["b"] for e in ents], [[xin[j]] for j in order],
+                                 c, cpad, st["wpad"], L, tcfg, st["ck"])
+                        ys = [Y[j][m % 2] for j in range(self.nk)]          # block order = the reference's xs += order
+                        steps.append(("mean", ys[0], ys[1], ys[2] if self.nk == 3 else None, S, B * c * L,
+                                      1.0 / self.nk))
+                    elif all("u" in e for e in ents):
+                        segs = [make_wino_seg(T1[j], st["blocks"][j]["c2"][m]["u"], c, st["blocks"][j]["k"]) for j in order]
+                        wino_step([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, st["wpad"], L,
+                                                   scale=1.0 / self.nk)], st["wpad"], L, 1)
+                    else:
+                        segs = []
+                        for j in order:
+                            blk = st["blocks"][j]
+                            k = blk["k"]
+                            segs.append(make_conv_seg(T1[j], blk["c2"][m]["w"], c, [t - (k - 1) // 2 for t in range(k)]))
+                        conv_step([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L,
+                                                    scale=1.0 / self.nk)], cpad, L, tcfg, st["ck"])
             # Slot roles repeat every stage: the next up-conv reads S (slot 1) and writes the new X
             # (slot 0); slot 1 is rewritten only by that stage's last launch, after its readers.
             cur = S
@@ -427,6 +481,20 @@ class Vocoder:
             if timing is not None:
                 e1.record()
                 timing.append((e0, e1))
+        elif s[0] == "wino":
+            _, d, ng, wpad, length, dil, _flops = s
+            timing = self.conv_timing
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, B, wpad, length, dil, st), "fh_conv_wino_f32")
+            if timing is not None:
+                e1.record()
+                timing.append((e0, e1))
+        elif s[0] == "mean":
+            _, a, b_, c_, out, n, scale = s
+            hip.check(L.fh_mean_f32(a.data_ptr(), b_.data_ptr(), c_.data_ptr() if c_ is not None else None,
+                                    out.data_ptr(), n, scale, st), "fh_mean_f32")
         elif s[0] == "act":
             _, d, ng, c, length = s
             hip.check(L.fh_act1d_grouped_f32(d.data_ptr(), ng, B, c, length, st), "fh_act1d_grouped_f32")

@@ -128,10 +128,18 @@ int fh_sizeof_wino_group(void);
 int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
                      int dilation, void* stream);
 
+/* out = ((a + b) + c) * scale over n floats (c may be NULL; n % 4 == 0, 16-byte aligned pointers): the
+ * `xs += resblock(x); x = xs / num_kernels` of BigVGAN.forward (models/bigvgan/models.py:183-188) for the
+ * stages whose closing conv is not fused (too few blocks to fill the chip at batch 1). */
+int fh_mean_f32(const float* a, const float* b, const float* c, float* out, long long n, float scale,
+                void* stream);
+
 /* Debug: per-block timeline of the conv kernel.  buf = device array of uint64, buf[0] = record
  * counter (zero it), then 4 words per block {blockIdx | hw_id << 32 | xcc << 56, start, end
  * (100 MHz ticks), K steps}; NULL switches tracing off.  Synchronous (hipMemcpyToSymbol). */
 int fh_debug_set_conv_trace(void* buf);
+/* Same for the Winograd kernel: one record per WAVE, word 3 = wave index in the block. */
+int fh_debug_set_wino_trace(void* buf);
 
 /* conv_post + tanh (models/bigvgan/models.py:190-192): x [B, cin, L], w [cin, ksz], bias[1]
  * -> out [B, L] = tanh(bias + sum_ci sum_j w[ci,j] * x[b, ci, t + j - ksz/2]).  ksz odd <= 15. */

@@ -11,7 +11,7 @@ TILES = {0: (128, 128), 1: (192, 128), 2: (96, 256), 3: (64, 256), 4: (32, 512),
 cfg = synth.SYNTH_CFG
 voc = Vocoder(cfg, synth.make_state_dict(cfg, 0), 'cuda:0')
 p = voc.plan(B, N)
-convs = [s for s in p['steps'] if s[0] == 'conv']
+convs = [s for s in p['steps'] if s[0] in ('conv', 'wino')]
 for _ in range(3):
     voc.run(p)
 torch.cuda.synchronize()
@@ -27,9 +27,14 @@ voc.conv_timing = None
 tot_f = tot_t = 0.0
 print(f"{'#':>3} {'tile':>8} {'grp':>3} {'cpad':>5} {'n_len':>7} {'blocks':>6} {'GFLOP':>8} {'us':>8} {'TF/s':>7}")
 for i, s in enumerate(convs):
-    _, d, ng, cpad, n_len, tcfg, ck, fl = s
-    bm, bn = TILES[tcfg]
-    blocks = ng * B * (cpad // bm) * -(-n_len // bn)
+    if s[0] == 'wino':
+        _, d, ng, cpad, n_len, dil, fl = s
+        bm, bn = 64, 512
+        blocks = ng * B * (cpad // bm) * -(-(-(-n_len // dil)) // bn) * dil
+    else:
+        _, d, ng, cpad, n_len, tcfg, ck, fl = s
+        bm, bn = TILES[tcfg]
+        blocks = ng * B * (cpad // bm) * -(-n_len // bn)
     tot_f += fl; tot_t += acc[i]
-    print(f"{i:3d} {bm:>4}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
+    print(f"{i:3d} {('W' if s[0] == 'wino' else ' ')}{bm:>3}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
 print(f"total {tot_f/1e9:.1f} GFLOP {tot_t/1e3:.3f} ms {tot_f/tot_t/1e6:.1f} TF/s")
