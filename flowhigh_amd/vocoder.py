@@ -311,6 +311,7 @@ class Vocoder:
         B, N = batch, n_frames
         f32 = dict(dtype=torch.float32, device=dev)
         steps = []          # (kind, device descriptor tensor, n_groups, args...)
+        executed = [0.0]    # FLOPs issued to the matrix cores by all conv launches (Winograd: 1.5 G / k of the algorithmic)
         keep = []           # tensors that must stay alive
         L = N
 
@@ -324,6 +325,7 @@ class Vocoder:
             keep.append(d)
             flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * B
                         for g in groups for i in range(g.nseg))
+            executed[0] += flops
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
         def wino_step(groups, wpad, length, dil, sink=None):
@@ -331,6 +333,9 @@ class Vocoder:
             keep.append(d)
             flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
                         for g in groups for i in range(g.nseg))
+            # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
+            executed[0] += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
+                               for g in groups for i in range(g.nseg))
             (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops))
 
         def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None):
@@ -454,7 +459,7 @@ class Vocoder:
         act_step([make_act_group(cur, post_t, self.post_act)], c_last, L)
         wav = torch.empty(B, L, **f32)
         steps.append(("post", post_t, wav, c_last, L))
-        p = dict(steps=steps, keep=keep, mel_in=mel_in, wav=wav, B=B, N=N, L=L)
+        p = dict(steps=steps, keep=keep, mel_in=mel_in, wav=wav, B=B, N=N, L=L, conv_executed_flops=executed[0])
         self._plans[key] = p
         return p
 

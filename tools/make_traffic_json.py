@@ -7,7 +7,7 @@ def total(d, name):
     f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == name and 'conv_mfma_kernel' in r['Kernel_Name']:
+        if r['Counter_Name'] == name and ('conv_mfma_kernel' in r['Kernel_Name'] or 'conv_wino_kernel' in r['Kernel_Name']):
             tot += float(r['Counter_Value']); n += 1
     return tot, n
 fs, n1 = total(fetch_dir, 'FETCH_SIZE')
@@ -15,6 +15,6 @@ ws, n2 = total(write_dir, 'WRITE_SIZE')
 assert n1 == n2 and n1 > 0
 per = (2.0 * fs + ws) * 1024.0 / n1
 json.dump({"bytes_per_launch": round(per), "launches": n1, "fetch_kb_raw": fs, "write_kb": ws,
-           "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches, conv_mfma_kernel dispatches only"},
+           "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches, conv_wino_kernel + conv_mfma_kernel dispatches"},
           open(out, 'w'), indent=1)
 print(open(out).read())
