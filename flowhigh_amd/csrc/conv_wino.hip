@@ -13,8 +13,8 @@
 // a block works on ONE phase, so dilation only shows up as an element stride in its global
 // loads / stores.
 //
-// Block = 12 waves = 6 transform points x 2 halves of a 64 (co) x 128 (tiles = 512 outputs) tile;
-// wave (xi, th) owns M_xi for 64 co x 64 tiles.  One block per CU, 3 waves on every SIMD (a 6-wave
+// Block = 12 waves = 6 transform points x 2 halves of a 64 (co) x 128 (tiles = 512 outputs) tile
+// (96 x 64 tiles for C = 96); wave (xi, th) owns M_xi for 64 co x 64 tiles.  One block per CU, 3 waves on every SIMD (a 6-wave
 // block leaves the SIMDs 2/2/1/1 and the matrix pipes of two of them half idle).
 //   * per wave this is the 2x2 arrangement of v_mfma_f32_32x32x2_f32 tiles of the direct kernel
 //     (2 A + 2 B fragments per 4 MFMAs);
@@ -26,9 +26,10 @@
 //     barrier per CHUNK), de-interleaved into 4 planes (sample u -> plane u & 3, index u >> 2) so
 //     that lane `tile` reading sample 4 tile + s is a stride-1, conflict-free read.  Wave xi forms
 //     its B fragments from 3-4 such samples with its row of B^T.  On this chip every VALU
-//     instruction in the loop costs matrix-pipe time, so the two tile columns of a wave sit 64 tiles
-//     apart (one ds_read2st64_b32 with immediate offsets fetches both, no address arithmetic) and
-//     are transformed together with packed fp32 math: 4 LDS + 4 VALU instructions per 4 MFMAs;
+//     instruction in the loop costs matrix-pipe time, so channel pairs are interleaved in the slab
+//     and the two tile columns of a wave sit 64 tiles apart: one ds_read2st64_b64 with immediate
+//     offsets fetches one sample for 2 columns x 2 k-steps, and the transform is packed fp32 math
+//     over the k-step pair: 4 LDS + 8 VALU instructions per 8 MFMAs;
 //   * epilogue: the waves exchange their accumulators through LDS one 32x32 tile at a time,
 //     every thread applies A^T, bias, residuals and the scale, and stores 4 outputs.
 // MFMA work per output: 1.5 ceil(k/3) instead of k multiply-adds per channel pair (k = 3 / 7 / 11:
@@ -41,17 +42,27 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int W_BM = 64;             // output channels per block
-constexpr int W_BT = 128;            // F(4,3) tiles per block (512 outputs of one phase)
 constexpr int W_CK = 16;             // input channels per chunk
-constexpr int W_THREADS = 768;
-constexpr int W_P = 136;             // plane pitch, floats (>= 128 + 4)
-constexpr int W_RP2 = 1152;          // pitch of a channel PAIR (4 planes x 2 channels interleaved), multiple of 128
-constexpr int W_XPT = 11;            // slab samples per thread: 48 threads x 11 = 528 per row
-constexpr int W_SLAB = (W_CK / 2) * W_RP2;  // floats per slab buffer
+constexpr int W_THREADS = 768;       // 12 waves = 6 transform points x 2 tile halves
 constexpr int W_EP = 33;             // pitch of the epilogue exchange tiles
-constexpr int W_LDS_FLOATS = 2 * W_SLAB;                 // >= 12 * 32 * W_EP (epilogue)
 constexpr int W_RUN = 8;             // n-blocks of a panel that run together on one XCD
+
+// Wave tile = (32 MT) co x (32 NT) tiles; block tile = (32 MT) co x (64 NT) tiles (256 NT outputs).
+//   <2, 2>: 64 x 512 outputs  (C % 64 == 0)        <3, 1>: 96 x 256 outputs  (C = 96)
+template <int MT, int NT>
+struct WCfg {
+  static constexpr int BM = 32 * MT;                    // output channels per block
+  static constexpr int BT = 64 * NT;                    // F(4,3) tiles per block
+  static constexpr int P = BT + 8;                      // plane pitch, floats (>= BT + 4)
+  // pitch of a channel PAIR (4 planes x 2 channels interleaved); a multiple of 128 floats where the
+  // two tile columns of a wave are fetched by one ds_read2st64_b64
+  static constexpr int RP2 = NT == 2 ? 1152 : 8 * P;
+  static constexpr int XPT = (4 * BT + 16 + 47) / 48;   // slab samples per thread (48 threads per row)
+  static constexpr int SLAB = (W_CK / 2) * RP2;         // floats per slab buffer
+  static constexpr int EPI = 12 * 32 * W_EP;            // epilogue exchange, floats
+  static constexpr int LDS_FLOATS = 2 * SLAB > EPI ? 2 * SLAB : EPI;
+  static_assert(RP2 >= 8 * P, "planes overlap");
+};
 
 // rows of B^T as (sample index, coefficient) pairs; rows 0 and 5 have 3 terms (4th is a 0 * x dummy)
 __device__ const int kBtOff[6][4] = {{0, 2, 4, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 3, 5, 5}};
@@ -76,10 +87,13 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
   return w;
 }
 
+template <int MT, int NT>
 __global__ __attribute__((amdgpu_flat_work_group_size(W_THREADS, W_THREADS), amdgpu_waves_per_eu(3, 3)))
 void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles,
                       int n_tiles, int run_len, int dil) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];      // W_LDS_FLOATS
+  using Cfg = WCfg<MT, NT>;
+  constexpr int W_BM = Cfg::BM, W_BT = Cfg::BT, W_P = Cfg::P, W_RP2 = Cfg::RP2, W_XPT = Cfg::XPT, W_SLAB = Cfg::SLAB;
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // Cfg::LDS_FLOATS
   unsigned long long* const trace = g_wino_trace;
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
@@ -115,11 +129,11 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const int bo0 = kBtOff[xi][0], bo1 = kBtOff[xi][1], bo2 = kBtOff[xi][2], bo3 = kBtOff[xi][3];
   const float bc0 = kBtCoef[xi][0], bc1 = kBtCoef[xi][1], bc2 = kBtCoef[xi][2], bc3 = kBtCoef[xi][3];
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -158,13 +172,13 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
     for (int i = 0; i < W_XPT; ++i) dst[24 * i] = __uint_as_float(xreg[i]);
   };
   // A fragments of one step, [mt][half]: half h holds k-steps 4h .. 4h+3
-  u32x4 areg[2][2];
+  u32x4 areg[MT][2];
   const int a_lane = (l31 * W_CK + lh * 8) * 4;
   auto load_a_half = [&](int h, const WSeg& S, int chunk, int g, bool valid) {
     const float* up = uni(S.u + ((size_t)((chunk * S.ngrp + g) * 6 + xi) * cout_pad + co0) * W_CK);
     const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? W_BM * W_CK * 4 : 0);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
       areg[mt][h] = __builtin_amdgcn_raw_buffer_load_b128(r, a_lane + mt * 32 * W_CK * 4 + 16 * h, 0, 0);
   };
 
@@ -180,7 +194,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
     const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? (unsigned)(S.ngrp - 1) * gstride + W_BM * W_CK * 4 : 0u);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const unsigned off = (unsigned)(2 * j + lh) * gstride + (unsigned)l31 * 128u;
+      // (lanes past the tile's BM / 2 lines: out of range)
+      const unsigned off = l31 < W_BM / 2 ? (unsigned)(2 * j + lh) * gstride + (unsigned)l31 * 128u : 0x80000000u;
       asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pf) : "v"(off), "s"(r) : "memory");
     }
   };
@@ -210,15 +225,15 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       const WSeg& Sx = last_chunk ? Sn : S;              // owner of the next chunk
       const int cx = last_chunk ? 0 : c + 1;
       const float* xsb = lds + xbuf * W_SLAB + lh * 4 * W_RP2 + (th * 32 + l31) * 2;
-      f32x2 xr[2][4][2];                                 // [slot][sample][column] = (k-step 2 kp, 2 kp + 1)
+      f32x2 xr[2][4][NT];                                // [slot][sample][column] = (k-step 2 kp, 2 kp + 1)
       auto fetch = [&](int slot, int p) {
         const int j0 = 3 * (p >> 2), kp = p & 3;
         const int o[4] = {bo0, bo1, bo2, bo3};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float* q = xsb + (((j0 + o[r]) & 3) * W_P + ((j0 + o[r]) >> 2)) * 2 + kp * W_RP2;
-          xr[slot][r][0] = *reinterpret_cast<const f32x2*>(q);
-          xr[slot][r][1] = *reinterpret_cast<const f32x2*>(q + 128);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) xr[slot][r][nt] = *reinterpret_cast<const f32x2*>(q + 128 * nt);
         }
       };
       fetch(0, 0);
@@ -233,9 +248,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
         if (GC > 1 && p == 4 * (GC - 1) && has_next) store_x(xbuf ^ 1);
 #endif
         if (p + 1 < 4 * GC) fetch((p + 1) & 1, p + 1);
-        f32x2 bf[2];                               // [column] = B values of k-steps 2 kp, 2 kp + 1
+        f32x2 bf[NT];                              // [column] = B values of k-steps 2 kp, 2 kp + 1
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #if defined(WINO_ABL) && (WINO_ABL & 1)           // timing experiment: reads stay, no transform
           bf[nt] = xr[p & 1][0][nt];
           asm volatile("" : "+v"(bf[nt]) : "v"(xr[p & 1][1][nt]), "v"(xr[p & 1][2][nt]), "v"(xr[p & 1][3][nt]));
@@ -244,8 +259,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "v"(c1), "v"(xr[p & 1][1][nt]));
           asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "v"(c2), "v"(xr[p & 1][2][nt]));
           // (the hazard recognizer does not look inside asm: VALU result -> MFMA operand needs 2 wait
-          // states; the first MFMA reads column 0, so one s_nop after column 1 covers both)
-          if (nt == 0)
+          // states; the MFMAs read column 0 first, so one s_nop after the last column covers all)
+          if (nt + 1 < NT)
             asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "v"(c3), "v"(xr[p & 1][3][nt]));
           else
             asm("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(bf[nt]) : "v"(c3), "v"(xr[p & 1][3][nt]));
@@ -256,9 +271,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           const int e = 2 * (kp & 1) + k2;
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[mt][h][e]), bf[nt][k2],
                                                                  acc[mt][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
@@ -312,9 +327,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const bool vec = dil == 1 && (len & 3) == 0;      // 4 outputs of a tile = one aligned 16-byte vector
   float* E = lds;                                    // [th][xi][32][W_EP]
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -426,15 +441,15 @@ extern "C" int fh_debug_set_wino_trace(void* buf) {
 
 extern "C" int fh_sizeof_wino_group(void) { return (int)sizeof(fh_wino_group); }
 
-extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad,
-                                int len, int dilation, void* stream) {
-  FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && len > 0, "fh_conv_wino_f32: bad sizes");
-  FH_CHECK_ARG(cout_pad > 0 && cout_pad % W_BM == 0, "fh_conv_wino_f32: cout_pad %d not a multiple of %d", cout_pad, W_BM);
-  FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino_f32: dilation %d unsupported", dilation);
-  // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cin * len * 4 < 2^31
-  // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
-  const int co_tiles = cout_pad / W_BM;
-  const int n_tiles = fh_cdiv(fh_cdiv(len, dilation), 4 * W_BT) * dilation;
+namespace {
+
+template <int MT, int NT>
+int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
+                hipStream_t stream) {
+  using Cfg = WCfg<MT, NT>;
+  FH_CHECK_ARG(cout_pad > 0 && cout_pad % Cfg::BM == 0, "fh_conv_wino_f32: cout_pad %d not a multiple of %d", cout_pad, Cfg::BM);
+  const int co_tiles = cout_pad / Cfg::BM;
+  const int n_tiles = fh_cdiv(fh_cdiv(len, dilation), 4 * Cfg::BT) * dilation;
   const long long panels = (long long)n_groups * batch * co_tiles;
   const int run_len = fh_cdiv(n_tiles, fh_cdiv(n_tiles, W_RUN));
   const long long runs = panels * fh_cdiv(n_tiles, run_len);
@@ -442,16 +457,34 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino_f32: grid too large");
   static bool lds_opt_in = false;      // > 64 KB of dynamic LDS needs the attribute once per process
   if (!lds_opt_in) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       W_LDS_FLOATS * 4);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       Cfg::LDS_FLOATS * 4);
     if (e != hipSuccess) {
-      fh_set_error("fh_conv_wino_f32: cannot reserve %d bytes of LDS: %s", W_LDS_FLOATS * 4, hipGetErrorString(e));
+      fh_set_error("fh_conv_wino_f32: cannot reserve %d bytes of LDS: %s", Cfg::LDS_FLOATS * 4, hipGetErrorString(e));
       return FH_E_LAUNCH;
     }
     lds_opt_in = true;
   }
-  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks), dim3(W_THREADS), W_LDS_FLOATS * 4,
-                     (hipStream_t)stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation);
+  hipLaunchKernelGGL((conv_wino_kernel<MT, NT>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
+                     stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation);
   FH_CHECK_LAUNCH("fh_conv_wino_f32");
   return FH_OK;
+}
+
+}  // namespace
+
+extern "C" int fh_wino_tile_m(int tile_cfg) { return tile_cfg == 0 ? 64 : tile_cfg == 1 ? 96 : -1; }
+
+extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad,
+                                int len, int dilation, int tile_cfg, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && len > 0, "fh_conv_wino_f32: bad sizes");
+  FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino_f32: dilation %d unsupported", dilation);
+  // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cin * len * 4 < 2^31
+  // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
+  switch (tile_cfg) {
+    case 0: return launch_wino<2, 2>(groups, n_groups, batch, cout_pad, len, dilation, (hipStream_t)stream);
+    case 1: return launch_wino<3, 1>(groups, n_groups, batch, cout_pad, len, dilation, (hipStream_t)stream);
+  }
+  fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
+  return FH_E_ARG;
 }

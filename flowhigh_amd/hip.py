@@ -61,7 +61,8 @@ _SIGS = {
     "fh_conv_tile_n": [_I],
     "fh_conv_grouped_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
     "fh_sizeof_wino_group": [],
-    "fh_conv_wino_f32": [_P, _I, _I, _I, _I, _I, _P],
+    "fh_wino_tile_m": [_I],
+    "fh_conv_wino_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
     "fh_mean_f32": [_P, _P, _P, _P, C.c_longlong, _F, _P],
     "fh_debug_set_conv_trace": [_P],
     "fh_debug_set_wino_trace": [_P],

@@ -28,16 +28,29 @@ _TILE_OVERRIDE = {int(a): int(b) for a, b in
                   (kv.split(":") for kv in os.environ.get("FH_CONV_TILE_OVERRIDE", "").split(",") if kv)}
 
 
+def _parse_wino_rule(text):
+    rule = {}
+    for item in text.split(","):
+        if item:
+            c, ds = item.split(":")
+            rule[int(c)] = None if ds == "*" else {int(v) for v in ds.split("/")}
+    return rule
+
+
+# channel count -> dilations that run as Winograd below FH_WINO_MIN_C (measured with tools/wino_bench.py, B = 1)
+_WINO_RULE = _parse_wino_rule(os.environ.get("FH_WINO_RULE", "96:1/3,48:1"))
+
+
 def use_wino(c, d):
     """Residual-stack convs [c -> c, dilation d] that run as Winograd F(4,3) (conv_wino.hip) instead of the
-    direct implicit GEMM: measured faster (tools/wino_bench.py) for c >= FH_WINO_MIN_C (default 192) at every
-    dilation, and for the undilated convs of the channel counts in FH_WINO_D1_C (default 48, where the direct
-    kernel pads 48 -> 64 rows).  FH_WINO=0 switches the path off."""
+    direct implicit GEMM: where it measured faster (tools/wino_bench.py), i.e. for c >= FH_WINO_MIN_C (default
+    192) at every dilation and for the (c, d) pairs of FH_WINO_RULE ("96:1/3,48:1": dilated convs of the narrow
+    stages lose to the strided access of one-phase-per-block).  FH_WINO=0 switches the path off."""
     if os.environ.get("FH_WINO", "1") == "0" or c % 16:
         return False
     if c >= int(os.environ.get("FH_WINO_MIN_C", "192")):
         return True
-    return d == 1 and c in [int(v) for v in os.environ.get("FH_WINO_D1_C", "48").split(",") if v]
+    return c in _WINO_RULE and (_WINO_RULE[c] is None or d in _WINO_RULE[c])
 
 
 def pick_tile_cfg(cout):
@@ -135,6 +148,13 @@ _WINO_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
 WINO_BM = 64
 
 
+def pick_wino_tile(c):
+    """(tile_cfg, cout_pad) of the Winograd kernel: 96-row tiles where they divide c and 64-row tiles do not."""
+    if c % 64 and c % 96 == 0:
+        return 1, c
+    return 0, -(-c // WINO_BM) * WINO_BM
+
+
 def pack_wino_weight(w, cout_pad):
     """Conv1d weight [co, ci, k] -> transformed [ci/16, G, 6, cout_pad, 16], G = ceil(k/3):
     u[c, g, xi, co, :] = sum_j G[xi][j] w[co, 16c:16c+16, 3g + j] (float64 on the host, taps past k = 0)."""
@@ -174,10 +194,10 @@ def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0):
     return g
 
 
-def conv_wino(groups, batch, cout_pad, length, dilation, device):
+def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0):
     """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
     d = hip.to_device_struct_array(groups, device)
-    hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
+    hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation, tile_cfg,
                                          hip.stream()), "fh_conv_wino_f32")
     return d
 
@@ -254,7 +274,8 @@ class Vocoder:
             c = self.chans[i]
             tcfg, bm, cpad = pick_tile_cfg(c)
             st = dict(c=c, cin=self.c0 // (2 ** i), u=u, k=k, tile_cfg=tcfg, cpad=cpad,
-                      ck=pick_ck(c), up_ck=pick_ck(self.c0 // (2 ** i)), wpad=-(-c // WINO_BM) * WINO_BM)
+                      ck=pick_ck(c), up_ck=pick_ck(self.c0 // (2 ** i)))
+            st["wcfg"], st["wpad"] = pick_wino_tile(c)
             wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
             st["up_b"] = g(f"ups.{i}.0.bias").to(dev)
             st["up_phases"] = []
@@ -328,7 +349,7 @@ class Vocoder:
             executed[0] += flops
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
-        def wino_step(groups, wpad, length, dil, sink=None):
+        def wino_step(groups, wpad, length, dil, wcfg, sink=None):
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
             flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
@@ -336,14 +357,14 @@ class Vocoder:
             # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
             executed[0] += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
                                for g in groups for i in range(g.nseg))
-            (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops))
+            (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops, wcfg))
 
-        def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None):
+        def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None, wcfg=0):
             """One launch of the same conv position in the nk AMP blocks (one group per block)."""
             if all("u" in e for e in ents):
                 wino_step([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i])], biases[i],
                                            res[i], outs[i], c, wpad, L) for i in range(len(ents))],
-                          wpad, L, dil, sink)
+                          wpad, L, dil, wcfg, sink)
             else:
                 groups = []
                 for i, e in enumerate(ents):
@@ -396,11 +417,11 @@ class Vocoder:
                         k, d = blk["k"], blk["dil"][m]
                         act_step([make_act_group(xin[j], T1[j], blk["acts"][2 * m])], c, L, chains[j])
                         res_conv([blk["c1"][m]], [T1[j]], [k], d, [T2[j]], [blk["c1"][m]["b"]], [[]],
-                                 c, cpad, st["wpad"], L, tcfg, st["ck"], chains[j])
+                                 c, cpad, st["wpad"], L, tcfg, st["ck"], chains[j], wcfg=st["wcfg"])
                         act_step([make_act_group(T2[j], T1[j], blk["acts"][2 * m + 1])], c, L, chains[j])
                         if not last:
                             res_conv([blk["c2"][m]], [T1[j]], [k], 1, [Y[j][m % 2]], [blk["c2"][m]["b"]], [[xin[j]]],
-                                     c, cpad, st["wpad"], L, tcfg, st["ck"], chains[j])
+                                     c, cpad, st["wpad"], L, tcfg, st["ck"], chains[j], wcfg=st["wcfg"])
                     if not last:
                         xin = [Y[j][m % 2] for j in range(self.nk)]
                     else:
@@ -412,7 +433,7 @@ class Vocoder:
                     if all(b_["dil"][m] == d1 for b_ in blks):
                         res_conv([b_["c1"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], d1,
                                  [T2[j] for j in order], [b_["c1"][m]["b"] for b_ in blks], [[] for _ in blks],
-                                 c, cpad, st["wpad"], L, tcfg, st["ck"])
+                                 c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
                     else:               # mixed dilations: one direct launch, per-group tap offsets
                         groups = []
                         for j in order:
@@ -426,23 +447,24 @@ class Vocoder:
                     if not last:
                         res_conv([b_["c2"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], 1,
                                  [Y[j][m % 2] for j in order], [b_["c2"][m]["b"] for b_ in blks],
-                                 [[xin[j]] for j in order], c, cpad, st["wpad"], L, tcfg, st["ck"])
+                                 [[xin[j]] for j in order], c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
                         xin = [Y[j][m % 2] for j in range(self.nk)]
                 if last:
                     ents = [st["blocks"][j]["c2"][m] for j in order]
-                    fused_blocks = B * (st["wpad"] // WINO_BM) * -(-L // 512)
+                    wbm, wbn = (96, 256) if st["wcfg"] == 1 else (64, 512)
+                    fused_blocks = B * (st["wpad"] // wbm) * -(-L // wbn)
                     if all("u" in e for e in ents) and fused_blocks < _WINO_FUSE_MIN_BLOCKS and self.nk in (2, 3):
                         # one group = too few blocks for 256 CUs: run the nk convs as groups and average after
                         res_conv(ents, [T1[j] for j in order], [st["blocks"][j]["k"] for j in order], 1,
                                  [Y[j][m % 2] for j in order], [e["b"] for e in ents], [[xin[j]] for j in order],
-                                 c, cpad, st["wpad"], L, tcfg, st["ck"])
+                                 c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
                         ys = [Y[j][m % 2] for j in range(self.nk)]          # block order = the reference's xs += order
                         steps.append(("mean", ys[0], ys[1], ys[2] if self.nk == 3 else None, S, B * c * L,
                                       1.0 / self.nk))
                     elif all("u" in e for e in ents):
                         segs = [make_wino_seg(T1[j], st["blocks"][j]["c2"][m]["u"], c, st["blocks"][j]["k"]) for j in order]
                         wino_step([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, st["wpad"], L,
-                                                   scale=1.0 / self.nk)], st["wpad"], L, 1)
+                                                   scale=1.0 / self.nk)], st["wpad"], L, 1, st["wcfg"])
                     else:
                         segs = []
                         for j in order:
@@ -487,12 +509,12 @@ class Vocoder:
                 e1.record()
                 timing.append((e0, e1))
         elif s[0] == "wino":
-            _, d, ng, wpad, length, dil, _flops = s
+            _, d, ng, wpad, length, dil, _flops, wcfg = s
             timing = self.conv_timing
             if timing is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, B, wpad, length, dil, st), "fh_conv_wino_f32")
+            hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, B, wpad, length, dil, wcfg, st), "fh_conv_wino_f32")
             if timing is not None:
                 e1.record()
                 timing.append((e0, e1))

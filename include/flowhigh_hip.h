@@ -99,7 +99,7 @@ int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch, in
  *                            + sum_seg sum_ci sum_{j<k} w[co, ci, j] * x[b, ci, n + (j - center) * dilation])
  * u = host-transformed weights (flowhigh_amd/vocoder.py: pack_wino_weight):
  *   [cin/16][ngrp][6][cout_pad][16], u[., g, xi, co, .] = sum_j G[xi][j] * w[co, ., 3g + j]
- *   (taps past k are zero), cout_pad % 64 == 0, cin % 16 == 0.
+ *   (taps past k are zero), cout_pad % (64 or 96, see tile_cfg) == 0, cin % 16 == 0.
  */
 typedef struct {
   const float* x;      /* [B, cin, len] */
@@ -124,9 +124,11 @@ typedef struct {
 } fh_wino_group;
 
 int fh_sizeof_wino_group(void);
+/* tile_cfg: 0 = 64 co x 512 outputs per block, 1 = 96 co x 256 outputs (cout_pad % fh_wino_tile_m == 0) */
+int fh_wino_tile_m(int tile_cfg);
 /* groups: device array; all groups share cout_pad, len and the dilation. */
 int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
-                     int dilation, void* stream);
+                     int dilation, int tile_cfg, void* stream);
 
 /* out = ((a + b) + c) * scale over n floats (c may be NULL; n % 4 == 0, 16-byte aligned pointers): the
  * `xs += resblock(x); x = xs / num_kernels` of BigVGAN.forward (models/bigvgan/models.py:183-188) for the

@@ -114,24 +114,26 @@ def test_conv_three_segments_fused_average():
 
 
 @pytest.mark.parametrize("c,k,d,L,B", [(64, 3, 1, 1000, 2), (64, 7, 3, 1001, 1), (128, 11, 5, 777, 2),
-                                       (48, 11, 1, 256, 1), (96, 7, 1, 5000, 1), (16, 3, 5, 13, 2)])
+                                       (48, 11, 1, 256, 1), (96, 7, 1, 5000, 1), (16, 3, 5, 13, 2),
+                                       (96, 11, 3, 2999, 2), (192, 3, 1, 700, 1)])
 def test_conv_wino(c, k, d, L, B):
     """Winograd F(4,3) form of the residual-stack convs against the direct fp64 definition."""
     x, w, b = rnd(B, c, L, seed=100), rnd(c, c, k, seed=101, scale=1.0 / (c * k) ** 0.5), rnd(c, seed=102)
     r1 = rnd(B, c, L, seed=103)
     ref = ((F.conv1d(x.double(), w.double(), b.double(), dilation=d, padding=(k - 1) // 2 * d) + r1.double()) * 0.5).float()
-    cpad = -(-c // V.WINO_BM) * V.WINO_BM
+    wcfg, cpad = V.pick_wino_tile(c)
     out = torch.full((B, c, L), float("nan"), device=DEV)
     xd, ud, bd, rd = x.to(DEV), V.pack_wino_weight(w, cpad).to(DEV), b.to(DEV), r1.to(DEV)
     g = V.make_wino_group([V.make_wino_seg(xd, ud, c, k)], bd, [rd], out, c, cpad, L, scale=0.5)
-    keep = V.conv_wino([g], B, cpad, L, d, DEV)
+    keep = V.conv_wino([g], B, cpad, L, d, DEV, wcfg)
     torch.cuda.synchronize()
     assert maxdiff(out, ref) <= 2e-5          # |out| ~ 3; F(4,3) transforms amplify fp32 rounding ~4x
     del keep
 
 
-def test_conv_wino_three_segments_fused_average():
-    c, L, B = 64, 1203, 2
+@pytest.mark.parametrize("c", [64, 96])
+def test_conv_wino_three_segments_fused_average(c):
+    L, B = 1203, 2
     ks = [11, 7, 3]
     xs = [rnd(B, c, L, seed=120 + i) for i in range(3)]
     ws = [rnd(c, c, k, seed=130 + i, scale=0.05) for i, k in enumerate(ks)]
@@ -144,7 +146,7 @@ def test_conv_wino_three_segments_fused_average():
     bsum = sum(bs).to(DEV)
     g = V.make_wino_group([V.make_wino_seg(xd[i], ud[i], c, k) for i, k in enumerate(ks)], bsum, rd, out, c, c, L,
                           scale=1.0 / 3)
-    keep = V.conv_wino([g], B, c, L, 1, DEV)
+    keep = V.conv_wino([g], B, c, L, 1, DEV, V.pick_wino_tile(c)[0])
     torch.cuda.synchronize()
     assert maxdiff(out, ref) <= 2e-5
     del keep

@@ -33,13 +33,13 @@ for c, L in ((768, 5000), (384, 20000), (192, 60000), (96, 120000), (48, 240000)
         gd = [V.make_conv_group([V.make_conv_seg(xs[i], wd[i], c, [(t - (k - 1) // 2) * d for t in range(k)])],
                                 bs[i], [], outs[i], c, cpad, L, L, L) for i, k in enumerate(KS)]
         dd = hip.to_device_struct_array(gd, DEV)
-        wpad = -(-c // V.WINO_BM) * V.WINO_BM
+        wcfg, wpad = V.pick_wino_tile(c)
         ud = [V.pack_wino_weight(w, wpad).to(DEV) for w in ws]
         gw = [V.make_wino_group([V.make_wino_seg(xs[i], ud[i], c, k)], bs[i], [], outs[i], c, wpad, L)
               for i, k in enumerate(KS)]
         dw = hip.to_device_struct_array(gw, DEV)
         st = hip.stream()
         t_d = bench(lambda: hip.check(hip.lib().fh_conv_grouped_f32(dd.data_ptr(), 3, B, cpad, L, tcfg, ck, st)))
-        t_w = bench(lambda: hip.check(hip.lib().fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, st)))
+        t_w = bench(lambda: hip.check(hip.lib().fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, wcfg, st)))
         fl = 2.0 * c * c * sum(KS) * L * B
         print(f"{c:5d} {L:7d} {d:2d} {fl/1e9:8.2f} {t_d:10.1f} {fl/t_d/1e6:6.1f} {t_w:9.1f} {fl/t_w/1e6:8.1f} {t_d/t_w:7.2f}")

@@ -14,7 +14,7 @@ wd = [V.pack_conv_weight(w, cpad, ck).to(DEV) for w in ws]
 gd = [V.make_conv_group([V.make_conv_seg(xs[i], wd[i], c, [(t - (k - 1) // 2) * d for t in range(k)])],
                         bs[i], [], outs[i], c, cpad, L, L, L) for i, k in enumerate(KS)]
 dd = hip.to_device_struct_array(gd, DEV)
-wpad = -(-c // V.WINO_BM) * V.WINO_BM
+wcfg, wpad = V.pick_wino_tile(c)
 ud = [V.pack_wino_weight(w, wpad).to(DEV) for w in ws]
 gw = [V.make_wino_group([V.make_wino_seg(xs[i], ud[i], c, k)], bs[i], [], outs[i], c, wpad, L) for i, k in enumerate(KS)]
 dw = hip.to_device_struct_array(gw, DEV)
@@ -23,5 +23,5 @@ for _ in range(5):
     if which in ("both", "direct"):
         hip.check(hip.lib().fh_conv_grouped_f32(dd.data_ptr(), 3, B, cpad, L, tcfg, ck, st))
     if which in ("both", "wino"):
-        hip.check(hip.lib().fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, st))
+        hip.check(hip.lib().fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, wcfg, st))
 torch.cuda.synchronize()

@@ -8,14 +8,14 @@ xs = [torch.randn(B, c, L, device=DEV) for _ in KS]
 outs = [torch.empty(B, c, L, device=DEV) for _ in KS]
 ws = [torch.randn(c, c, k) * 0.02 for k in KS]
 bs = [torch.randn(c, device=DEV) for _ in KS]
-wpad = -(-c // V.WINO_BM) * V.WINO_BM
+wcfg, wpad = V.pick_wino_tile(c)
 ud = [V.pack_wino_weight(w, wpad).to(DEV) for w in ws]
 gw = [V.make_wino_group([V.make_wino_seg(xs[i], ud[i], c, k)], bs[i], [], outs[i], c, wpad, L) for i, k in enumerate(KS)]
 dw = hip.to_device_struct_array(gw, DEV)
 st = hip.stream()
 lib = hip.lib()
 lib.fh_debug_set_wino_trace.argtypes = [ctypes.c_void_p]
-run = lambda: hip.check(lib.fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, st))
+run = lambda: hip.check(lib.fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, wcfg, st))
 for _ in range(3): run()
 torch.cuda.synchronize()
 buf = torch.zeros(1 + 4 * 100000, dtype=torch.int64, device=DEV)
