@@ -22,31 +22,31 @@
 // packed-fp32 VALU (v_pk_fma_f32).  (A persistent, software-prefetching variant measured slower.)
 #include "fh_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte access at any dword address
 
-// sin^2(a) without libm's sinf, two values at a time.  Cody-Waite reduction by pi/2 in three fused
-// steps (exact products for |k| < 2^15), then the odd Taylor polynomial of sin to r^9 on
-// |r| <= pi/4 (truncation 2e-9); sin^2 = s^2 for even k, 1 - s^2 for odd k.  Absolute error
-// <= 1.2e-7 (checked on the host against float64 over |a| < 3e4), the same size as squaring a
-// 1-ulp sinf.  |a| >= 32768 is patched by the caller.
+// sin^2(a) without libm's sinf, two values at a time.  sin^2 has period pi and is even: Cody-Waite
+// reduction by pi in three fused steps (exact products for |k| < 2^15) to |r| <= pi/2, then
+// sin^2(r) = w P(w), w = r^2, P = degree-5 near-minimax fit of sin^2(sqrt w) / w on [0, (pi/2)^2]
+// (tools: numpy Chebyshev fit).  No quadrant select.  Absolute error <= 1.6e-7 in fp32 (checked on the
+// host against float64), the same size as squaring a 1-ulp sinf.  |a| >= 32768 is patched by the caller.
 __device__ __forceinline__ f32x2 sin_squared2(f32x2 a) {
-  const f32x2 t = a * 0.63661977236758134308f;
+  const f32x2 t = a * 0.31830988618379067154f;
   const f32x2 k = {rintf(t[0]), rintf(t[1])};
-  f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-1.5703125f), a);
-  r = __builtin_elementwise_fma(k, (f32x2)(-4.837512969970703125e-4f), r);
-  r = __builtin_elementwise_fma(k, (f32x2)(-7.549789948768648e-8f), r);
-  const f32x2 r2 = r * r;
-  f32x2 p = __builtin_elementwise_fma(r2, (f32x2)(2.7557314297e-06f), (f32x2)(-1.9841270114e-04f));
-  p = __builtin_elementwise_fma(r2, p, (f32x2)(8.3333337680e-03f));
-  p = __builtin_elementwise_fma(r2, p, (f32x2)(-1.6666667163e-01f));
-  const f32x2 s = __builtin_elementwise_fma(r * r2, p, r);
-  const f32x2 s2 = s * s;
-  f32x2 o;
-  o[0] = (static_cast<int>(k[0]) & 1) ? 1.0f - s2[0] : s2[0];
-  o[1] = (static_cast<int>(k[1]) & 1) ? 1.0f - s2[1] : s2[1];
-  return o;
+  f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-3.140625f), a);
+  r = __builtin_elementwise_fma(k, (f32x2)(-9.67502593994140625e-4f), r);
+  r = __builtin_elementwise_fma(k, (f32x2)(-1.5099579897537296e-7f), r);
+  const f32x2 w = r * r;
+  f32x2 p = __builtin_elementwise_fma(w, (f32x2)(-3.6304279547e-06f), (f32x2)(1.3934598246e-04f));
+  p = __builtin_elementwise_fma(w, p, (f32x2)(-3.1723924913e-03f));
+  p = __builtin_elementwise_fma(w, p, (f32x2)(4.4443175197e-02f));
+  p = __builtin_elementwise_fma(w, p, (f32x2)(-3.3333307505e-01f));
+  p = __builtin_elementwise_fma(w, p, (f32x2)(1.0f));
+  return w * p;
 }
 
 __device__ __noinline__ float sin_squared_slow(float a) {   // huge arguments only (never in practice)
@@ -54,8 +54,14 @@ __device__ __noinline__ float sin_squared_slow(float a) {   // huge arguments on
   return s * s;
 }
 
-constexpr int ACT_PPT = 4;                   // z pairs (and outputs) per thread, consecutive
-constexpr int ACT_PAIRS = 256 * ACT_PPT;     // z pairs of a tile: samples i = t0 - 4 + p
+#ifndef ACT_PPT_N
+#define ACT_PPT_N 4
+#endif
+constexpr int ACT_PPT = ACT_PPT_N;                   // z pairs (and outputs) per thread, consecutive
+#ifndef ACT_THREADS
+#define ACT_THREADS 256
+#endif
+constexpr int ACT_PAIRS = ACT_THREADS * ACT_PPT;     // z pairs of a tile: samples i = t0 - 4 + p
 constexpr int ACT_TT = ACT_PAIRS - 8;        // outputs per tile (multiple of 8: tiles start 16-byte aligned)
 constexpr int ACT_XS = ACT_TT + 16;          // staged inputs x[t0-8 .. t0+TT+7]
 constexpr int ACT_XF4 = ACT_XS / 4;          // ... as float4s
@@ -63,9 +69,13 @@ constexpr int ACT_XF4 = ACT_XS / 4;          // ... as float4s
 // One block = one (group, batch, channel, tile).  Thread t owns pairs 4t .. 4t+3 and outputs
 // 4t .. 4t+3: every LDS access is a 16-byte vector, and when rows are 16-byte aligned
 // (len % 4 == 0) so is every global access -- 4-byte-per-lane loads ran this kernel at 2.5 TB/s.
-__global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restrict__ groups,
+// din / dout > 1: the input / output tensor is phase-major for that dilation (fh_phase_len, include/
+// flowhigh_hip.h): element t of a row lives at (t % d) * lp + t / d.  A dilated Winograd conv between two
+// such launches then works on contiguous runs.  Consecutive lanes still touch consecutive t, i.e. d runs of
+// 64 / d contiguous floats per wave instruction.
+__global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const fh_act_group* __restrict__ groups,
                                                     int batch, int channels, int len,
-                                                    int tiles_per_row) {
+                                                    int tiles_per_row, int din, int dout) {
   __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
 
@@ -75,9 +85,10 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   const int gb = row / channels;
   const fh_act_group& G = groups[gb / batch];
   const int b = gb % batch;
-  const size_t base = ((size_t)b * channels + c) * len;
-  const float* __restrict__ x = G.x + base;
-  float* __restrict__ y = G.y + base;
+  const int lp_in = ((len + din - 1) / din + 3) & ~3, lp_out = ((len + dout - 1) / dout + 3) & ~3;
+  const size_t rowi = (size_t)b * channels + c;
+  const float* __restrict__ x = G.x + rowi * (din > 1 ? (size_t)din * lp_in : (size_t)len);
+  float* __restrict__ y = G.y + rowi * (dout > 1 ? (size_t)dout * lp_out : (size_t)len);
   const float alpha = G.alpha[c];
   const float inv_beta = G.inv_beta[c];
   const int t0 = tile * ACT_TT;
@@ -86,9 +97,38 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   const bool vec = (len & 3) == 0 && ((((size_t)G.x) | ((size_t)G.y)) & 15) == 0;
 
   // phase 1: xs[j] = x[clamp(t0 - 8 + j)], j < XS; thread t stages float4 #t, #256+t, ...
+  if (din > 1) {
+    const int tb = t0 - 8;
+    if (tb >= 0 && tb + ACT_XS <= len) {
+      // tile interior: every thread fetches 4 consecutive samples of ONE phase (16 bytes, contiguous in the
+      // phase-major row) and scatters them to their natural positions in LDS (stride din, odd -> conflict free)
+      const int nq = ((ACT_XS + din - 1) / din + 3) / 4;
+      for (int q = tid; q < din * nq; q += ACT_THREADS) {
+        const int p = q / nq, k = q - p * nq;
+        const int u_lo = (tb - p + din - 1) / din;
+        const int u_hi = (tb + ACT_XS - 1 - p) / din;
+        const int u = u_lo + 4 * k;
+        const float* src = x + p * lp_in + u;
+        if (u + 3 <= u_hi) {
+          const f32x4u v = *reinterpret_cast<const f32x4u*>(src);
 #pragma unroll
-  for (int rep = 0; rep < (ACT_XF4 + 255) / 256; ++rep) {
-    const int f = tid + 256 * rep;
+          for (int e = 0; e < 4; ++e) xs[(u + e) * din + p - tb] = v[e];
+        } else {
+          for (int e = 0; e < 4 && u + e <= u_hi; ++e) xs[(u + e) * din + p - tb] = src[e];
+        }
+      }
+    } else {
+      for (int j = tid; j < ACT_XS; j += ACT_THREADS) {
+        int t = tb + j;
+        t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
+        const int u = t / din;
+        xs[j] = x[(t - u * din) * lp_in + u];
+      }
+    }
+  } else
+#pragma unroll
+  for (int rep = 0; rep < (ACT_XF4 + ACT_THREADS - 1) / ACT_THREADS; ++rep) {
+    const int f = tid + ACT_THREADS * rep;
     if (f >= ACT_XF4) break;
     const int t = t0 - 8 + 4 * f;
     f32x4 v;
@@ -110,8 +150,8 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   f32x2 fu2[7];             // taps of x[i-3 .. i+3] for (z[2i], z[2i+1]); the unused end tap is 0
 #pragma unroll
   for (int q = -3; q <= 3; ++q) {
-    fu2[q + 3][0] = q <= 2 ? G.up_taps[5 - 2 * q] : 0.f;
-    fu2[q + 3][1] = q >= -2 ? G.up_taps[6 - 2 * q] : 0.f;
+    fu2[q + 3][0] = q <= 2 ? 2.f * G.up_taps[5 - 2 * q] : 0.f;      // (the 2x of UpSample1d folded in: exact)
+    fu2[q + 3][1] = q >= -2 ? 2.f * G.up_taps[6 - 2 * q] : 0.f;
   }
   {
     float xv[ACT_PPT + 8];  // xs[PPT tid .. PPT tid + PPT + 7]; pair r uses xv[r + 1 .. r + 7]
@@ -126,7 +166,6 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
       f32x2 z = {0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 7; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + 1 + q]), fu2[q], z);
-      z = z * 2.f;
       const f32x2 arg = z * alpha;
       f32x2 s2 = sin_squared2(arg);
       if (__builtin_expect(fabsf(arg[0]) >= 32768.f || fabsf(arg[1]) >= 32768.f, 0)) {
@@ -148,9 +187,16 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   float fd[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) fd[k] = G.down_taps[k];
+  // taps as aligned (even, odd) z pairs: pair j of output r is (zv[2r + 2 + 2j], zv[2r + 3 + 2j]) = taps (2j - 1, 2j)
+  f32x2 fdp[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    fdp[j][0] = j > 0 ? fd[2 * j - 1] : 0.f;
+    fdp[j][1] = j < 6 ? fd[2 * j] : 0.f;
+  }
   const int o0 = ACT_PPT * tid;
   const int i0 = t0 + o0;
-  if (o0 >= ACT_TT || i0 >= len) return;
+  if (dout == 1 && (o0 >= ACT_TT || i0 >= len)) return;
   float zv[2 * ACT_PPT + 16];   // zs[2 PPT tid .. + 2 PPT + 15]
 #pragma unroll
   for (int v = 0; v < ACT_PPT / 2 + 4; ++v) {
@@ -164,8 +210,11 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
     const int i = i0 + r;
     float acc = 0.f;
     if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {
+      f32x2 a2 = {0.f, 0.f};                          // even-tap and odd-tap partial sums, packed
 #pragma unroll
-      for (int k = 0; k < 12; ++k) acc = fmaf(zv[2 * r + 3 + k], fd[k], acc);
+      for (int j = 0; j < 7; ++j)
+        a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
+      acc = a2[0] + a2[1];
     } else if (i < len) {
 #pragma unroll
       for (int k = 0; k < 12; ++k) {
@@ -175,6 +224,30 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
       }
     }
     out[r] = acc;
+  }
+  if (dout > 1) {          // through LDS (xs is free now) so that every store instruction writes runs
+#pragma unroll
+    for (int v = 0; v < ACT_PPT / 4; ++v)
+      *reinterpret_cast<f32x4*>(xs + o0 + 4 * v) = (f32x4){out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+    __syncthreads();
+    const int t_end = (t0 + ACT_TT < len ? t0 + ACT_TT : len) - 1;      // last output of this tile
+    const int nq = ((ACT_TT + dout - 1) / dout + 3) / 4;
+    for (int q = tid; q < dout * nq; q += ACT_THREADS) {                         // 4 consecutive outputs of one phase
+      const int p = q / nq, k = q - p * nq;
+      const int u_lo = (t0 - p + dout - 1) / dout;
+      const int u_hi = t_end >= p ? (t_end - p) / dout : -1;
+      const int u = u_lo + 4 * k;
+      float* dst = y + p * lp_out + u;
+      if (u + 3 <= u_hi) {
+        f32x4u v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = xs[(u + e) * dout + p - t0];
+        *reinterpret_cast<f32x4u*>(dst) = v;
+      } else {
+        for (int e = 0; e < 4 && u + e <= u_hi; ++e) dst[e] = xs[(u + e) * dout + p - t0];
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int v = 0; v < ACT_PPT / 4; ++v) {   // o0 + PPT - 1 < TT always holds for o0 < TT (TT % PPT == 0)
@@ -188,18 +261,283 @@ __global__ __launch_bounds__(256) void act1d_kernel(const fh_act_group* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Plain-layout launches: software-pipelined strips.  The kernel above holds at most ~1/3 of a CU's
+// loads in flight (load -> barrier -> math -> barrier -> math -> store per block, all resident blocks in
+// phase) and stalls at ~3 TB/s where a copy reaches 6-7.  Here a block walks ACT_NTILE consecutive tiles
+// of the flattened (row, tile) space and requests tile i + 1 before it computes tile i.  All global
+// accesses are unconditional buffer operations (invalid = out-of-range offset), so the compiler's
+// s_waitcnt are exact: the wait for the prefetched tile does not drain the stores issued after it.
+constexpr int ACT_NTILE = 4;
+
+// PIN / POUT: input / output rows are phase-major for dilation din / dout (see act1d_kernel).
+template <bool VEC, bool PIN, bool POUT>
+__global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __restrict__ groups, int batch,
+                                                          int channels, int len, int tiles_per_row,
+                                                          long long total_tiles, int din, int dout) {
+  static_assert(ACT_THREADS == 256 && ACT_PPT == 4, "strip kernel is written for 256 threads x 4 outputs");
+  __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
+  __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
+  __shared__ __attribute__((aligned(16))) float ys[POUT ? ACT_PAIRS : 4];     // outputs of a tile, natural order
+  const int tid = threadIdx.x;
+  const int zlast = 2 * len - 1;
+  const long long g0 = (long long)blockIdx.x * ACT_NTILE;
+  const int lp_in = ((len + din - 1) / din + 3) & ~3, lp_out = ((len + dout - 1) / dout + 3) & ~3;
+  const int pitch_in = PIN ? din * lp_in : len, pitch_out = POUT ? dout * lp_out : len;
+  // phase-major input: chunk q = (phase p, 4 consecutive decimated samples); <= 2 chunks per thread
+  const int nq_in = PIN ? ((ACT_XS + din - 1) / din + 3) / 4 : 1;
+  const int nq_out = POUT ? ((ACT_TT + dout - 1) / dout + 3) / 4 : 1;
+
+  struct Tile {                       // wave-uniform description of one flattened tile
+    __amdgpu_buffer_rsrc_t rx, ry;
+    const fh_act_group* G;
+    int t0, c;
+    float alpha, inv_beta;            // vector loads, requested one tile ahead together with the tile itself
+  };
+  auto tile_of = [&](long long g) {
+    Tile T;
+    const bool ok = g < total_tiles;
+    const long long gg = ok ? g : total_tiles - 1;
+    const int tile = uni((int)(gg % tiles_per_row));
+    const long long row = gg / tiles_per_row;          // (group * batch + b) * channels + c
+    T.c = uni((int)(row % channels));
+    const long long gb = row / channels;
+    T.G = groups + uni((int)(gb / batch));
+    const size_t rowi = (size_t)uni((int)(gb % batch)) * channels + T.c;
+    T.rx = make_rsrc(uni(T.G->x) + rowi * (size_t)pitch_in, ok ? (unsigned)pitch_in * 4u : 0u);
+    T.ry = make_rsrc(uni((const float*)T.G->y) + rowi * (size_t)pitch_out, ok ? (unsigned)pitch_out * 4u : 0u);
+    T.t0 = tile * ACT_TT;
+    // (buffer loads, not flat ones: with a flat load in flight the compiler has to wait with vmcnt(0))
+    T.alpha = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+        make_rsrc(uni(T.G->alpha), (unsigned)channels * 4u), (unsigned)T.c * 4u, 0, 0));
+    T.inv_beta = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+        make_rsrc(uni(T.G->inv_beta), (unsigned)channels * 4u), (unsigned)T.c * 4u, 0, 0));
+    return T;
+  };
+  // x[t0 - 8 + 4 f .. + 3] for f = tid, tid + 256 (258 float4 per tile); out of the row -> 0, patched below
+  auto load_tile = [&](const Tile& T, u32x4 (&xr)[2]) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int f = tid + 256 * rep;
+      if (PIN) {           // 4 consecutive samples of one phase: 16 bytes at a dword-aligned address
+        const int tb = T.t0 - 8;
+        const int p = f / nq_in, k = f - p * nq_in;
+        const int ul = (tb - p + 9 * din - 1) / din - 8;          // ceil((tb - p) / din), tb >= -8
+        const int u = (ul > 0 ? ul : 0) + 4 * k;
+        // (past the row: reads a neighbour phase or falls out of range; such samples are not used)
+        xr[rep] = __builtin_amdgcn_raw_buffer_load_b128(T.rx, p < din ? (unsigned)((p * lp_in + u) * 4) : 0x80000000u, 0, 0);
+        continue;
+      }
+      const int t = T.t0 - 8 + 4 * f;
+      if (VEC) {
+        xr[rep] = __builtin_amdgcn_raw_buffer_load_b128(T.rx, f < ACT_XF4 ? (unsigned)(t * 4) : 0x80000000u, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          xr[rep][e] = __builtin_amdgcn_raw_buffer_load_b32(T.rx, f < ACT_XF4 ? (unsigned)((t + e) * 4) : 0x80000000u, 0, 0);
+      }
+    }
+  };
+
+  Tile T = tile_of(g0);
+  u32x4 cur[2], nxt[2];
+  load_tile(T, cur);
+#pragma unroll
+  for (int it = 0; it < ACT_NTILE; ++it) {
+    const Tile Tn = tile_of(g0 + it + 1);
+    const fh_act_group& G = *T.G;
+    const float alpha = T.alpha, inv_beta = T.inv_beta;
+    if (PIN) {                 // scatter the phase chunks to their natural positions (stride din, odd: conflict free)
+      const int tb = T.t0 - 8;
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const int f = tid + 256 * rep;
+        const int p = f / nq_in, k = f - p * nq_in;
+        const int ul = (tb - p + 9 * din - 1) / din - 8;
+        const int u = (ul > 0 ? ul : 0) + 4 * k;
+        if (p < din) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int t = (u + e) * din + p;
+            if (t >= 0 && t < len && t - tb < ACT_XS) xs[t - tb] = __uint_as_float(cur[rep][e]);
+          }
+        }
+      }
+    } else {
+      *reinterpret_cast<u32x4*>(xs + 4 * tid) = cur[0];
+      if (tid + 256 < ACT_XF4) *reinterpret_cast<u32x4*>(xs + 4 * (tid + 256)) = cur[1];
+    }
+    if (it + 1 < ACT_NTILE) load_tile(Tn, nxt);
+    __syncthreads();
+    const int t0 = T.t0, tb = t0 - 8;
+    if (tb < 0 || tb + ACT_XS > len) {             // replicate padding at the row ends (uniform branch, LDS only)
+      for (int j = tid; j < ACT_XS; j += 256) {
+        const int t = tb + j;
+        if (t < 0) xs[j] = xs[-tb];
+        else if (t >= len && len - 1 - tb >= 0) xs[j] = xs[len - 1 - tb];
+      }
+      __syncthreads();
+    }
+    // phase 2 (as above)
+    {
+      f32x2 fu2[7];
+#pragma unroll
+      for (int q = -3; q <= 3; ++q) {
+        fu2[q + 3][0] = q <= 2 ? 2.f * G.up_taps[5 - 2 * q] : 0.f;
+        fu2[q + 3][1] = q >= -2 ? 2.f * G.up_taps[6 - 2 * q] : 0.f;
+      }
+      float xv[ACT_PPT + 8];
+#pragma unroll
+      for (int v = 0; v < ACT_PPT / 4 + 2; ++v) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(xs + ACT_PPT * tid + 4 * v);
+        xv[4 * v] = t4[0]; xv[4 * v + 1] = t4[1]; xv[4 * v + 2] = t4[2]; xv[4 * v + 3] = t4[3];
+      }
+      f32x2 zout[ACT_PPT];
+#pragma unroll
+      for (int r = 0; r < ACT_PPT; ++r) {
+        f32x2 z = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 7; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + 1 + q]), fu2[q], z);
+#if defined(ACT_ABL) && (ACT_ABL & 2)
+        zout[r] = (f32x2){xv[r + 1], xv[r + 2]} * alpha + inv_beta;
+        continue;
+#endif
+        const f32x2 arg = z * alpha;
+#if defined(ACT_ABL) && (ACT_ABL & 1)
+        f32x2 s2 = arg;
+#else
+        f32x2 s2 = sin_squared2(arg);
+        if (__builtin_expect(fabsf(arg[0]) >= 32768.f || fabsf(arg[1]) >= 32768.f, 0)) {
+          s2[0] = sin_squared_slow(arg[0]);
+          s2[1] = sin_squared_slow(arg[1]);
+        }
+#endif
+        zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2, z);
+      }
+      f32x4* zw = reinterpret_cast<f32x4*>(zs + 2 * ACT_PPT * tid);
+#pragma unroll
+      for (int v = 0; v < ACT_PPT / 2; ++v)
+        zw[v] = (f32x4){zout[2 * v][0], zout[2 * v][1], zout[2 * v + 1][0], zout[2 * v + 1][1]};
+    }
+    __syncthreads();
+    // phase 3 (as above); every thread computes, invalid outputs get an out-of-range store offset
+    {
+      float fd[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) fd[k] = G.down_taps[k];
+      f32x2 fdp[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        fdp[j][0] = j > 0 ? fd[2 * j - 1] : 0.f;
+        fdp[j][1] = j < 6 ? fd[2 * j] : 0.f;
+      }
+      const int o0 = ACT_PPT * tid;
+      const int i0 = t0 + o0;
+      float zv[2 * ACT_PPT + 16];
+#pragma unroll
+      for (int v = 0; v < ACT_PPT / 2 + 4; ++v) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 2 * ACT_PPT * tid + 4 * v);
+        zv[4 * v] = t4[0]; zv[4 * v + 1] = t4[1]; zv[4 * v + 2] = t4[2]; zv[4 * v + 3] = t4[3];
+      }
+      float out[ACT_PPT];
+      const int zbase = 2 * (t0 - 4);
+#pragma unroll
+      for (int r = 0; r < ACT_PPT; ++r) {
+        const int i = i0 + r;
+        float acc = 0.f;
+#if defined(ACT_ABL) && (ACT_ABL & 4)
+        out[r] = zv[2 * r + 8];
+        continue;
+#endif
+        if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {
+          f32x2 a2 = {0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 7; ++j)
+            a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
+          acc = a2[0] + a2[1];
+        } else if (i < len && o0 < ACT_TT) {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) {
+            int m = 2 * i + k - 5;
+            m = m < 0 ? 0 : (m > zlast ? zlast : m);
+            acc = fmaf(zs[m - zbase], fd[k], acc);
+          }
+        }
+        out[r] = acc;
+      }
+      if (POUT) {                // natural order through LDS, then 4 consecutive outputs of one phase per thread
+        *reinterpret_cast<f32x4*>(ys + o0) = (f32x4){out[0], out[1], out[2], out[3]};
+        __syncthreads();
+        const int t_end = (t0 + ACT_TT < len ? t0 + ACT_TT : len) - 1;      // last output of this tile
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+          const int q = tid + 256 * rep;
+          const int p = q / nq_out, k = q - p * nq_out;
+          const int u = (t0 - p + dout - 1) / dout + 4 * k;                 // t0 - p + dout - 1 >= 0
+          const int u_hi = (p < dout && t_end >= p) ? (t_end - p) / dout : -1;
+          const unsigned off0 = (unsigned)((p * lp_out + u) * 4);
+          if (u + 3 <= u_hi) {
+            u32x4 ou;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ou[e] = __float_as_uint(ys[(u + e) * dout + p - t0]);
+            __builtin_amdgcn_raw_buffer_store_b128(ou, T.ry, off0, 0, 0);
+          } else {
+            for (int e = 0; e < 4 && u + e <= u_hi; ++e)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ys[(u + e) * dout + p - t0]), T.ry, off0 + 4u * e, 0, 0);
+          }
+        }
+      } else if (VEC) {
+        const unsigned off = (o0 < ACT_TT && i0 < len) ? (unsigned)(i0 * 4) : 0x80000000u;
+        const u32x4 ou = {__float_as_uint(out[0]), __float_as_uint(out[1]), __float_as_uint(out[2]), __float_as_uint(out[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(ou, T.ry, off, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[r]), T.ry,
+                                                (o0 < ACT_TT && i0 + r < len) ? (unsigned)((i0 + r) * 4) : 0x80000000u, 0, 0);
+      }
+    }
+    T = Tn;
+    cur[0] = nxt[0];
+    cur[1] = nxt[1];
+  }
+}
+
 }  // namespace
 
 extern "C" int fh_sizeof_act_group(void) { return (int)sizeof(fh_act_group); }
 
-extern "C" int fh_act1d_grouped_f32(const fh_act_group* groups, int n_groups, int batch,
-                                    int channels, int len, void* stream) {
+extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups, int batch,
+                                       int channels, int len, int din, int dout, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && channels > 0 && len > 0, "fh_act1d_grouped_f32: bad sizes");
+  FH_CHECK_ARG(din >= 1 && dout >= 1 && din <= 64 && dout <= 64, "fh_act1d_grouped_pm_f32: bad dilations %d / %d", din, dout);
   const int tiles = fh_cdiv(len, ACT_TT);
   const long long blocks = (long long)n_groups * batch * channels * tiles;
   FH_CHECK_ARG(blocks < (1ll << 31), "fh_act1d_grouped_f32: grid too large");
-  hipLaunchKernelGGL(act1d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, groups,
-                     batch, channels, len, tiles);
+  // chunks of a tile in phase-major form must fit 2 per thread: ceil(ceil(XS / d) / 4) * d <= 512
+  const bool strip_ok = (long long)len * 4 * (din > dout ? din : dout) < (1ll << 31) && din <= 16 && dout <= 16 &&
+                        !getenv("FH_ACT_NO_STRIP");
+  if (strip_ok) {
+    const long long strips = (blocks + ACT_NTILE - 1) / ACT_NTILE;
+    const bool vec = (len & 3) == 0;   // rows 16-byte aligned provided the tensors are (checked by the host plan)
+#define FH_ACT_LAUNCH(V, PI, PO)                                                                              \
+  hipLaunchKernelGGL((act1d_strip_kernel<V, PI, PO>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
+                     groups, batch, channels, len, tiles, blocks, din, dout)
+    if (din > 1 && dout > 1) FH_ACT_LAUNCH(false, true, true);
+    else if (din > 1) { if (vec) FH_ACT_LAUNCH(true, true, false); else FH_ACT_LAUNCH(false, true, false); }
+    else if (dout > 1) { if (vec) FH_ACT_LAUNCH(true, false, true); else FH_ACT_LAUNCH(false, false, true); }
+    else { if (vec) FH_ACT_LAUNCH(true, false, false); else FH_ACT_LAUNCH(false, false, false); }
+#undef FH_ACT_LAUNCH
+    FH_CHECK_LAUNCH("fh_act1d_grouped_f32");
+    return FH_OK;
+  }
+  hipLaunchKernelGGL(act1d_kernel, dim3((unsigned)blocks), dim3(ACT_THREADS), 0, (hipStream_t)stream, groups,
+                     batch, channels, len, tiles, din, dout);
   FH_CHECK_LAUNCH("fh_act1d_grouped_f32");
   return FH_OK;
+}
+
+extern "C" int fh_act1d_grouped_f32(const fh_act_group* groups, int n_groups, int batch,
+                                    int channels, int len, void* stream) {
+  return fh_act1d_grouped_pm_f32(groups, n_groups, batch, channels, len, 1, 1, stream);
 }

@@ -90,7 +90,7 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
 template <int MT, int NT>
 __global__ __attribute__((amdgpu_flat_work_group_size(W_THREADS, W_THREADS), amdgpu_waves_per_eu(3, 3)))
 void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles,
-                      int n_tiles, int run_len, int dil) {
+                      int n_tiles, int run_len, int dil, int pm) {
   using Cfg = WCfg<MT, NT>;
   constexpr int W_BM = Cfg::BM, W_BT = Cfg::BT, W_P = Cfg::P, W_RP2 = Cfg::RP2, W_XPT = Cfg::XPT, W_SLAB = Cfg::SLAB;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // Cfg::LDS_FLOATS
@@ -126,6 +126,10 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const int co0 = cot * W_BM;
   const int len = uni(G->len), cout_pad = uni(G->cout_pad), nseg = uni(G->nseg);
 
+  // phase-major tensors (pm): row = dil phases of lp samples, x[p + dil u] at p * lp + u
+  const int lp = ((len + dil - 1) / dil + 3) & ~3;
+  const int pitch = pm ? dil * lp : len;             // floats per (batch, channel) row, inputs and outputs
+
   const int bo0 = kBtOff[xi][0], bo1 = kBtOff[xi][1], bo2 = kBtOff[xi][2], bo3 = kBtOff[xi][3];
   const float bc0 = kBtCoef[xi][0], bc1 = kBtCoef[xi][1], bc2 = kBtCoef[xi][2], bc3 = kBtCoef[xi][3];
 
@@ -148,20 +152,21 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   unsigned xreg[W_XPT];
   auto load_x = [&](const WSeg& S, int chunk, bool valid) {
     const __amdgpu_buffer_rsrc_t r =
-        make_rsrc(uni(S.x + (size_t)b * S.cin * len), valid ? (unsigned)(S.cin * len) * 4u : 0u);
-    const int posb = (tb * (4 * W_BT) - S.center) * dil + ph;            // first staged position (uniform)
-    const int pos0 = posb + ltt * dil;
-    const int rowoff = (chunk * W_CK + lrow) * len;
+        make_rsrc(uni(S.x + (size_t)b * S.cin * pitch), valid ? (unsigned)(S.cin * pitch) * 4u : 0u);
+    const int ub = tb * (4 * W_BT) - S.center;                           // first staged decimated index (uniform)
+    const int posb = ub * dil + ph;                                      // ... and its position in the clip
+    const int rowoff = (chunk * W_CK + lrow) * pitch;
+    const int estride = pm ? 1 : dil;                                    // element stride of consecutive u
+    const int eoff0 = rowoff + (pm ? ph * lp + ub + ltt : posb + ltt * dil);
     if (posb >= 0 && posb + (48 * W_XPT - 1) * dil < len) {               // block interior: no per-sample checks
-      const unsigned off0 = (unsigned)(rowoff + pos0) * 4u;
 #pragma unroll
       for (int i = 0; i < W_XPT; ++i)
-        xreg[i] = __builtin_amdgcn_raw_buffer_load_b32(r, off0 + (unsigned)(48 * 4 * i) * (unsigned)dil, 0, 0);
+        xreg[i] = __builtin_amdgcn_raw_buffer_load_b32(r, (unsigned)(eoff0 + 48 * i * estride) * 4u, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < W_XPT; ++i) {
-        const int pos = pos0 + 48 * i * dil;             // outside the row: out-of-range offset -> 0
-        const unsigned off = (unsigned)pos < (unsigned)len ? (unsigned)(rowoff + pos) * 4u : 0x80000000u;
+        const int pos = posb + (ltt + 48 * i) * dil;     // outside the clip: out-of-range offset -> 0
+        const unsigned off = (unsigned)pos < (unsigned)len ? (unsigned)(eoff0 + 48 * i * estride) * 4u : 0x80000000u;
         xreg[i] = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
       }
     }
@@ -255,15 +260,15 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           bf[nt] = xr[p & 1][0][nt];
           asm volatile("" : "+v"(bf[nt]) : "v"(xr[p & 1][1][nt]), "v"(xr[p & 1][2][nt]), "v"(xr[p & 1][3][nt]));
 #else
-          asm("v_pk_mul_f32 %0, %1, %2" : "=v"(bf[nt]) : "v"(c0), "v"(xr[p & 1][0][nt]));
-          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "v"(c1), "v"(xr[p & 1][1][nt]));
-          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "v"(c2), "v"(xr[p & 1][2][nt]));
+          asm("v_pk_mul_f32 %0, %1, %2" : "=v"(bf[nt]) : "s"(c0), "v"(xr[p & 1][0][nt]));
+          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(c1), "v"(xr[p & 1][1][nt]));
+          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(c2), "v"(xr[p & 1][2][nt]));
           // (the hazard recognizer does not look inside asm: VALU result -> MFMA operand needs 2 wait
           // states; the MFMAs read column 0 first, so one s_nop after the last column covers all)
           if (nt + 1 < NT)
-            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "v"(c3), "v"(xr[p & 1][3][nt]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(c3), "v"(xr[p & 1][3][nt]));
           else
-            asm("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(bf[nt]) : "v"(c3), "v"(xr[p & 1][3][nt]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(bf[nt]) : "s"(c3), "v"(xr[p & 1][3][nt]));
 #endif
         }
 #pragma unroll
@@ -318,13 +323,13 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const float scale = G->scale;
   const int cout = uni(G->cout);
   const float* __restrict__ bias = uni(G->bias);
-  const size_t slab = (size_t)b * cout * len;
-  const unsigned slab_bytes = (unsigned)cout * (unsigned)len * 4u;
+  const size_t slab = (size_t)b * cout * pitch;
+  const unsigned slab_bytes = (unsigned)cout * (unsigned)pitch * 4u;
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(uni((const float*)G->out) + slab, slab_bytes);
   const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? uni(G->res[0]) + slab : nullptr, nres > 0 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? uni(G->res[1]) + slab : nullptr, nres > 1 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? uni(G->res[2]) + slab : nullptr, nres > 2 ? slab_bytes : 0u);
-  const bool vec = dil == 1 && (len & 3) == 0;      // 4 outputs of a tile = one aligned 16-byte vector
+  const bool vec = pm || (dil == 1 && (len & 3) == 0);   // 4 outputs of a tile = one aligned 16-byte vector
   float* E = lds;                                    // [th][xi][32][W_EP]
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -353,9 +358,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           const int v0 = tb * (4 * W_BT) + (nt * 64 + eh * 32 + col) * 4;   // decimated index of y[0]
           const bool rowok = co < cout;
           const float bv = (bias && rowok) ? bias[co] : 0.f;
-          const unsigned rowoff = (unsigned)co * (unsigned)len;
-          if (vec) {
-            const unsigned off = (rowok && v0 < len) ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
+          const unsigned rowoff = (unsigned)co * (unsigned)pitch + (pm ? (unsigned)(ph * lp) : 0u);
+          if (vec && (v0 + 3) * dil + ph < len) {
+            const unsigned off = rowok ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
             f32x4 o = {y[0] + bv, y[1] + bv, y[2] + bv, y[3] + bv};
             if (nres > 0) {
               u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr0, off, 0, 0);
@@ -377,7 +382,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int n = ph + dil * (v0 + q);
-              const unsigned off = (rowok && n < len) ? (rowoff + (unsigned)n) * 4u : 0x80000000u;
+              const unsigned off = (rowok && n < len) ? (rowoff + (unsigned)(pm ? v0 + q : n)) * 4u : 0x80000000u;
               float o = y[q] + bv;
               if (nres > 0) {
                 float rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));
@@ -445,7 +450,7 @@ namespace {
 
 template <int MT, int NT>
 int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
-                hipStream_t stream) {
+                int phase_major, hipStream_t stream) {
   using Cfg = WCfg<MT, NT>;
   FH_CHECK_ARG(cout_pad > 0 && cout_pad % Cfg::BM == 0, "fh_conv_wino_f32: cout_pad %d not a multiple of %d", cout_pad, Cfg::BM);
   const int co_tiles = cout_pad / Cfg::BM;
@@ -466,7 +471,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
     lds_opt_in = true;
   }
   hipLaunchKernelGGL((conv_wino_kernel<MT, NT>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
-                     stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation);
+                     stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major);
   FH_CHECK_LAUNCH("fh_conv_wino_f32");
   return FH_OK;
 }
@@ -475,15 +480,17 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
 
 extern "C" int fh_wino_tile_m(int tile_cfg) { return tile_cfg == 0 ? 64 : tile_cfg == 1 ? 96 : -1; }
 
+extern "C" int fh_phase_len(int len, int dilation) { return ((len + dilation - 1) / dilation + 3) & ~3; }
+
 extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad,
-                                int len, int dilation, int tile_cfg, void* stream) {
+                                int len, int dilation, int phase_major, int tile_cfg, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && len > 0, "fh_conv_wino_f32: bad sizes");
   FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino_f32: dilation %d unsupported", dilation);
   // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cin * len * 4 < 2^31
   // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
   switch (tile_cfg) {
-    case 0: return launch_wino<2, 2>(groups, n_groups, batch, cout_pad, len, dilation, (hipStream_t)stream);
-    case 1: return launch_wino<3, 1>(groups, n_groups, batch, cout_pad, len, dilation, (hipStream_t)stream);
+    case 0: return launch_wino<2, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 1: return launch_wino<3, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
   }
   fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
   return FH_E_ARG;

@@ -62,12 +62,14 @@ _SIGS = {
     "fh_conv_grouped_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
     "fh_sizeof_wino_group": [],
     "fh_wino_tile_m": [_I],
-    "fh_conv_wino_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
+    "fh_phase_len": [_I, _I],
+    "fh_conv_wino_f32": [_P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fh_mean_f32": [_P, _P, _P, _P, C.c_longlong, _F, _P],
     "fh_debug_set_conv_trace": [_P],
     "fh_debug_set_wino_trace": [_P],
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
+    "fh_act1d_grouped_pm_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
     "fh_gemm_f32": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P],
     "fh_gemv_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
     "fh_time_fourier_f32": [_P, _F, _P, _I, _P],

@@ -37,15 +37,19 @@ def _parse_wino_rule(text):
     return rule
 
 
+# Dilated Winograd convs work on phase-major tensors written / read by the neighbouring activation launches
+# (contiguous runs instead of stride-d access); FH_WINO_PM=0 keeps the plain layout.
+_WINO_PM = os.environ.get("FH_WINO_PM", "1") != "0"
 # channel count -> dilations that run as Winograd below FH_WINO_MIN_C (measured with tools/wino_bench.py, B = 1)
-_WINO_RULE = _parse_wino_rule(os.environ.get("FH_WINO_RULE", "96:1/3,48:1"))
+_WINO_RULE = _parse_wino_rule(os.environ.get("FH_WINO_RULE", "96:*,48:*" if _WINO_PM else "96:1/3,48:1"))
 
 
 def use_wino(c, d):
     """Residual-stack convs [c -> c, dilation d] that run as Winograd F(4,3) (conv_wino.hip) instead of the
     direct implicit GEMM: where it measured faster (tools/wino_bench.py), i.e. for c >= FH_WINO_MIN_C (default
-    192) at every dilation and for the (c, d) pairs of FH_WINO_RULE ("96:1/3,48:1": dilated convs of the narrow
-    stages lose to the strided access of one-phase-per-block).  FH_WINO=0 switches the path off."""
+    192) at every dilation and for the (c, d) pairs of FH_WINO_RULE (default "96:*,48:*"; without the phase-major
+    layout, FH_WINO_PM=0, the dilated convs of the narrow stages lose to stride-d access: "96:1/3,48:1").
+    FH_WINO=0 switches the path off."""
     if os.environ.get("FH_WINO", "1") == "0" or c % 16:
         return False
     if c >= int(os.environ.get("FH_WINO_MIN_C", "192")):
@@ -194,11 +198,38 @@ def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0):
     return g
 
 
-def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0):
+def phase_len(length, d):
+    """Per-phase row length of the phase-major layout (fh_phase_len)."""
+    return ((length + d - 1) // d + 3) & ~3
+
+
+def to_phase_major(x, d):
+    """[B, C, L] -> [B, C, d * phase_len]: x[..., p + d u] at [..., p * lp + u] (host helper for tests / tools)."""
+    B, C, L = x.shape
+    lp = phase_len(L, d)
+    out = torch.zeros(B, C, d, lp, dtype=x.dtype, device=x.device)
+    for p_ in range(d):
+        v = x[..., p_::d]
+        out[:, :, p_, :v.shape[-1]] = v
+    return out.reshape(B, C, d * lp)
+
+
+def from_phase_major(xp, d, length):
+    B, C, _ = xp.shape
+    lp = phase_len(length, d)
+    v = xp.reshape(B, C, d, lp)
+    out = torch.empty(B, C, length, dtype=xp.dtype, device=xp.device)
+    for p_ in range(d):
+        n = len(range(p_, length, d))
+        out[..., p_::d] = v[:, :, p_, :n]
+    return out
+
+
+def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0, phase_major=False):
     """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
     d = hip.to_device_struct_array(groups, device)
-    hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation, tile_cfg,
-                                         hip.stream()), "fh_conv_wino_f32")
+    hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
+                                         int(phase_major), tile_cfg, hip.stream()), "fh_conv_wino_f32")
     return d
 
 
@@ -210,10 +241,10 @@ def conv_grouped(groups, batch, cout_pad, n_len, tile_cfg, device, ck=8):
     return d
 
 
-def act1d_grouped(groups, batch, channels, length, device):
+def act1d_grouped(groups, batch, channels, length, device, din=1, dout=1):
     d = hip.to_device_struct_array(groups, device)
-    hip.check(hip.lib().fh_act1d_grouped_f32(d.data_ptr(), len(groups), batch, channels, length, hip.stream()),
-              "fh_act1d_grouped_f32")
+    hip.check(hip.lib().fh_act1d_grouped_pm_f32(d.data_ptr(), len(groups), batch, channels, length, din, dout,
+                                                hip.stream()), "fh_act1d_grouped_pm_f32")
     return d
 
 
@@ -349,7 +380,7 @@ class Vocoder:
             executed[0] += flops
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
-        def wino_step(groups, wpad, length, dil, wcfg, sink=None):
+        def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False):
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
             flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
@@ -357,14 +388,14 @@ class Vocoder:
             # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
             executed[0] += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
                                for g in groups for i in range(g.nseg))
-            (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops, wcfg))
+            (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm)))
 
-        def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None, wcfg=0):
+        def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None, wcfg=0, pm=False):
             """One launch of the same conv position in the nk AMP blocks (one group per block)."""
             if all("u" in e for e in ents):
                 wino_step([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i])], biases[i],
                                            res[i], outs[i], c, wpad, L) for i in range(len(ents))],
-                          wpad, L, dil, wcfg, sink)
+                          wpad, L, dil, wcfg, sink, pm)
             else:
                 groups = []
                 for i, e in enumerate(ents):
@@ -373,10 +404,10 @@ class Vocoder:
                                                   outs[i], c, cpad, L, L, L))
                 conv_step(groups, cpad, L, tcfg, ck, sink)
 
-        def act_step(groups, c, length, sink=None):
+        def act_step(groups, c, length, sink=None, din=1, dout=1):
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
-            (sink if sink is not None else steps).append(("act", d, len(groups), c, length))
+            (sink if sink is not None else steps).append(("act", d, len(groups), c, length, din, dout))
 
         mel_in = torch.empty(B, self.num_mels, N, **f32)
         pre = torch.empty(B, self.c0, N, **f32)
@@ -385,7 +416,10 @@ class Vocoder:
         conv_step([make_conv_group([make_conv_seg(mel_in, self.pre_w, self.num_mels, k7)], self.pre_b, [],
                                     pre, self.c0, self.pre_cpad, N, N, N)], self.pre_cpad, N, self.pre_cfg, self.pre_ck)
         cur = pre
-        max_elems = max(st["c"] * N * math.prod(self.rates[:i + 1]) for i, st in enumerate(self.stages))
+        dils = sorted({d for dl in self.dil for d in dl})
+        # (phase-major intermediates of the dilated convs are padded to d * phase_len >= L floats per row)
+        max_elems = max(st["c"] * max(d * phase_len(N * math.prod(self.rates[:i + 1]), d) for d in dils + [1])
+                        for i, st in enumerate(self.stages))
         nbuf = 2 + 4 * self.nk
         pool = torch.empty(nbuf, B * max_elems, **f32)
         keep.append(pool)
@@ -427,13 +461,18 @@ class Vocoder:
                     else:
                         steps.append(("fork", [chains[j] for j in order]))
                 else:
-                    act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L)
                     blks = [st["blocks"][j] for j in order]
                     d1 = blks[0]["dil"][m]
-                    if all(b_["dil"][m] == d1 for b_ in blks):
+                    same_d = all(b_["dil"][m] == d1 for b_ in blks)
+                    # dilated Winograd conv: the activations on both sides write / read phase-major tensors
+                    pm = _WINO_PM and same_d and d1 > 1 and all("u" in b_["c1"][m] for b_ in blks)
+                    dpm = d1 if pm else 1
+                    act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L,
+                             dout=dpm)
+                    if same_d:
                         res_conv([b_["c1"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], d1,
                                  [T2[j] for j in order], [b_["c1"][m]["b"] for b_ in blks], [[] for _ in blks],
-                                 c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
+                                 c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"], pm=pm)
                     else:               # mixed dilations: one direct launch, per-group tap offsets
                         groups = []
                         for j in order:
@@ -443,7 +482,8 @@ class Vocoder:
                             groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
                                                            blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
                         conv_step(groups, cpad, L, tcfg, st["ck"])
-                    act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L)
+                    act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L,
+                             din=dpm)
                     if not last:
                         res_conv([b_["c2"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], 1,
                                  [Y[j][m % 2] for j in order], [b_["c2"][m]["b"] for b_ in blks],
@@ -509,12 +549,12 @@ class Vocoder:
                 e1.record()
                 timing.append((e0, e1))
         elif s[0] == "wino":
-            _, d, ng, wpad, length, dil, _flops, wcfg = s
+            _, d, ng, wpad, length, dil, _flops, wcfg, pm = s
             timing = self.conv_timing
             if timing is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, B, wpad, length, dil, wcfg, st), "fh_conv_wino_f32")
+            hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, B, wpad, length, dil, pm, wcfg, st), "fh_conv_wino_f32")
             if timing is not None:
                 e1.record()
                 timing.append((e0, e1))
@@ -523,8 +563,8 @@ class Vocoder:
             hip.check(L.fh_mean_f32(a.data_ptr(), b_.data_ptr(), c_.data_ptr() if c_ is not None else None,
                                     out.data_ptr(), n, scale, st), "fh_mean_f32")
         elif s[0] == "act":
-            _, d, ng, c, length = s
-            hip.check(L.fh_act1d_grouped_f32(d.data_ptr(), ng, B, c, length, st), "fh_act1d_grouped_f32")
+            _, d, ng, c, length, din, dout = s
+            hip.check(L.fh_act1d_grouped_pm_f32(d.data_ptr(), ng, B, c, length, din, dout, st), "fh_act1d_grouped_pm_f32")
         else:
             _, x, wav, c, length = s
             hip.check(L.fh_conv_post_tanh_f32(x.data_ptr(), self.post_w.data_ptr(), self.post_b.data_ptr(),

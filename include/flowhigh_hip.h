@@ -126,9 +126,14 @@ typedef struct {
 int fh_sizeof_wino_group(void);
 /* tile_cfg: 0 = 64 co x 512 outputs per block, 1 = 96 co x 256 outputs (cout_pad % fh_wino_tile_m == 0) */
 int fh_wino_tile_m(int tile_cfg);
-/* groups: device array; all groups share cout_pad, len and the dilation. */
+/* Phase-major layout of a [B, C, len] tensor for dilation d: every (batch, channel) row holds its d decimated
+ * phases one after the other, x[b, c, p + d u] at row + p * fh_phase_len(len, d) + u, row pitch
+ * d * fh_phase_len(len, d) floats.  A dilated conv then reads and writes contiguous runs. */
+int fh_phase_len(int len, int dilation);
+/* groups: device array; all groups share cout_pad, len and the dilation.  phase_major != 0: x, res and out of
+ * every group are phase-major for this dilation (see above), else plain [B, C, len]. */
 int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
-                     int dilation, int tile_cfg, void* stream);
+                     int dilation, int phase_major, int tile_cfg, void* stream);
 
 /* out = ((a + b) + c) * scale over n floats (c may be NULL; n % 4 == 0, 16-byte aligned pointers): the
  * `xs += resblock(x); x = xs / num_kernels` of BigVGAN.forward (models/bigvgan/models.py:183-188) for the
@@ -171,6 +176,10 @@ typedef struct {
 int fh_sizeof_act_group(void);
 int fh_act1d_grouped_f32(const fh_act_group* groups, int n_groups, int batch, int channels,
                          int len, void* stream);
+/* Same with phase-major tensors (fh_phase_len below): din / dout = dilation whose phase-major layout x / y
+ * use, 1 = plain [B, C, len].  Used on both sides of a dilated Winograd conv. */
+int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups, int batch, int channels, int len,
+                            int din, int dout, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 MFMA GEMM:  C[M, N] = epilogue( A[M, K] * W[N, K]^T )

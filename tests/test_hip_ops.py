@@ -131,6 +131,23 @@ def test_conv_wino(c, k, d, L, B):
     del keep
 
 
+@pytest.mark.parametrize("c,k,d,L,B", [(64, 11, 3, 1000, 2), (96, 7, 5, 1001, 1), (128, 3, 3, 5000, 1), (64, 7, 5, 23, 2)])
+def test_conv_wino_phase_major(c, k, d, L, B):
+    """Dilated Winograd conv on phase-major tensors (contiguous runs per decimated phase)."""
+    x, w, b = rnd(B, c, L, seed=160), rnd(c, c, k, seed=161, scale=1.0 / (c * k) ** 0.5), rnd(c, seed=162)
+    ref = F.conv1d(x.double(), w.double(), b.double(), dilation=d, padding=(k - 1) // 2 * d).float()
+    wcfg, cpad = V.pick_wino_tile(c)
+    xd = V.to_phase_major(x, d).to(DEV)
+    out = torch.full_like(xd, float("nan"))
+    ud, bd = V.pack_wino_weight(w, cpad).to(DEV), b.to(DEV)
+    g = V.make_wino_group([V.make_wino_seg(xd, ud, c, k)], bd, [], out, c, cpad, L)
+    keep = V.conv_wino([g], B, cpad, L, d, DEV, wcfg, phase_major=True)
+    torch.cuda.synchronize()
+    got = V.from_phase_major(out.cpu(), d, L)
+    assert maxdiff(got, ref) <= 2e-5
+    del keep
+
+
 @pytest.mark.parametrize("c", [64, 96])
 def test_conv_wino_three_segments_fused_average(c):
     L, B = 1203, 2
@@ -166,6 +183,28 @@ def test_conv_post_tanh():
 # ------------------------------------------------------------------------------------------
 # anti-aliased activation
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,din,dout", [(1500, 1, 3), (1500, 3, 1), (2033, 5, 1), (2033, 1, 5), (41, 3, 5), (7, 1, 3)])
+def test_act1d_phase_major(L, din, dout):
+    """Activation1d reading / writing the phase-major layout used around dilated Winograd convs."""
+    B, C = 2, 5
+    filt = synth.kaiser_sinc_filter()
+    x = rnd(B, C, L, seed=170, scale=1.5)
+    al, be = rnd(C, seed=171, scale=0.4), rnd(C, seed=172, scale=0.4)
+    h = {"activation": "snakebeta", "snake_logscale": True}
+    sd = {"a.act.alpha": al, "a.act.beta": be, "a.upsample.filter": filt, "a.downsample.lowpass.filter": filt}
+    ref = ref_cpu.activation1d(sd, "a.", x, h)
+    p = dict(alpha=torch.exp(al).to(DEV), inv_beta=(1.0 / (torch.exp(be) + 1e-9)).to(DEV),
+             up=filt.flatten().tolist(), down=filt.flatten().tolist())
+    xd = (V.to_phase_major(x, din) if din > 1 else x).to(DEV)
+    yd = torch.full((B, C, dout * V.phase_len(L, dout) if dout > 1 else L), float("nan"), device=DEV)
+    keep = V.act1d_grouped([V.make_act_group(xd, yd, p)], B, C, L, DEV, din, dout)
+    torch.cuda.synchronize()
+    got = V.from_phase_major(yd.cpu(), dout, L) if dout > 1 else yd.cpu()
+    assert maxdiff(got, ref) <= 3e-6
+    del keep
+
+
+
 @pytest.mark.parametrize("L", [1, 5, 41, 506, 507, 1500])
 @pytest.mark.parametrize("kind", ["snakebeta_log", "snake_lin"])
 def test_act1d(L, kind):

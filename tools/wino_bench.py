@@ -40,6 +40,15 @@ for c, L in ((768, 5000), (384, 20000), (192, 60000), (96, 120000), (48, 240000)
         dw = hip.to_device_struct_array(gw, DEV)
         st = hip.stream()
         t_d = bench(lambda: hip.check(hip.lib().fh_conv_grouped_f32(dd.data_ptr(), 3, B, cpad, L, tcfg, ck, st)))
-        t_w = bench(lambda: hip.check(hip.lib().fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, wcfg, st)))
+        t_w = bench(lambda: hip.check(hip.lib().fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, 0, wcfg, st)))
+        t_p = float('nan')
+        if d > 1:      # same launch on phase-major tensors (timing only: the buffers are reinterpreted)
+            pl = d * V.phase_len(L, d)
+            xs2 = [torch.randn(B, c, pl, device=DEV) for _ in KS]
+            outs2 = [torch.empty(B, c, pl, device=DEV) for _ in KS]
+            gp = [V.make_wino_group([V.make_wino_seg(xs2[i], ud[i], c, k)], bs[i], [], outs2[i], c, wpad, L)
+                  for i, k in enumerate(KS)]
+            dp = hip.to_device_struct_array(gp, DEV)
+            t_p = bench(lambda: hip.check(hip.lib().fh_conv_wino_f32(dp.data_ptr(), 3, B, wpad, L, d, 1, wcfg, st)))
         fl = 2.0 * c * c * sum(KS) * L * B
-        print(f"{c:5d} {L:7d} {d:2d} {fl/1e9:8.2f} {t_d:10.1f} {fl/t_d/1e6:6.1f} {t_w:9.1f} {fl/t_w/1e6:8.1f} {t_d/t_w:7.2f}")
+        print(f"{c:5d} {L:7d} {d:2d} {fl/1e9:8.2f} {t_d:10.1f} {fl/t_d/1e6:6.1f} {t_w:9.1f} {fl/t_w/1e6:8.1f} {t_d/t_w:7.2f}  pm {t_p:7.1f}")

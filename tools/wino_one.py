@@ -23,5 +23,5 @@ for _ in range(5):
     if which in ("both", "direct"):
         hip.check(hip.lib().fh_conv_grouped_f32(dd.data_ptr(), 3, B, cpad, L, tcfg, ck, st))
     if which in ("both", "wino"):
-        hip.check(hip.lib().fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, wcfg, st))
+        hip.check(hip.lib().fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, 0, wcfg, st))
 torch.cuda.synchronize()

@@ -15,7 +15,7 @@ dw = hip.to_device_struct_array(gw, DEV)
 st = hip.stream()
 lib = hip.lib()
 lib.fh_debug_set_wino_trace.argtypes = [ctypes.c_void_p]
-run = lambda: hip.check(lib.fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, wcfg, st))
+run = lambda: hip.check(lib.fh_conv_wino_f32(dw.data_ptr(), 3, B, wpad, L, d, 0, wcfg, st))
 for _ in range(3): run()
 torch.cuda.synchronize()
 buf = torch.zeros(1 + 4 * 100000, dtype=torch.int64, device=DEV)
