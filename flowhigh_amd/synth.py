@@ -41,6 +41,15 @@ ALT_CFG = dict(SYNTH_CFG, upsample_rates=[8, 6, 5, 2], upsample_kernel_sizes=[16
                resblock_dilation_sizes=[[1, 2, 4], [1, 3, 5]], activation="snake",
                snake_logscale=False)
 
+# AMPBlock2 variant (resblock "2"): channel counts 192 / 96 / 48 / 24 cover both Winograd tiles and the direct
+# kernel; the second dilation differs between the two blocks (mixed-dilation launch, unfused closing)
+ALT2_CFG = dict(SYNTH_CFG, resblock="2", upsample_rates=[8, 6, 5, 2], upsample_kernel_sizes=[16, 12, 11, 4],
+                upsample_initial_channel=384, resblock_kernel_sizes=[3, 7],
+                resblock_dilation_sizes=[[1, 3], [1, 5]])
+# ... and with 3 blocks sharing the dilations (fused closing conv with dilation 3)
+ALT3_CFG = dict(ALT2_CFG, resblock_kernel_sizes=[3, 5, 7],
+                resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]])
+
 VOC = "flowhigh.audio_enc_dec.vocoder."
 FH = "flowhigh."
 
@@ -124,6 +133,11 @@ def make_vocoder_state_dict(cfg, seed=0, prefix=VOC):
         for j in range(nk):
             r = i * nk + j
             ks = cfg["resblock_kernel_sizes"][j]
+            if str(cfg["resblock"]) == "2":       # AMPBlock2: one conv + one activation per dilation
+                for m in range(len(cfg["resblock_dilation_sizes"][j])):
+                    conv(f"resblocks.{r}.convs.{m}", chans[i], chans[i], ks, 0.4)
+                    act(f"resblocks.{r}.activations.{m}.", chans[i])
+                continue
             for m in range(len(cfg["resblock_dilation_sizes"][j])):
                 conv(f"resblocks.{r}.convs1.{m}", chans[i], chans[i], ks, 1.0)
                 conv(f"resblocks.{r}.convs2.{m}", chans[i], chans[i], ks, 0.2)

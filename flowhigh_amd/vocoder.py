@@ -255,8 +255,9 @@ class Vocoder:
         if isinstance(cfg, (str, bytes)) or hasattr(cfg, "read_text"):
             cfg = json.loads(open(cfg).read())
         self.cfg = dict(cfg)
-        if str(cfg["resblock"]) != "1":
-            raise NotImplementedError("only resblock '1' (AMPBlock1) is implemented")
+        self.resblock = str(cfg["resblock"])
+        if self.resblock not in ("1", "2"):
+            raise NotImplementedError(f"resblock {cfg['resblock']!r}")
         if cfg["activation"] not in ("snake", "snakebeta"):
             raise NotImplementedError(cfg["activation"])
         self.device = torch.device(device)
@@ -272,6 +273,8 @@ class Vocoder:
         self.nm = len(self.dil[0])
         if any(len(d) != self.nm for d in self.dil):
             raise NotImplementedError("ragged dilation lists")
+        if self.resblock == "2" and self.nk not in (2, 3):
+            raise NotImplementedError("AMPBlock2 with other than 2 or 3 kernel sizes")
         self.hop = math.prod(self.rates)
         self.chans = [self.c0 // (2 ** (i + 1)) for i in range(len(self.rates))]
         for c in [self.num_mels, self.c0] + self.chans:
@@ -318,6 +321,19 @@ class Vocoder:
             for j in range(self.nk):
                 r = i * self.nk + j
                 blk = dict(k=self.ks[j], dil=self.dil[j], c1=[], c2=[], acts=[])
+                if self.resblock == "2":        # AMPBlock2 (models.py:81-121): x = conv_l(act_l(x)) + x per dilation
+                    for m in range(self.nm):
+                        d = self.dil[j][m]
+                        ent = dict(b=g(f"resblocks.{r}.convs.{m}.bias").to(dev))
+                        w = g(f"resblocks.{r}.convs.{m}.weight")
+                        if use_wino(c, d) and all(self.dil[jj][m] == d for jj in range(self.nk)):
+                            ent["u"] = pack_wino_weight(w, st["wpad"]).to(dev)
+                        else:
+                            ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
+                        blk["c1"].append(ent)
+                        blk["acts"].append(act_params(f"resblocks.{r}.activations.{m}."))
+                    st["blocks"].append(blk)
+                    continue
                 for m in range(self.nm):
                     for tag, lst, d in (("convs1", blk["c1"], self.dil[j][m]), ("convs2", blk["c2"], 1)):
                         w = g(f"resblocks.{r}.{tag}.{m}.weight")
@@ -333,7 +349,8 @@ class Vocoder:
                     blk["acts"].append(act_params(f"resblocks.{r}.activations.{a}."))
                 st["blocks"].append(blk)
             # fused last conv2: pre-summed bias
-            st["last_bias"] = sum(b["c2"][self.nm - 1]["b"] for b in st["blocks"]).contiguous()
+            st["last_bias"] = sum(b["c2" if self.resblock == "1" else "c1"][self.nm - 1]["b"]
+                                  for b in st["blocks"]).contiguous()
             self.stages.append(st)
         self.post_act = act_params("activation_post.")
         self.post_w = g("conv_post.weight")[0].contiguous().to(dev)      # [c_last, 7]
@@ -439,8 +456,33 @@ class Vocoder:
             T2 = [view(3 + 4 * j) for j in range(self.nk)]
             Y = [[view(4 + 4 * j), view(5 + 4 * j)] for j in range(self.nk)]
             xin = [X] * self.nk
-            chains = [[] for _ in range(self.nk)] if self.chain_streams else None
-            for m in range(self.nm):
+            chains = [[] for _ in range(self.nk)] if self.chain_streams and self.resblock == "1" else None
+            for m in range(self.nm if self.resblock == "2" else 0):
+                # AMPBlock2: one activation + one conv (+ x) per dilation; the last one closes the stage
+                blks = [st["blocks"][j] for j in order]
+                ents = [b_["c1"][m] for b_ in blks]
+                ks = [b_["k"] for b_ in blks]
+                ds = [b_["dil"][m] for b_ in blks]
+                act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][m]) for j in order], c, L)
+                if m < self.nm - 1 or not all("w" in e for e in ents):
+                    outs = [Y[j][m % 2] for j in order]
+                    if all(d == ds[0] for d in ds):
+                        res_conv(ents, [T1[j] for j in order], ks, ds[0], outs, [e["b"] for e in ents],
+                                 [[xin[j]] for j in order], c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
+                    else:               # mixed dilations: direct kernel, per-group tap offsets
+                        conv_step([make_conv_group([make_conv_seg(T1[j], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])],
+                                                   e["b"], [xin[j]], Y[j][m % 2], c, cpad, L, L, L)
+                                   for j, e, k, d in zip(order, ents, ks, ds)], cpad, L, tcfg, st["ck"])
+                    xin = [Y[j][m % 2] for j in range(self.nk)]
+                    if m == self.nm - 1:            # xs / num_kernels, block order = the reference's xs += order
+                        steps.append(("mean", xin[0], xin[1], xin[2] if self.nk == 3 else None, S, B * c * L,
+                                      1.0 / self.nk))
+                else:                   # direct kernel: the nk closing convs as K segments of one group, / nk in the epilogue
+                    segs = [make_conv_seg(T1[j], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])
+                            for j, e, k, d in zip(order, ents, ks, ds)]
+                    conv_step([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L,
+                                                scale=1.0 / self.nk)], cpad, L, tcfg, st["ck"])
+            for m in range(self.nm if self.resblock == "1" else 0):
                 last = m == self.nm - 1
                 if chains is not None:
                     # one launch sequence per AMP block, each on its own stream (run()): the three

@@ -32,6 +32,8 @@ CASES = {
     "tiny_adaptive_i16": (synth.TINY_CFG, 2, 0.15, 24000, "euler", 2, "independent_cfm_adaptive", 1e-4, True),
     "tiny_ragged_16k": (synth.TINY_CFG, 3, 0.2017, 16000, "midpoint", 1, "basic_cfm", 0.0, False),
     "tiny_mix": (synth.TINY_CFG, 4, 0.18, 12000, "euler", 1, "independent_cfm_mix", 0.05, False),
+    "amp2_euler": (synth.ALT2_CFG, 5, 0.2, 12000, "euler", 1, "basic_cfm", 0.0, False),
+    "amp2_three_blocks": (synth.ALT3_CFG, 6, 0.16, 16000, "midpoint", 1, "basic_cfm", 0.0, False),
 }
 
 
@@ -122,6 +124,9 @@ def run_ops():
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     with torch.no_grad():
+        only = sys.argv[1:]                      # optional: names of the cases to (re)generate
         for name, args in CASES.items():
-            run_case(name, *args)
-        run_ops()
+            if not only or name in only:
+                run_case(name, *args)
+        if not only:
+            run_ops()

@@ -275,9 +275,19 @@ def amp_block1(sd, prefix, x, h, ksize, dilations):
     return x
 
 
+def amp_block2(sd, prefix, x, h, ksize, dilations):
+    """models.py:115-121"""
+    for m, d in enumerate(dilations):
+        xt = activation1d(sd, f"{prefix}activations.{m}.", x, h)
+        xt = F.conv1d(xt, sd[f"{prefix}convs.{m}.weight"], sd[f"{prefix}convs.{m}.bias"],
+                      dilation=d, padding=(ksize * d - d) // 2)
+        x = xt + x
+    return x
+
+
 def bigvgan_forward(sd, h, mel, return_stages=False):
-    """mel [B,256,N] -> [B,1,480N].  h = vocoder JSON dict (resblock '1' only)."""
-    assert str(h["resblock"]) == "1", "AMPBlock2 not covered by the oracle"
+    """mel [B,256,N] -> [B,1,480N].  h = vocoder JSON dict."""
+    amp_block = amp_block1 if str(h["resblock"]) == "1" else amp_block2
     stages = {}
     x = F.conv1d(mel, sd[VOC + "conv_pre.weight"], sd[VOC + "conv_pre.bias"], padding=3)
     stages["conv_pre"] = x
@@ -288,7 +298,7 @@ def bigvgan_forward(sd, h, mel, return_stages=False):
         stages[f"up{i}"] = x
         xs = None
         for j in range(nk):
-            y = amp_block1(sd, f"{VOC}resblocks.{i * nk + j}.", x, h,
+            y = amp_block(sd, f"{VOC}resblocks.{i * nk + j}.", x, h,
                            h["resblock_kernel_sizes"][j], h["resblock_dilation_sizes"][j])
             xs = y if xs is None else xs + y
         x = xs / nk

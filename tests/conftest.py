@@ -38,4 +38,5 @@ def load_golden(name):
     return d
 
 
-E2E_CASES = ["tiny_euler", "alt_midpoint", "tiny_adaptive_i16", "tiny_ragged_16k", "tiny_mix"]
+E2E_CASES = ["tiny_euler", "alt_midpoint", "tiny_adaptive_i16", "tiny_ragged_16k", "tiny_mix",
+             "amp2_euler", "amp2_three_blocks"]         # AMPBlock2 vocoders (resblock "2")
