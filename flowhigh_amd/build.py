@@ -8,7 +8,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libflowhigh_hip.so"
 SOURCES = ["api_common.hip", "conv_mfma.hip", "conv_wino.hip", "act1d.hip", "gemm_mfma.hip", "flow_ops.hip",
-           "attention.hip", "frontend.hip"]
+           "attention.hip", "frontend.hip", "fft.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

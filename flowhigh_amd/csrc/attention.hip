@@ -23,9 +23,13 @@ namespace {
 constexpr int KP = 68;   // K tile pitch (floats): b128 reads conflict free
 constexpr int VP = 64;
 
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
-                                                        float* __restrict__ out, int n, int heads,
-                                                        float scale) {
+// WAVES = 4: 128 queries per block; WAVES = 2: 64 (twice the blocks when the grid would not fill the chip).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __restrict__ qkv,
+                                                               float* __restrict__ out, int n, int heads,
+                                                               float scale) {
+  constexpr int NT = 64 * WAVES;           // threads
+  constexpr int NLD = 512 / NT;            // float4 of K (and of V) staged per thread and tile
   __shared__ __attribute__((aligned(16))) float Ks[32 * KP];
   __shared__ __attribute__((aligned(16))) float Vs[32 * VP];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const int inner = heads * 64;
   const size_t ld = (size_t)3 * inner;
   const float* base = qkv + (size_t)b * n * ld + h * 64;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * WAVES) + wave * 32;
   const int qi = q0 + l31;
 
   // Q fragments: qf[q'][e] = Q[qi][8 q' + 4 lh + e]
@@ -51,22 +55,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
 
-  for (int k0 = 0; k0 < n; k0 += 32) {
-    __syncthreads();
-    // stage K and V tiles: 512 float4 each, 2 per thread
+  // K / V tiles (512 float4 each) go global -> registers one tile ahead, registers -> LDS at the top of
+  // their own iteration: the loads of tile i + 1 are in flight while tile i is on the matrix cores
+  f32x4 kreg[NLD], vreg[NLD];
+  auto load_kv = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int f = tid + 256 * i, key = f >> 4, c4 = f & 15;
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + NT * i, key = f >> 4, c4 = f & 15;
       f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
       if (k0 + key < n) {
         const float* rowp = base + (size_t)(k0 + key) * ld + 4 * c4;
         kv = *reinterpret_cast<const f32x4*>(rowp + inner);
         vv = *reinterpret_cast<const f32x4*>(rowp + 2 * inner);
       }
-      *reinterpret_cast<f32x4*>(Ks + key * KP + 4 * c4) = kv;
-      *reinterpret_cast<f32x4*>(Vs + key * VP + 4 * c4) = vv;
+      kreg[i] = kv;
+      vreg[i] = vv;
+    }
+  };
+  load_kv(0);
+  for (int k0 = 0; k0 < n; k0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + NT * i, key = f >> 4, c4 = f & 15;
+      *reinterpret_cast<f32x4*>(Ks + key * KP + 4 * c4) = kreg[i];
+      *reinterpret_cast<f32x4*>(Vs + key * VP + 4 * c4) = vreg[i];
     }
     __syncthreads();
+    if (k0 + 32 < n) load_kv(k0 + 32);
 
     // S^T tile
     f32x16 s;
@@ -135,8 +151,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 extern "C" int fh_attention_f32(const float* qkv, float* out, int batch, int n, int heads,
                                 float scale, void* stream) {
   FH_CHECK_ARG(qkv && out && batch > 0 && n > 0 && heads > 0, "fh_attention_f32: bad args");
-  dim3 grid(fh_cdiv(n, 128), heads, batch);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
+  if ((long long)fh_cdiv(n, 128) * heads * batch >= 512) {
+    dim3 grid(fh_cdiv(n, 128), heads, batch);
+    hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
+  } else {
+    dim3 grid(fh_cdiv(n, 64), heads, batch);
+    hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(128), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
+  }
   FH_CHECK_LAUNCH("fh_attention_f32");
   return FH_OK;
 }

@@ -4,14 +4,20 @@
   PostProcessor   PostProcessing.post_processing   /root/reference/src/flowhigh/postprocessing.py:5-41
   Resampler       scipy.signal.resample_poly + peak normalise   flowhighsr.py:68-69
 
-STFT / iSTFT are DFT-by-GEMM on the fp32 matrix cores (8.4 MFLOP per frame, negligible next to the
-vocoder) with the magnitude, the mel projection's log and the window / overlap-add fused around
-them; the reference's python cutoff loop (one host sync per bin on GPU) is a device scan.
+STFT / iSTFT are 2048-point FFTs in LDS (csrc/fft.hip; FH_FFT=0 selects the older DFT-by-GEMM on the
+matrix cores, 8.4 MFLOP per frame) with the magnitude, the mel projection's log and the window /
+overlap-add fused around them; the reference's python cutoff loop (one host sync per bin on GPU) is a
+device scan.
 """
+import os
+
 import torch
 
 from . import hip, tables
 from .tables import HOP, MAG_WIDTH, N_FFT, N_MELS, P_WIDTH
+
+
+_USE_FFT = os.environ.get("FH_FFT", "1") != "0"
 
 
 class _Const:
@@ -26,7 +32,8 @@ class _Const:
                 hann=tables.hann_window().to(device),
                 w_fwd=tables.dft_forward_weight().to(device),
                 w_inv=tables.dft_inverse_weight().to(device),
-                w_mel=tables.mel_gemm_weight().to(device))
+                w_mel=tables.mel_gemm_weight().to(device),
+                tw=tables.fft_twiddles().to(device))
         return cls._cache[key]
 
 
@@ -51,7 +58,11 @@ class LogMel:
         audio = audio.contiguous()
         hip.check(L.fh_frame_f32(audio.data_ptr(), self.c["hann"].data_ptr(), frames.data_ptr(), B, T, N,
                                  N_FFT, HOP, (N_FFT - HOP) // 2, 0, st), "fh_frame_f32")
-        hip.gemm(frames, self.c["w_fwd"], mag, B * N, P_WIDTH, N_FFT, epilogue=hip.EPI_MAG)
+        if _USE_FFT:
+            hip.check(L.fh_rfft2048_f32(frames.data_ptr(), self.c["tw"].data_ptr(), mag.data_ptr(), B * N, 1, st),
+                      "fh_rfft2048_f32")
+        else:
+            hip.gemm(frames, self.c["w_fwd"], mag, B * N, P_WIDTH, N_FFT, epilogue=hip.EPI_MAG)
         mel = torch.empty(B * N, N_MELS, dtype=torch.float32, device=self.device)
         hip.gemm(mag, self.c["w_mel"], mel, B * N, N_MELS, MAG_WIDTH, epilogue=hip.EPI_LOGCLAMP)
         return mel
@@ -82,12 +93,20 @@ class PostProcessor:
         for sig, n, spec in ((pred, Tp, w["sp"]), (src, T, w["ss"])):
             hip.check(L.fh_frame_f32(sig.data_ptr(), hann, w["frames"].data_ptr(), B, n, F, N_FFT, HOP,
                                      N_FFT // 2, 1, st), "fh_frame_f32")
-            hip.gemm(w["frames"], self.c["w_fwd"], spec, B * F, P_WIDTH, N_FFT)
+            if _USE_FFT:
+                hip.check(L.fh_rfft2048_f32(w["frames"].data_ptr(), self.c["tw"].data_ptr(), spec.data_ptr(), B * F,
+                                            0, st), "fh_rfft2048_f32")
+            else:
+                hip.gemm(w["frames"], self.c["w_fwd"], spec, B * F, P_WIDTH, N_FFT)
         hip.check(L.fh_spec_energy_f32(w["ss"].data_ptr(), w["energy"].data_ptr(), B, F, st), "fh_spec_energy_f32")
         hip.check(L.fh_cutoff_index_f32(w["energy"].data_ptr(), w["cr"].data_ptr(), B, 1025, 0.99, st), "fh_cutoff_index_f32")
         hip.check(L.fh_spec_splice_f32(w["sp"].data_ptr(), w["ss"].data_ptr(), w["cr"].data_ptr(),
                                        w["sp"].data_ptr(), B, F, st), "fh_spec_splice_f32")
-        hip.gemm(w["sp"], self.c["w_inv"], w["frames"], B * F, N_FFT, P_WIDTH)
+        if _USE_FFT:
+            hip.check(L.fh_irfft2048_f32(w["sp"].data_ptr(), self.c["tw"].data_ptr(), w["frames"].data_ptr(), B * F, st),
+                      "fh_irfft2048_f32")
+        else:
+            hip.gemm(w["sp"], self.c["w_inv"], w["frames"], B * F, N_FFT, P_WIDTH)
         out = torch.empty(B, length, dtype=torch.float32, device=self.device)
         w["peak"].zero_()
         hip.check(L.fh_istft_ola_f32(w["frames"].data_ptr(), hann, out.data_ptr(), w["peak"].data_ptr(), B, F,

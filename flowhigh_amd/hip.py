@@ -77,6 +77,8 @@ _SIGS = {
     "fh_rmsnorm_f32": [_P, _P, _P, _P, _I, _I, _P],
     "fh_qknorm_rope_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "fh_attention_f32": [_P, _P, _I, _I, _I, _F, _P],
+    "fh_rfft2048_f32": [_P, _P, _P, _I, _I, _P],
+    "fh_irfft2048_f32": [_P, _P, _P, _I, _P],
     "fh_frame_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fh_spec_energy_f32": [_P, _P, _I, _I, _P],
     "fh_cutoff_index_f32": [_P, _P, _I, _I, _F, _P],

@@ -109,6 +109,14 @@ def dft_inverse_weight():
     return _pad_rows(torch.from_numpy(w))
 
 
+@lru_cache(maxsize=None)
+def fft_twiddles():
+    """[1024, 2] float64: (cos, -sin)(2 pi k / 2048) (fh_rfft2048_f32 / fh_irfft2048_f32)."""
+    k = np.arange(N_FFT // 2, dtype=np.float64)
+    ang = 2.0 * np.pi * k / N_FFT
+    return torch.from_numpy(np.stack([np.cos(ang), -np.sin(ang)], axis=1)).contiguous()
+
+
 def rotary_tables(inv_freq, n):
     """cos, sin [n, 32] float32 from the checkpoint's fp32 inv_freq (pos_emb.py:44-51)."""
     inv_freq = inv_freq.detach().float().cpu()

@@ -256,6 +256,16 @@ int fh_spec_energy_f32(const float* spec, float* energy, int batch, int n_frames
 int fh_cutoff_index_f32(const float* energy, int32_t* cr, int batch, int nbins, float thr,
                         void* stream);
 
+/* 2048-point real FFT of framed audio and its inverse (the DFT halves of torch.stft / torch.istft,
+ * models/melvoco.py:56-86, postprocessing.py:5-9,39): frames [rows, 2048] ->
+ *   mode 0: packed complex spectrum [rows, 2112] (33 blocks of 32 Re + 32 Im, bins >= 1025 zero),
+ *   mode 1: magnitudes sqrt(re^2 + im^2 + 1e-9) [rows, 1056] (melvoco.py:81, the input of the mel projection);
+ * fh_irfft2048_f32: packed spectrum -> frames (C2R, imaginary parts of DC / Nyquist ignored, 1/N).
+ * The butterflies run in float64 (see csrc/fft.hip).
+ * twiddles: [1024, 2] DOUBLE = (cos, -sin)(2 pi k / 2048), flowhigh_amd/tables.py: fft_twiddles. */
+int fh_rfft2048_f32(const float* frames, const double* twiddles, float* out, int rows, int mode, void* stream);
+int fh_irfft2048_f32(const float* spec, const double* twiddles, float* frames, int rows, void* stream);
+
 /* Sampler options of cfm_superresolution.py: mel-domain cutoff energy (:134-159, input to
  * fh_cutoff_index_f32 with thr 0.9995), low-band replacement mel_replace_ops (:146-152), and the
  * independent_cfm_* prior cond * std_1 + eps * std_2 (:226-236).  mel tensors are [B, n, d]. */

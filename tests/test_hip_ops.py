@@ -180,6 +180,38 @@ def test_conv_post_tanh():
     assert maxdiff(out, ref) <= 2e-6
 
 
+def test_rfft_irfft_2048():
+    """LDS FFT against torch.fft (float64): packed spectrum, magnitudes, and the C2R inverse."""
+    from flowhigh_amd import tables
+    R = 37
+    x = rnd(R, 2048, seed=180)
+    ref = torch.fft.rfft(x.double(), dim=-1)
+    tw = tables.fft_twiddles().to(DEV)
+    xd = x.to(DEV)
+    spec = torch.full((R, 2112), float("nan"), device=DEV)
+    mag = torch.full((R, 1056), float("nan"), device=DEV)
+    L, st = hip.lib(), hip.stream()
+    hip.check(L.fh_rfft2048_f32(xd.data_ptr(), tw.data_ptr(), spec.data_ptr(), R, 0, st))
+    hip.check(L.fh_rfft2048_f32(xd.data_ptr(), tw.data_ptr(), mag.data_ptr(), R, 1, st))
+    torch.cuda.synchronize()
+    sp = spec.cpu().view(R, 33, 2, 32)
+    re, im = sp[:, :, 0].reshape(R, 1056), sp[:, :, 1].reshape(R, 1056)
+    scale = float(ref.abs().max())
+    assert (re[:, :1025].double() - ref.real).abs().max().item() <= 2e-6 * scale
+    assert (im[:, :1025].double() - ref.imag).abs().max().item() <= 2e-6 * scale
+    assert float(re[:, 1025:].abs().max()) == 0.0 and float(im[:, 1025:].abs().max()) == 0.0
+    assert (mag.cpu()[:, :1025].double() - torch.sqrt(ref.abs() ** 2 + 1e-9)).abs().max().item() <= 2e-6 * scale
+    assert float(mag.cpu()[:, 1025:].abs().max()) == 0.0
+    # inverse of a spectrum with junk in the ignored imaginary parts (DC, Nyquist)
+    spj = spec.clone().view(R, 33, 2, 32)
+    spj[:, 0, 1, 0] = 3.0
+    spj[:, 32, 1, 0] = -2.0
+    back = torch.full((R, 2048), float("nan"), device=DEV)
+    hip.check(L.fh_irfft2048_f32(spj.data_ptr(), tw.data_ptr(), back.data_ptr(), R, st))
+    torch.cuda.synchronize()
+    assert maxdiff(back, x) <= 5e-6
+
+
 # ------------------------------------------------------------------------------------------
 # anti-aliased activation
 # ------------------------------------------------------------------------------------------
