@@ -49,7 +49,9 @@ constexpr int W_RUN = 8;             // n-blocks of a panel that run together on
 
 // Wave tile = (32 MT) co x (32 NT) tiles; block tile = (32 MT) co x (64 NT) tiles (256 NT outputs).
 //   <2, 2>: 64 x 512 outputs  (C % 64 == 0)        <3, 1>: 96 x 256 outputs  (C = 96)
-template <int MT, int NT>
+// SUBS = 16-channel chunks per LDS slab buffer: with 2 the block synchronises once per 32 input channels
+// (needs cin % 32 == 0 in every segment; 147 KB of LDS for the <2, 2> tile).
+template <int MT, int NT, int SUBS = 1>
 struct WCfg {
   static constexpr int BM = 32 * MT;                    // output channels per block
   static constexpr int BT = 64 * NT;                    // F(4,3) tiles per block
@@ -58,7 +60,7 @@ struct WCfg {
   // two tile columns of a wave are fetched by one ds_read2st64_b64
   static constexpr int RP2 = NT == 2 ? 1152 : 8 * P;
   static constexpr int XPT = (4 * BT + 16 + 47) / 48;   // slab samples per thread (48 threads per row)
-  static constexpr int SLAB = (W_CK / 2) * RP2;         // floats per slab buffer
+  static constexpr int SLAB = SUBS * (W_CK / 2) * RP2;  // floats per slab buffer
   static constexpr int EPI = 12 * 32 * W_EP;            // epilogue exchange, floats
   static constexpr int LDS_FLOATS = 2 * SLAB > EPI ? 2 * SLAB : EPI;
   static_assert(RP2 >= 8 * P, "planes overlap");
@@ -87,12 +89,13 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
   return w;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int SUBS>
 __global__ __attribute__((amdgpu_flat_work_group_size(W_THREADS, W_THREADS), amdgpu_waves_per_eu(3, 3)))
 void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles,
                       int n_tiles, int run_len, int dil, int pm) {
-  using Cfg = WCfg<MT, NT>;
+  using Cfg = WCfg<MT, NT, SUBS>;
   constexpr int W_BM = Cfg::BM, W_BT = Cfg::BT, W_P = Cfg::P, W_RP2 = Cfg::RP2, W_XPT = Cfg::XPT, W_SLAB = Cfg::SLAB;
+  constexpr int W_SUB = (W_CK / 2) * W_RP2;          // floats of one 16-channel chunk inside a slab buffer
   extern __shared__ __attribute__((aligned(16))) float lds[];      // Cfg::LDS_FLOATS
   unsigned long long* const trace = g_wino_trace;
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -171,8 +174,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       }
     }
   };
-  auto store_x = [&](int buf) {
-    float* dst = lds + buf * W_SLAB + lds_st;
+  auto store_x = [&](int buf, int sub) {
+    float* dst = lds + buf * W_SLAB + sub * W_SUB + lds_st;
 #pragma unroll
     for (int i = 0; i < W_XPT; ++i) dst[24 * i] = __uint_as_float(xreg[i]);
   };
@@ -207,11 +210,14 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 
   // ---- prologue -------------------------------------------------------------------------------
   WSeg S0 = load_wseg(&G->seg[0]);
-  load_x(S0, 0, true);
   load_a_half(0, S0, 0, 0, true);
   load_a_half(1, S0, 0, 0, true);
   int xbuf = 0;
-  store_x(0);
+#pragma unroll
+  for (int sub = 0; sub < SUBS; ++sub) {
+    load_x(S0, sub, true);
+    store_x(0, sub);
+  }
   __syncthreads();
 
   f32x2 c0 = {bc0, bc0}, c1 = {bc1, bc1}, c2 = {bc2, bc2}, c3 = {bc3, bc3};
@@ -229,7 +235,13 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       const bool has_next = !last_chunk || more_seg;
       const WSeg& Sx = last_chunk ? Sn : S;              // owner of the next chunk
       const int cx = last_chunk ? 0 : c + 1;
-      const float* xsb = lds + xbuf * W_SLAB + lh * 4 * W_RP2 + (th * 32 + l31) * 2;
+      // the slab rows this chunk occupies are refilled (in the other buffer) by the chunk SUBS ahead
+      const int sub = c % SUBS;
+      const bool wrap = SUBS == 1 ? last_chunk : c + SUBS >= nch;
+      const bool has_slab = SUBS == 1 ? has_next : (!wrap || more_seg);
+      const WSeg& Ss = SUBS == 1 ? Sx : (wrap ? Sn : S);
+      const int cs = SUBS == 1 ? cx : (wrap ? c + SUBS - nch : c + SUBS);
+      const float* xsb = lds + xbuf * W_SLAB + sub * W_SUB + lh * 4 * W_RP2 + (th * 32 + l31) * 2;
       f32x2 xr[2][4][NT];                                // [slot][sample][column] = (k-step 2 kp, 2 kp + 1)
       auto fetch = [&](int slot, int p) {
         const int j0 = 3 * (p >> 2), kp = p & 3;
@@ -247,10 +259,10 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
         const int g = p >> 2, kp = p & 3, h = kp >> 1;
 #if !(defined(WINO_ABL) && (WINO_ABL & 8))       // timing experiment: slab of the first chunk only
         if (p == 0) {
-          load_x(Sx, cx, has_next);                       // stored in the last tap group of this chunk
+          load_x(Ss, cs, has_slab);                       // stored in the last tap group of this chunk
           if (th == 0) prefetch_a(Sx, cx, has_next);
         }
-        if (GC > 1 && p == 4 * (GC - 1) && has_next) store_x(xbuf ^ 1);
+        if (GC > 1 && p == 4 * (GC - 1) && has_slab) store_x(xbuf ^ 1, sub);
 #endif
         if (p + 1 < 4 * GC) fetch((p + 1) & 1, p + 1);
         f32x2 bf[NT];                              // [column] = B values of k-steps 2 kp, 2 kp + 1
@@ -292,8 +304,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #endif
       }
 #if !(defined(WINO_ABL) && (WINO_ABL & 8))
-      if (has_next) {
-        if (GC == 1) store_x(xbuf ^ 1);
+      if (GC == 1 && has_slab) store_x(xbuf ^ 1, sub);
+      if (has_next && sub == SUBS - 1) {                 // end of a slab: one barrier per SUBS chunks
         __syncthreads();
         xbuf ^= 1;
       }
@@ -448,10 +460,10 @@ extern "C" int fh_sizeof_wino_group(void) { return (int)sizeof(fh_wino_group); }
 
 namespace {
 
-template <int MT, int NT>
+template <int MT, int NT, int SUBS>
 int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
                 int phase_major, hipStream_t stream) {
-  using Cfg = WCfg<MT, NT>;
+  using Cfg = WCfg<MT, NT, SUBS>;
   FH_CHECK_ARG(cout_pad > 0 && cout_pad % Cfg::BM == 0, "fh_conv_wino_f32: cout_pad %d not a multiple of %d", cout_pad, Cfg::BM);
   const int co_tiles = cout_pad / Cfg::BM;
   const int n_tiles = fh_cdiv(fh_cdiv(len, dilation), 4 * Cfg::BT) * dilation;
@@ -462,7 +474,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino_f32: grid too large");
   static bool lds_opt_in = false;      // > 64 KB of dynamic LDS needs the attribute once per process
   if (!lds_opt_in) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<MT, NT, SUBS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        Cfg::LDS_FLOATS * 4);
     if (e != hipSuccess) {
       fh_set_error("fh_conv_wino_f32: cannot reserve %d bytes of LDS: %s", Cfg::LDS_FLOATS * 4, hipGetErrorString(e));
@@ -470,7 +482,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
     }
     lds_opt_in = true;
   }
-  hipLaunchKernelGGL((conv_wino_kernel<MT, NT>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
+  hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
                      stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major);
   FH_CHECK_LAUNCH("fh_conv_wino_f32");
   return FH_OK;
@@ -478,7 +490,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
 
 }  // namespace
 
-extern "C" int fh_wino_tile_m(int tile_cfg) { return tile_cfg == 0 ? 64 : tile_cfg == 1 ? 96 : -1; }
+extern "C" int fh_wino_tile_m(int tile_cfg) { return (tile_cfg & ~3) ? -1 : (tile_cfg & 1) ? 96 : 64; }
 
 extern "C" int fh_phase_len(int len, int dilation) { return ((len + dilation - 1) / dilation + 3) & ~3; }
 
@@ -489,8 +501,10 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
   // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cin * len * 4 < 2^31
   // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
   switch (tile_cfg) {
-    case 0: return launch_wino<2, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
-    case 1: return launch_wino<3, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 0: return launch_wino<2, 2, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 1: return launch_wino<3, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 2: return launch_wino<2, 2, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 3: return launch_wino<3, 1, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
   }
   fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
   return FH_E_ARG;

@@ -153,10 +153,13 @@ WINO_BM = 64
 
 
 def pick_wino_tile(c):
-    """(tile_cfg, cout_pad) of the Winograd kernel: 96-row tiles where they divide c and 64-row tiles do not."""
+    """(tile_cfg, cout_pad) of the Winograd kernel: 96-row tiles where they divide c and 64-row tiles do not;
+    + 2 = 32-channel LDS slabs (half the block barriers; FH_WINO_SLAB32=1, measured 0 %: the per-chunk cost is
+    the slab's load / store instructions, not the barrier)."""
+    wide = 2 if c % 32 == 0 and os.environ.get("FH_WINO_SLAB32", "0") == "1" else 0
     if c % 64 and c % 96 == 0:
-        return 1, c
-    return 0, -(-c // WINO_BM) * WINO_BM
+        return 1 + wide, c
+    return 0 + wide, -(-c // WINO_BM) * WINO_BM
 
 
 def pack_wino_weight(w, cout_pad):
@@ -533,7 +536,7 @@ class Vocoder:
                         xin = [Y[j][m % 2] for j in range(self.nk)]
                 if last:
                     ents = [st["blocks"][j]["c2"][m] for j in order]
-                    wbm, wbn = (96, 256) if st["wcfg"] == 1 else (64, 512)
+                    wbm, wbn = (96, 256) if st["wcfg"] & 1 else (64, 512)
                     fused_blocks = B * (st["wpad"] // wbm) * -(-L // wbn)
                     if all("u" in e for e in ents) and fused_blocks < _WINO_FUSE_MIN_BLOCKS and self.nk in (2, 3):
                         # one group = too few blocks for 256 CUs: run the nk convs as groups and average after
