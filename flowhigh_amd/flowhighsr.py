@@ -269,6 +269,37 @@ class FlowHighSR:
         return out
 
     @torch.no_grad()
+    def generate_many(self, clips, sr, target_sampling_rate=48000, timestep=1, *, noise=None, generator=None,
+                      max_batch=64):
+        """Serving-side entry (the gradio caller of app.py:8-26, many requests at once): clips of ANY lengths,
+        int16 or float.  Clips of equal length run as one batch (at most max_batch rows), so every result is
+        what generate() returns for that clip alone; the prior noise is drawn in the order of `clips`, as a loop
+        over generate() would.  noise: optional list of [1, N_i, n_mels] tensors.  Returns a list of [1, T48_i]."""
+        clips = list(clips)
+        if noise is None:
+            noise = []
+            for a in clips:
+                n_in = int(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a).shape[-1])
+                t48 = n_in * target_sampling_rate // sr if (n_in * target_sampling_rate) % sr == 0 \
+                    else -(-n_in * target_sampling_rate // sr)
+                noise.append(self._draw_noise(1, t48 // 480, generator))
+        if len(noise) != len(clips):
+            raise ValueError("one noise tensor per clip")
+        buckets = {}
+        for i, a in enumerate(clips):
+            key = (int(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a).shape[-1]), tuple(noise[i].shape))
+            buckets.setdefault(key, []).append(i)
+        out = [None] * len(clips)
+        for idx in buckets.values():
+            for k in range(0, len(idx), max_batch):
+                part = idx[k:k + max_batch]
+                y = self.generate_batch([clips[i] for i in part], sr, target_sampling_rate, timestep,
+                                        noise=torch.cat([noise[i] for i in part], 0))
+                for r, i in enumerate(part):
+                    out[i] = y[r:r + 1].clone()
+        return out
+
+    @torch.no_grad()
     def generate_from_device(self, x, sr, timestep=1, *, noise):
         """Device-resident variant (no host work, no sync; graph-capturable): x [B, T_in] float32
         low-rate clips already in HBM (|x| <= 1), noise [B, N, n_mels] -> [B, T48].  Same
