@@ -41,6 +41,31 @@ def reference_prior_draw(n_frames, n_mels=256, generator=None):
     return t.normal_(generator=generator)
 
 
+class GraphedGenerate:
+    """One captured generate_from_device call (FlowHighSR.capture)."""
+
+    def __init__(self, model, batch, n_in, sr, timestep):
+        dev = model.device
+        self.x = torch.zeros(batch, n_in, dtype=torch.float32, device=dev)
+        t48 = -(-n_in * 48000 // sr)
+        self.noise = torch.zeros(batch * (t48 // 480), model.flowhigh.n_mels, dtype=torch.float32, device=dev)
+        self.x[:, 0] = 1.0                                  # any non-silent clip: the peak normalisation divides by max |x|
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # warm-up outside the capture: plans, workspaces, LDS opt-in
+            for _ in range(2):
+                model.generate_from_device(self.x, sr, timestep, noise=self.noise)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model.generate_from_device(self.x, sr, timestep, noise=self.noise)
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+
 class FLowHigh:
     """Device-resident weights of the vector-field net + its mel codec (the reference's
     `FLowHigh` with `audio_enc_dec = MelVoco`, models/flow.py:54-142, models/melvoco.py:16-46)."""
@@ -308,6 +333,13 @@ class FlowHighSR:
         kw = dict(std_2=1.) if self.cfm_method == 'independent_cfm_adaptive' else {}
         wav = self.sample(cond=cond, time_steps=timestep, cfm_method=self.cfm_method, noise=noise, **kw).squeeze(1)
         return self.postproc(wav, cond, cond.size(-1))
+
+    @torch.no_grad()
+    def capture(self, batch, n_in, sr, timestep=1):
+        """HIP-graph form of generate_from_device for one input shape: the ~150 launches of a call are recorded once
+        and replayed with a single enqueue (short clips are launch-bound from Python).  Returns a `GraphedGenerate`
+        with static buffers `.x` [batch, n_in] and `.noise` [batch * N, n_mels]; fill them and call `.replay()`."""
+        return GraphedGenerate(self, batch, n_in, sr, timestep)
 
     @torch.no_grad()
     def generate(self, audio, sr: int, target_sampling_rate=48000, timestep=1, *, noise=None, generator=None):

@@ -182,6 +182,21 @@ def test_generate_many_ragged_list_equals_single_calls():
     assert all(torch.equal(x, y) for x, y in zip(a, b))
 
 
+def test_graph_capture_replays_bit_identical():
+    """FlowHighSR.capture: the whole device path as one HIP graph; replays equal the eager call bit for bit."""
+    m, _ = model_for(synth.TINY_CFG, 0, upsampling="hip")
+    n_in = 6000
+    g = m.capture(2, n_in, 12000, 1)
+    for seed in (50, 51):
+        x = torch.from_numpy(np.stack([synth.lowres_clip(seed + i, n_in / 12000, 12000) for i in range(2)])).cuda()
+        noise = torch.cat([synth.prior_noise(seed + i, 50) for i in range(2)], 0).cuda().reshape(100, -1).contiguous()
+        g.x.copy_(x)
+        g.noise.copy_(noise)
+        got = g.replay().clone()
+        ref = m.generate_from_device(x, 12000, 1, noise=noise)
+        assert torch.equal(got, ref)
+
+
 def test_baseline_config5_long_clip_multi_nfe():
     """BASELINE.json configs[4] shape: 30 s clips, 24 -> 48 kHz, time_step = 4 midpoint (8 NFE,
     N = 3000 frames, attention over 3000 keys), B = 2 here: finite, deterministic, peak-normalised."""
