@@ -81,3 +81,61 @@ def test_weight_packing_roundtrip():
     sd = {"a.weight_g": torch.tensor([[[2.0]], [[3.0]]]), "a.weight_v": torch.ones(2, 4, 1), "a.bias": torch.zeros(2)}
     f = V.fold_weight_norm(sd)
     assert torch.allclose(f["a.weight"], torch.tensor([1.0, 1.5]).view(2, 1, 1).expand(2, 4, 1))
+
+
+# ------------------------------------------------------------------------------------------
+# Winograd host side: weight transform / packing and the phase-major layout (no GPU needed)
+# ------------------------------------------------------------------------------------------
+_BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
+                    [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+_AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]],
+                   dtype=torch.float64)
+
+
+@pytest.mark.parametrize("c,k", [(16, 3), (32, 7), (48, 11), (16, 5)])
+def test_pack_wino_weight_is_the_f43_transform_of_the_conv(c, k):
+    """The packed layout [ci/16, G, 6, cout_pad, 16] with B^T / A^T as the kernel applies them (conv_wino.hip)
+    reproduces F.conv1d: y[4t + i] = sum_xi A^T[i, xi] sum_{g, ci} U[g, xi, co, ci] (B^T x[4t + 3g - center ..])[xi]."""
+    import torch.nn.functional as F
+    from flowhigh_amd import vocoder as V
+    g = torch.Generator().manual_seed(k)
+    w = torch.randn(c, c, k, generator=g, dtype=torch.float64)
+    x = torch.randn(1, c, 64, generator=g, dtype=torch.float64)
+    cpad = 64
+    u = V.pack_wino_weight(w, cpad).double()                      # [c/16, G, 6, cpad, 16]
+    ng, center = -(-k // 3), (k - 1) // 2
+    assert tuple(u.shape) == (c // 16, ng, 6, cpad, 16)
+    assert float(u[:, :, :, c:].abs().max()) == 0.0               # padded output rows
+    xp = torch.nn.functional.pad(x, (center, 3 * ng + 8))
+    tiles = 64 // 4
+    m = torch.zeros(6, cpad, tiles, dtype=torch.float64)
+    for gi in range(ng):
+        d = xp[0, :, 3 * gi:].unfold(-1, 6, 4)[:, :tiles]         # [c, tiles, 6]
+        v = torch.einsum("xj,ctj->xct", _BT, d)
+        ug = u[:, gi].permute(1, 2, 0, 3).reshape(6, cpad, c)     # [6, cpad, ci]
+        m += torch.einsum("xoc,xct->xot", ug, v)
+    y = torch.einsum("ix,xot->oti", _AT, m).reshape(cpad, 64)[:c]
+    ref = F.conv1d(x, w, padding=center)[0]
+    # U is stored in float32: the error is the float32 rounding of the transformed weights
+    assert (y - ref).abs().max().item() <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("L,d", [(23, 3), (1000, 5), (17, 1), (4, 5)])
+def test_phase_major_round_trip(L, d):
+    from flowhigh_amd import hip, vocoder as V
+    x = torch.randn(2, 3, L)
+    pm = V.to_phase_major(x, d)
+    lp = V.phase_len(L, d)
+    assert lp == hip.lib().fh_phase_len(L, d) and lp % 4 == 0 and d * lp >= L
+    assert tuple(pm.shape) == (2, 3, d * lp)
+    for t in (0, L // 2, L - 1):
+        assert torch.equal(pm[..., (t % d) * lp + t // d], x[..., t])
+    assert torch.equal(V.from_phase_major(pm, d, L), x)
+
+
+def test_wino_rule_and_tiles():
+    from flowhigh_amd import vocoder as V
+    assert V.pick_wino_tile(768)[0] & 1 == 0 and V.pick_wino_tile(768)[1] == 768
+    assert V.pick_wino_tile(96) == (1, 96)
+    assert V.pick_wino_tile(48)[1] == 64
+    assert V.use_wino(768, 5) and V.use_wino(192, 3) and not V.use_wino(24, 1)
