@@ -36,6 +36,8 @@
 // 2.0x / 1.56x / 1.83x fewer matrix-core cycles).
 #include "fh_common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace {
@@ -89,7 +91,9 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
   return w;
 }
 
-template <int MT, int NT, int SUBS>
+// VL: the slab is fetched with 16-byte loads (4 consecutive samples of 2 channels per thread) and written with
+// 8-byte LDS stores; needs contiguous, 16-byte aligned rows: phase-major tensors, or dilation 1 and len % 4 == 0.
+template <int MT, int NT, int SUBS, bool VL>
 __global__ __attribute__((amdgpu_flat_work_group_size(W_THREADS, W_THREADS), amdgpu_waves_per_eu(3, 3)))
 void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles,
                       int n_tiles, int run_len, int dil, int pm) {
@@ -179,6 +183,43 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #pragma unroll
     for (int i = 0; i < W_XPT; ++i) dst[24 * i] = __uint_as_float(xreg[i]);
   };
+  // VL form: thread (pair = tid / 96, vt = tid % 96) handles absolute quads q0 + vt (+ 96): samples
+  // 4 Q .. 4 Q + 3 of its two channels = two aligned 16-byte loads, then 4 unmasked ds_write_b64 (channel pair)
+  // into the 4 planes.  The slab then starts at the quad boundary below the first sample needed; the B reads
+  // add the 0-3 samples of slack (`sh`) to their sample index.
+  constexpr int W_XQ = W_BT + 5;                       // absolute quads a slab can touch
+  constexpr int W_NITEM = (W_XQ + 95) / 96;
+  const int vp = tid / 96, vt = tid % 96;
+  u32x4 xq[2][2];                                      // [item slot][channel of the pair]
+  auto vl_load = [&](const WSeg& S, int chunk, bool valid, int item, int slot) {
+    const __amdgpu_buffer_rsrc_t r =
+        make_rsrc(uni(S.x + (size_t)b * S.cin * pitch), valid ? (unsigned)(S.cin * pitch) * 4u : 0u);
+    const int ub = tb * (4 * W_BT) - S.center;                           // first decimated index needed (>= -5)
+    const int q0 = (ub - (ub & 3)) >> 2;                                 // floor(ub / 4)
+    const int rowlen = pm ? lp : len;
+    const int q = vt + 96 * item, qa = q0 + q;
+    const bool ok = q < W_XQ && qa >= 0 && 4 * qa < rowlen;              // (outside the row: zero padding)
+    const int e0 = (chunk * W_CK + 2 * vp) * pitch + (pm ? ph * lp : 0) + 4 * qa;
+    xq[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)e0 * 4u : 0x80000000u, 0, 0);
+    xq[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(e0 + pitch) * 4u : 0x80000000u, 0, 0);
+  };
+  auto vl_store = [&](const WSeg& S, int buf, int sub, int item, int slot) {
+    const int ub = tb * (4 * W_BT) - S.center;
+    const int ua = ub - (ub & 3);                                        // decimated index of slab sample 0
+    const int q = vt + 96 * item;
+    const int nvalid = pm ? (len - ph + dil - 1) / dil : len;            // samples of this phase / row
+    if (ua + 4 * W_XQ > nvalid) {                                        // last block of the row: zero past the end
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ua + 4 * q + e >= nvalid) { xq[slot][0][e] = 0u; xq[slot][1][e] = 0u; }
+    }
+    if (q < W_XQ) {
+      float* dst = lds + buf * W_SLAB + sub * W_SUB + vp * W_RP2 + 2 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<f32x2*>(dst + e * W_P * 2) = (f32x2){__uint_as_float(xq[slot][0][e]), __uint_as_float(xq[slot][1][e])};
+    }
+  };
   // A fragments of one step, [mt][half]: half h holds k-steps 4h .. 4h+3
   u32x4 areg[MT][2];
   const int a_lane = (l31 * W_CK + lh * 8) * 4;
@@ -215,8 +256,16 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   int xbuf = 0;
 #pragma unroll
   for (int sub = 0; sub < SUBS; ++sub) {
-    load_x(S0, sub, true);
-    store_x(0, sub);
+    if constexpr (VL) {
+#pragma unroll
+      for (int item = 0; item < W_NITEM; ++item) {
+        vl_load(S0, sub, true, item, 0);
+        vl_store(S0, 0, sub, item, 0);
+      }
+    } else {
+      load_x(S0, sub, true);
+      store_x(0, sub);
+    }
   }
   __syncthreads();
 
@@ -243,8 +292,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       const int cs = SUBS == 1 ? cx : (wrap ? c + SUBS - nch : c + SUBS);
       const float* xsb = lds + xbuf * W_SLAB + sub * W_SUB + lh * 4 * W_RP2 + (th * 32 + l31) * 2;
       f32x2 xr[2][4][NT];                                // [slot][sample][column] = (k-step 2 kp, 2 kp + 1)
+      const int sh = VL ? (tb * (4 * W_BT) - S.center) & 3 : 0;     // slab starts `sh` samples before the first tap
       auto fetch = [&](int slot, int p) {
-        const int j0 = 3 * (p >> 2), kp = p & 3;
+        const int j0 = 3 * (p >> 2) + sh, kp = p & 3;
         const int o[4] = {bo0, bo1, bo2, bo3};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -258,11 +308,27 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       for (int p = 0; p < 4 * GC; ++p) {
         const int g = p >> 2, kp = p & 3, h = kp >> 1;
 #if !(defined(WINO_ABL) && (WINO_ABL & 8))       // timing experiment: slab of the first chunk only
-        if (p == 0) {
-          load_x(Ss, cs, has_slab);                       // stored in the last tap group of this chunk
-          if (th == 0) prefetch_a(Sx, cx, has_next);
+        if constexpr (VL) {
+          // item 0 at the first pair; with two items per thread the first is stored (the other buffer is
+          // free all chunk long) and the second requested a few pairs later, in the same 8 registers
+          // (a one-group chunk is too short for that: both items at once, in two register sets)
+          if (p == 0) {
+            vl_load(Ss, cs, has_slab, 0, 0);
+            if (W_NITEM == 2 && GC == 1) vl_load(Ss, cs, has_slab, 1, 1);
+            if (th == 0) prefetch_a(Sx, cx, has_next);
+          }
+          if (W_NITEM == 2 && GC > 1 && p == 4) {
+            if (has_slab) vl_store(Ss, xbuf ^ 1, sub, 0, 0);
+            vl_load(Ss, cs, has_slab, 1, 0);
+          }
+          if (W_NITEM == 1 && GC > 1 && p == 4 * (GC - 1) && has_slab) vl_store(Ss, xbuf ^ 1, sub, 0, 0);
+        } else {
+          if (p == 0) {
+            load_x(Ss, cs, has_slab);                     // stored in the last tap group of this chunk
+            if (th == 0) prefetch_a(Sx, cx, has_next);
+          }
+          if (GC > 1 && p == 4 * (GC - 1) && has_slab) store_x(xbuf ^ 1, sub);
         }
-        if (GC > 1 && p == 4 * (GC - 1) && has_slab) store_x(xbuf ^ 1, sub);
 #endif
         if (p + 1 < 4 * GC) fetch((p + 1) & 1, p + 1);
         f32x2 bf[NT];                              // [column] = B values of k-steps 2 kp, 2 kp + 1
@@ -304,7 +370,14 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #endif
       }
 #if !(defined(WINO_ABL) && (WINO_ABL & 8))
-      if (GC == 1 && has_slab) store_x(xbuf ^ 1, sub);
+      if constexpr (VL) {
+        if (has_slab) {
+          if (GC == 1) vl_store(Ss, xbuf ^ 1, sub, 0, 0);
+          if (W_NITEM == 2) vl_store(Ss, xbuf ^ 1, sub, 1, GC == 1 ? 1 : 0);
+        }
+      } else {
+        if (GC == 1 && has_slab) store_x(xbuf ^ 1, sub);
+      }
       if (has_next && sub == SUBS - 1) {                 // end of a slab: one barrier per SUBS chunks
         __syncthreads();
         xbuf ^= 1;
@@ -460,8 +533,8 @@ extern "C" int fh_sizeof_wino_group(void) { return (int)sizeof(fh_wino_group); }
 
 namespace {
 
-template <int MT, int NT, int SUBS>
-int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
+template <int MT, int NT, int SUBS, bool VL>
+int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
                 int phase_major, hipStream_t stream) {
   using Cfg = WCfg<MT, NT, SUBS>;
   FH_CHECK_ARG(cout_pad > 0 && cout_pad % Cfg::BM == 0, "fh_conv_wino_f32: cout_pad %d not a multiple of %d", cout_pad, Cfg::BM);
@@ -474,7 +547,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino_f32: grid too large");
   static bool lds_opt_in = false;      // > 64 KB of dynamic LDS needs the attribute once per process
   if (!lds_opt_in) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<MT, NT, SUBS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<MT, NT, SUBS, VL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        Cfg::LDS_FLOATS * 4);
     if (e != hipSuccess) {
       fh_set_error("fh_conv_wino_f32: cannot reserve %d bytes of LDS: %s", Cfg::LDS_FLOATS * 4, hipGetErrorString(e));
@@ -482,10 +555,19 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
     }
     lds_opt_in = true;
   }
-  hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
+  hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS, VL>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
                      stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major);
   FH_CHECK_LAUNCH("fh_conv_wino_f32");
   return FH_OK;
+}
+
+template <int MT, int NT, int SUBS>
+int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
+                int phase_major, hipStream_t stream) {
+  // 16-byte slab loads need contiguous aligned rows (tensors themselves 16-byte aligned: host plan)
+  const bool vl = (phase_major || (dilation == 1 && len % 4 == 0)) && !getenv("FH_WINO_NO_VL");
+  return vl ? launch_wino_vl<MT, NT, SUBS, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, stream)
+            : launch_wino_vl<MT, NT, SUBS, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, stream);
 }
 
 }  // namespace
