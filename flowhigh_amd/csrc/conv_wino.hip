@@ -572,7 +572,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
 
 }  // namespace
 
-extern "C" int fh_wino_tile_m(int tile_cfg) { return (tile_cfg & ~3) ? -1 : (tile_cfg & 1) ? 96 : 64; }
+extern "C" int fh_wino_tile_m(int tile_cfg) { return tile_cfg == 4 ? 64 : (tile_cfg & ~3) ? -1 : (tile_cfg & 1) ? 96 : 64; }
 
 extern "C" int fh_phase_len(int len, int dilation) { return ((len + dilation - 1) / dilation + 3) & ~3; }
 
@@ -587,6 +587,7 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
     case 1: return launch_wino<3, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
     case 2: return launch_wino<2, 2, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
     case 3: return launch_wino<3, 1, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 4: return launch_wino<2, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
   }
   fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
   return FH_E_ARG;

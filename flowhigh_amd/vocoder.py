@@ -401,6 +401,12 @@ class Vocoder:
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
         def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False):
+            if wcfg == 0:
+                # 64 x 512-output blocks work on one dilation phase each: a short phase (L / d) can leave the last
+                # block mostly empty; the 64 x 256 tile (cfg 4, ~10 % slower per output) then wins
+                lp_ = -(-length // dil)
+                if 1.10 * (-(-lp_ // 256) * 256) < -(-lp_ // 512) * 512:
+                    wcfg = 4
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
             flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B

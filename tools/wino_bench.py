@@ -34,6 +34,9 @@ for c, L in ((768, 5000), (384, 20000), (192, 60000), (96, 120000), (48, 240000)
                                 bs[i], [], outs[i], c, cpad, L, L, L) for i, k in enumerate(KS)]
         dd = hip.to_device_struct_array(gd, DEV)
         wcfg, wpad = V.pick_wino_tile(c)
+        import os
+        if os.environ.get("WCFG"):
+            wcfg = int(os.environ["WCFG"])
         ud = [V.pack_wino_weight(w, wpad).to(DEV) for w in ws]
         gw = [V.make_wino_group([V.make_wino_seg(xs[i], ud[i], c, k)], bs[i], [], outs[i], c, wpad, L)
               for i, k in enumerate(KS)]
