@@ -1,0 +1,49 @@
+"""Randomised check of fh_conv_wino_f32 (all tiles, layouts, dilations, residuals, ragged lengths) against
+float64 F.conv1d.  python tools/wino_fuzz.py [n_cases] [seed]"""
+import sys, random, torch, torch.nn.functional as F
+sys.path.insert(0, '.')
+from flowhigh_amd import hip, vocoder as V
+DEV = torch.device('cuda:0')
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = 0.0
+for case in range(n_cases):
+    c = rng.choice([16, 32, 48, 64, 96, 128, 192])
+    k = rng.choice([1, 3, 5, 7, 9, 11])
+    d = rng.choice([1, 1, 2, 3, 5])
+    B = rng.choice([1, 2, 3])
+    L = rng.choice([rng.randint(1, 40), rng.randint(41, 700), rng.randint(701, 4000)])
+    pm = d > 1 and rng.random() < 0.6
+    nres = 0 if pm else rng.choice([0, 1, 2])
+    nseg = rng.choice([1, 1, 2, 3]) if d == 1 else 1
+    ks = [k] + [rng.choice([3, 7, 11]) for _ in range(nseg - 1)]
+    g = torch.Generator().manual_seed(case)
+    xs = [torch.randn(B, c, L, generator=g) for _ in ks]
+    ws = [torch.randn(c, c, kk, generator=g) / (c * kk) ** 0.5 for kk in ks]
+    bias = torch.randn(c, generator=g)
+    res = [torch.randn(B, c, L, generator=g) for _ in range(nres)]
+    scale = rng.choice([1.0, 0.5, 1.0 / 3])
+    ref = sum(F.conv1d(x.double(), w.double(), None, dilation=d, padding=(kk - 1) // 2 * d) for x, w, kk in zip(xs, ws, ks))
+    ref = ((ref + bias.double().view(1, -1, 1) + sum(r.double() for r in res)) * scale).float()
+    wcfg, cpad = V.pick_wino_tile(c)
+    if wcfg == 0 and rng.random() < 0.3:
+        wcfg = 4
+    if wcfg in (0, 1) and c % 32 == 0 and rng.random() < 0.2:
+        wcfg += 2
+    conv = lambda t: (V.to_phase_major(t, d) if pm else t).to(DEV)
+    xd = [conv(x) for x in xs]
+    rd = [conv(r) for r in res]
+    out = torch.full_like(xd[0], float("nan"))
+    ud = [V.pack_wino_weight(w, cpad).to(DEV) for w in ws]
+    bd = bias.to(DEV)                      # (descriptors hold raw pointers: every tensor must stay referenced)
+    grp = V.make_wino_group([V.make_wino_seg(xd[i], ud[i], c, kk) for i, kk in enumerate(ks)], bd, rd, out,
+                            c, cpad, L, scale=scale)
+    keep = V.conv_wino([grp], B, cpad, L, d, DEV, wcfg, phase_major=pm)
+    torch.cuda.synchronize()
+    got = V.from_phase_major(out.cpu(), d, L) if pm else out.cpu()
+    err = (got - ref).abs().max().item()
+    worst = max(worst, err)
+    ok = err <= 3e-5 * nseg and bool(torch.isfinite(got).all())
+    if not ok:
+        print(f"FAIL case {case}: c={c} ks={ks} d={d} B={B} L={L} pm={pm} nres={nres} cfg={wcfg} err={err}")
+print(f"{n_cases} cases, worst error {worst:.2e}")
