@@ -12,7 +12,7 @@
 // and 8 KB write per frame.  The butterflies run in float64: an fp32 FFT carries the rounding of the
 // LARGEST bins into every output (absolute floor ~1e-6 of the spectral peak), and the log-mel of the
 // empty band above the input's Nyquist is decided right there (torch's own fp32 FFT is 6e-4 off the
-// float64 pipeline in those bins; tools/mel_compare.py).  In float64 the result is the correctly rounded
+// float64 pipeline in those bins; tests/tools/mel_compare.py).  In float64 the result is the correctly rounded
 // spectrum of the fp32 frames: 2.3e-4 from the float64 pipeline, 3.7e-4 from the reference.
 //
 // Spectrum layout ("P-layout", shared with fh_spec_energy_f32 / fh_spec_splice_f32): 33 blocks of 64

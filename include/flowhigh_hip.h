@@ -94,7 +94,7 @@ int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch, in
  * cin x cout residual-stack convs) evaluated with the Winograd minimal-filtering identity
  * F(4,3): the k taps are walked in groups of 3 and every group of 4 outputs costs 6 instead of
  * 12 multiply-adds per (cin, cout) pair.  Exact in exact arithmetic; in fp32 the end-to-end
- * difference to the direct form is ~1e-6 (tools/winograd_numerics.py).
+ * difference to the direct form is ~1e-6 (tests/tools/winograd_numerics.py).
  *   out[b, co, n] = scale * (bias[co] + sum_res res[b, co, n]
  *                            + sum_seg sum_ci sum_{j<k} w[co, ci, j] * x[b, ci, n + (j - center) * dilation])
  * u = host-transformed weights (flowhigh_amd/vocoder.py: pack_wino_weight):

@@ -149,12 +149,12 @@ def test_conv_wino_phase_major(c, k, d, L, B):
 
 
 def test_act1d_randomised_configurations():
-    """tools/act_fuzz.py as a test: random batches / channels / groups / lengths / layouts vs the oracle."""
+    """tests/tools/act_fuzz.py as a test: random batches / channels / groups / lengths / layouts vs the oracle."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
-    r = subprocess.run([sys.executable, str(root / "tools" / "act_fuzz.py"), "120", "11"], cwd=root,
+    r = subprocess.run([sys.executable, str(root / "tests" / "tools" / "act_fuzz.py"), "120", "11"], cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "FAIL" not in r.stdout, r.stdout[-2000:]
@@ -162,13 +162,13 @@ def test_act1d_randomised_configurations():
 
 
 def test_conv_wino_randomised_configurations():
-    """tools/wino_fuzz.py as a test: 150 random (channels, taps, dilation, batch, length, layout, residuals,
+    """tests/tools/wino_fuzz.py as a test: 150 random (channels, taps, dilation, batch, length, layout, residuals,
     segments, tile) combinations against float64 F.conv1d."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
-    r = subprocess.run([sys.executable, str(root / "tools" / "wino_fuzz.py"), "150", "7"], cwd=root,
+    r = subprocess.run([sys.executable, str(root / "tests" / "tools" / "wino_fuzz.py"), "150", "7"], cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "FAIL" not in r.stdout, r.stdout[-2000:]

@@ -1,5 +1,5 @@
 """Randomised check of fh_act1d_grouped_pm_f32 (plain / phase-major in and out, ragged lengths, several groups)
-against the oracle's Activation1d.  python tools/act_fuzz.py [n_cases] [seed]"""
+against the oracle's Activation1d.  python tests/tools/act_fuzz.py [n_cases] [seed]"""
 import sys, random, torch
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, synth, vocoder as V

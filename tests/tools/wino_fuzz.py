@@ -1,5 +1,5 @@
 """Randomised check of fh_conv_wino_f32 (all tiles, layouts, dilations, residuals, ragged lengths) against
-float64 F.conv1d.  python tools/wino_fuzz.py [n_cases] [seed]"""
+float64 F.conv1d.  python tests/tools/wino_fuzz.py [n_cases] [seed]"""
 import sys, random, torch, torch.nn.functional as F
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, vocoder as V
