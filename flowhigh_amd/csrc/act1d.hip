@@ -294,19 +294,27 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     int t0, c;
     float alpha, inv_beta;            // vector loads, requested one tile ahead together with the tile itself
   };
-  auto tile_of = [&](long long g) {
+  // position of a flattened tile: (tile in row, channel, batch, group); the first one of the block is found by
+  // 32-bit divisions, the following ones by carrying (a 64-bit division per tile cost ~400 scalar instructions)
+  struct Pos { int tile, c, bb, gi; };
+  auto pos_next = [&](Pos p) {
+    if (++p.tile == tiles_per_row) {
+      p.tile = 0;
+      if (++p.c == channels) {
+        p.c = 0;
+        if (++p.bb == batch) { p.bb = 0; ++p.gi; }
+      }
+    }
+    return p;
+  };
+  auto tile_of = [&](const Pos& p, bool ok) {
     Tile T;
-    const bool ok = g < total_tiles;
-    const long long gg = ok ? g : total_tiles - 1;
-    const int tile = uni((int)(gg % tiles_per_row));
-    const long long row = gg / tiles_per_row;          // (group * batch + b) * channels + c
-    T.c = uni((int)(row % channels));
-    const long long gb = row / channels;
-    T.G = groups + uni((int)(gb / batch));
-    const size_t rowi = (size_t)uni((int)(gb % batch)) * channels + T.c;
+    T.c = p.c;
+    T.G = groups + p.gi;
+    const size_t rowi = (size_t)p.bb * channels + p.c;
     T.rx = make_rsrc(uni(T.G->x) + rowi * (size_t)pitch_in, ok ? (unsigned)pitch_in * 4u : 0u);
     T.ry = make_rsrc(uni((const float*)T.G->y) + rowi * (size_t)pitch_out, ok ? (unsigned)pitch_out * 4u : 0u);
-    T.t0 = tile * ACT_TT;
+    T.t0 = p.tile * ACT_TT;
     // (buffer loads, not flat ones: with a flat load in flight the compiler has to wait with vmcnt(0))
     T.alpha = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
         make_rsrc(uni(T.G->alpha), (unsigned)channels * 4u), (unsigned)T.c * 4u, 0, 0));
@@ -339,12 +347,24 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     }
   };
 
-  Tile T = tile_of(g0);
+  Pos pos;
+  {
+    const unsigned g32 = (unsigned)g0;                       // total_tiles < 2^31 (checked by the launcher)
+    const unsigned row = g32 / (unsigned)tiles_per_row;
+    pos.tile = uni((int)(g32 - row * (unsigned)tiles_per_row));
+    const unsigned gb = row / (unsigned)channels;
+    pos.c = uni((int)(row - gb * (unsigned)channels));
+    pos.gi = uni((int)(gb / (unsigned)batch));
+    pos.bb = uni((int)(gb - (unsigned)pos.gi * (unsigned)batch));
+  }
+  Tile T = tile_of(pos, true);
   u32x4 cur[2], nxt[2];
   load_tile(T, cur);
 #pragma unroll
   for (int it = 0; it < ACT_NTILE; ++it) {
-    const Tile Tn = tile_of(g0 + it + 1);
+    const bool ok_n = g0 + it + 1 < total_tiles;
+    if (ok_n) pos = pos_next(pos);                            // (past the end: stay on the last tile, zero-sized descriptors)
+    const Tile Tn = tile_of(pos, ok_n);
     const fh_act_group& G = *T.G;
     const float alpha = T.alpha, inv_beta = T.inv_beta;
     if (PIN) {                 // scatter the phase chunks to their natural positions (stride din, odd: conflict free)
