@@ -408,13 +408,16 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const float scale = G->scale;
   const int cout = uni(G->cout);
   const float* __restrict__ bias = uni(G->bias);
-  const size_t slab = (size_t)b * cout * pitch;
-  const unsigned slab_bytes = (unsigned)cout * (unsigned)pitch * 4u;
+  const int ostride = uni(G->out_stride) > 1 ? uni(G->out_stride) : 1;      // transposed-conv phase: out row = ostride * len
+  const int ophase = uni(G->out_phase);
+  const int opitch = pitch * ostride;
+  const size_t slab = (size_t)b * cout * opitch;
+  const unsigned slab_bytes = (unsigned)cout * (unsigned)opitch * 4u;
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(uni((const float*)G->out) + slab, slab_bytes);
   const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? uni(G->res[0]) + slab : nullptr, nres > 0 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? uni(G->res[1]) + slab : nullptr, nres > 1 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? uni(G->res[2]) + slab : nullptr, nres > 2 ? slab_bytes : 0u);
-  const bool vec = pm || (dil == 1 && (len & 3) == 0);   // 4 outputs of a tile = one aligned 16-byte vector
+  const bool vec = (pm || (dil == 1 && (len & 3) == 0)) && ostride == 1;   // 4 outputs of a tile = one aligned 16-byte vector
   float* E = lds;                                    // [th][xi][32][W_EP]
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -443,7 +446,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           const int v0 = tb * (4 * W_BT) + (nt * 64 + eh * 32 + col) * 4;   // decimated index of y[0]
           const bool rowok = co < cout;
           const float bv = (bias && rowok) ? bias[co] : 0.f;
-          const unsigned rowoff = (unsigned)co * (unsigned)pitch + (pm ? (unsigned)(ph * lp) : 0u);
+          const unsigned rowoff = (unsigned)co * (unsigned)opitch + (pm ? (unsigned)(ph * lp) : 0u);
           if (vec && (v0 + 3) * dil + ph < len) {
             const unsigned off = rowok ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
             f32x4 o = {y[0] + bv, y[1] + bv, y[2] + bv, y[3] + bv};
@@ -467,7 +470,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int n = ph + dil * (v0 + q);
-              const unsigned off = (rowok && n < len) ? (rowoff + (unsigned)(pm ? v0 + q : n)) * 4u : 0x80000000u;
+              const unsigned off = (rowok && n < len) ? (rowoff + (unsigned)(pm ? v0 + q : n * ostride + ophase)) * 4u
+                                                      : 0x80000000u;
               float o = y[q] + bv;
               if (nres > 0) {
                 float rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));

@@ -40,7 +40,8 @@ class WinoSeg(C.Structure):
 class WinoGroup(C.Structure):
     _fields_ = [("seg", WinoSeg * CONV_MAX_SEG), ("bias", C.c_void_p), ("res", C.c_void_p * CONV_MAX_SEG),
                 ("out", C.c_void_p), ("nseg", C.c_int32), ("nres", C.c_int32), ("cout", C.c_int32),
-                ("cout_pad", C.c_int32), ("len", C.c_int32), ("scale", C.c_float)]
+                ("cout_pad", C.c_int32), ("len", C.c_int32), ("scale", C.c_float), ("out_stride", C.c_int32),
+                ("out_phase", C.c_int32)]
 
 
 class ActGroup(C.Structure):

@@ -179,13 +179,14 @@ def pack_wino_weight(w, cout_pad):
     return p.contiguous()
 
 
-def make_wino_seg(x, u, cin, k):
+def make_wino_seg(x, u, cin, k, center=None):
     s = hip.WinoSeg()
-    s.x, s.u, s.cin, s.ngrp, s.center = hip.ptr(x), hip.ptr(u), cin, -(-k // 3), (k - 1) // 2
+    s.x, s.u, s.cin, s.ngrp = hip.ptr(x), hip.ptr(u), cin, -(-k // 3)
+    s.center = (k - 1) // 2 if center is None else center
     return s
 
 
-def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0):
+def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0, stride=1, phase=0):
     g = hip.WinoGroup()
     # the kernel walks the segments in one pass per tap-group count, largest first
     for i, s in enumerate(sorted(segs, key=lambda s: -s.ngrp)):
@@ -195,10 +196,22 @@ def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0):
     for i, r in enumerate(res):
         g.res[i] = hip.ptr(r)
     g.out = hip.ptr(out)
-    if max(cout, max(s.cin for s in segs)) * length * 4 >= 2 ** 31:
+    if max(cout * stride, max(s.cin for s in segs)) * length * 4 >= 2 ** 31:
         raise NotImplementedError("per-clip tensor exceeds the 2 GiB range of a buffer descriptor")
     g.cout, g.cout_pad, g.len, g.scale = cout, cpad, length, scale
+    g.out_stride, g.out_phase = stride, phase
     return g
+
+
+def wino_phase_weight(wt, taps):
+    """ConvTranspose1d weight [cin, cout, k] + the taps [(j, offset)] of one output phase (transposed_conv_phases)
+    -> (Conv1d-style weight [cout, cin, k_r] with taps ordered by input offset, center = -smallest offset)."""
+    taps = sorted(taps, key=lambda t: t[1])
+    offs = [o for _, o in taps]
+    if offs != list(range(offs[0], offs[0] + len(offs))):
+        raise NotImplementedError(f"phase offsets {offs} are not contiguous")
+    w = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1).permute(1, 0, 2).contiguous()
+    return w, -offs[0]
 
 
 def phase_len(length, d):
@@ -320,6 +333,16 @@ class Vocoder:
                 wsel = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1)        # [cin, c, nt]
                 st["up_phases"].append(dict(w=pack_conv_weight(wsel.permute(1, 0, 2), cpad, st["up_ck"]).to(dev),
                                             offs=[o for _, o in taps]))
+            # the same transposed conv as Winograd phase groups (strided output) where the tile shapes fit
+            st["up_wino"] = None
+            # (measured at B = 1: 366 -> 207 us for 1536 -> 768 channels, a wash at 768 -> 384, slower below: the
+            # one-tap-group blocks pay the per-chunk slab cost on every step)
+            if use_wino(max(c, 48), 1) and c % 16 == 0 and c >= 48 and st["cin"] % 16 == 0 \
+                    and st["cin"] >= int(os.environ.get("FH_WINO_UPS_MIN_CIN", "768")):
+                st["up_wino"] = []
+                for taps in transposed_conv_phases(k, u):
+                    wph, center = wino_phase_weight(wt, taps)
+                    st["up_wino"].append(dict(u=pack_wino_weight(wph, st["wpad"]).to(dev), k=wph.shape[-1], center=center))
             st["blocks"] = []
             for j in range(self.nk):
                 r = i * self.nk + j
@@ -400,7 +423,9 @@ class Vocoder:
             executed[0] += flops
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
-        def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False):
+        def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False, flops=None):
+            if wcfg == 0 and B * len(groups) * (wpad // WINO_BM) * -(-length // 512) < 200:
+                wcfg = 4            # too few 512-wide blocks for 256 CUs (first-stage upsampler at batch 1)
             if wcfg == 0:
                 # 64 x 512-output blocks work on one dilation phase each: a short phase (L / d) can leave the last
                 # block mostly empty; the 64 x 256 tile (cfg 4, ~10 % slower per output) then wins
@@ -409,8 +434,9 @@ class Vocoder:
                     wcfg = 4
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
-            flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
-                        for g in groups for i in range(g.nseg))
+            if flops is None:
+                flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
+                            for g in groups for i in range(g.nseg))
             # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
             executed[0] += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
                                for g in groups for i in range(g.nseg))
@@ -455,10 +481,17 @@ class Vocoder:
             view = lambda idx: pool[idx, :B * c * L].view(B, c, L)
             X = view(0)
             S = view(1)
-            groups = [make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X,
-                                       c, cpad, lin, L, lin, stride=u, phase=r)
-                      for r, ph in enumerate(st["up_phases"])]
-            conv_step(groups, cpad, lin, tcfg, st["up_ck"])
+            if st["up_wino"] is not None:
+                groups = [make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"])], st["up_b"], [],
+                                          X, c, st["wpad"], lin, stride=u, phase=r)
+                          for r, ph in enumerate(st["up_wino"])]
+                wino_step(groups, st["wpad"], lin, 1, st["wcfg"],
+                          flops=sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"]))
+            else:
+                groups = [make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X,
+                                           c, cpad, lin, L, lin, stride=u, phase=r)
+                          for r, ph in enumerate(st["up_phases"])]
+                conv_step(groups, cpad, lin, tcfg, st["up_ck"])
             # heavy kernel sizes first (dispatch order == launch order of the panels)
             order = sorted(range(self.nk), key=lambda j: -st["blocks"][j]["k"])
             T1 = [view(2 + 4 * j) for j in range(self.nk)]

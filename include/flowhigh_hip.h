@@ -100,6 +100,10 @@ int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch, in
  * u = host-transformed weights (flowhigh_amd/vocoder.py: pack_wino_weight):
  *   [cin/16][ngrp][6][cout_pad][16], u[., g, xi, co, .] = sum_j G[xi][j] * w[co, ., 3g + j]
  *   (taps past k are zero), cout_pad % (64 or 96, see tile_cfg) == 0, cin % 16 == 0.
+ * cin need not equal cout.  With out_stride = u > 1 a group is one output phase of ConvTranspose1d(k, stride u,
+ * padding (k - u) / 2) (models/bigvgan/models.py:131-140,179): its taps j = r + p (mod u), ordered by input offset,
+ * form a stride-1 correlation with `center` = minus the smallest offset (flowhigh_amd/vocoder.py:
+ * transposed_conv_phases), and its outputs interleave with the other phases'.
  */
 typedef struct {
   const float* x;      /* [B, cin, len] */
@@ -121,6 +125,8 @@ typedef struct {
   int32_t cout_pad;
   int32_t len;
   float scale;
+  int32_t out_stride;   /* 0 or 1: out[b, co, n]; u > 1: one output phase of a transposed conv (models.py:179),   */
+  int32_t out_phase;    /*   out [B, cout, u * len] written at u * n + out_phase (dilation 1, plain layout, no res)  */
 } fh_wino_group;
 
 int fh_sizeof_wino_group(void);

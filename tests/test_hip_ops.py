@@ -148,6 +148,26 @@ def test_conv_wino_phase_major(c, k, d, L, B):
     del keep
 
 
+@pytest.mark.parametrize("u,k,cin,cout,L,B", [(5, 11, 64, 32, 157, 2), (4, 8, 32, 64, 1000, 1), (3, 7, 48, 96, 333, 2),
+                                              (2, 4, 96, 48, 2049, 1), (8, 16, 16, 64, 50, 1)])
+def test_conv_transpose_as_wino_phase_groups(u, k, cin, cout, L, B):
+    """ConvTranspose1d as u Winograd groups with strided output (one per output phase)."""
+    x, wt, b = rnd(B, cin, L, seed=190), rnd(cin, cout, k, seed=191, scale=0.2), rnd(cout, seed=192)
+    ref = F.conv_transpose1d(x.double(), wt.double(), b.double(), stride=u, padding=(k - u) // 2).float()
+    wcfg, cpad = V.pick_wino_tile(cout)
+    xd, out, bd = x.to(DEV), torch.full((B, cout, u * L), float("nan"), device=DEV), b.to(DEV)
+    groups, keep = [], []
+    for r, taps in enumerate(V.transposed_conv_phases(k, u)):
+        w, center = V.wino_phase_weight(wt, taps)
+        ud = V.pack_wino_weight(w, cpad).to(DEV)
+        keep.append(ud)
+        groups.append(V.make_wino_group([V.make_wino_seg(xd, ud, cin, w.shape[-1], center)], bd, [], out, cout, cpad, L,
+                                        stride=u, phase=r))
+    keep.append(V.conv_wino(groups, B, cpad, L, 1, DEV, wcfg))
+    torch.cuda.synchronize()
+    assert maxdiff(out, ref) <= 2e-5
+
+
 def test_act1d_randomised_configurations():
     """tests/tools/act_fuzz.py as a test: random batches / channels / groups / lengths / layouts vs the oracle."""
     import subprocess
