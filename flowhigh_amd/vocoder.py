@@ -319,6 +319,12 @@ class Vocoder:
         self.pre_ck = pick_ck(self.num_mels)
         self.pre_w = pack_conv_weight(g("conv_pre.weight"), self.pre_cpad, self.pre_ck).to(dev)
         self.pre_b = g("conv_pre.bias").to(dev)
+        # conv_pre (num_mels -> c0, 7 taps) in Winograd form as well when the shapes fit
+        self.pre_u = None
+        if os.environ.get("FH_WINO_PRE", "1") != "0" and use_wino(self.c0, 1) and self.num_mels % 16 == 0 \
+                and self.c0 % 64 == 0:
+            self.pre_wcfg, self.pre_wpad = pick_wino_tile(self.c0)
+            self.pre_u = pack_wino_weight(g("conv_pre.weight"), self.pre_wpad).to(dev)
         self.stages = []
         for i, (u, k) in enumerate(zip(self.rates, self.up_k)):
             c = self.chans[i]
@@ -465,8 +471,12 @@ class Vocoder:
         pre = torch.empty(B, self.c0, N, **f32)
         keep.append(pre)            # descriptors hold raw pointers: every buffer they name must outlive the plan
         k7 = [j - 3 for j in range(7)]
-        conv_step([make_conv_group([make_conv_seg(mel_in, self.pre_w, self.num_mels, k7)], self.pre_b, [],
-                                    pre, self.c0, self.pre_cpad, N, N, N)], self.pre_cpad, N, self.pre_cfg, self.pre_ck)
+        if self.pre_u is not None:
+            wino_step([make_wino_group([make_wino_seg(mel_in, self.pre_u, self.num_mels, 7)], self.pre_b, [], pre,
+                                       self.c0, self.pre_wpad, N)], self.pre_wpad, N, 1, self.pre_wcfg)
+        else:
+            conv_step([make_conv_group([make_conv_seg(mel_in, self.pre_w, self.num_mels, k7)], self.pre_b, [],
+                                        pre, self.c0, self.pre_cpad, N, N, N)], self.pre_cpad, N, self.pre_cfg, self.pre_ck)
         cur = pre
         dils = sorted({d for dl in self.dil for d in dl})
         # (phase-major intermediates of the dilated convs are padded to d * phase_len >= L floats per row)
