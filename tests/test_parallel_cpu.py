@@ -1,6 +1,8 @@
 """CPU (gloo, world_size 2 and 3): the clip scatter / gather used for multi-GPU runs reproduces the
 unsharded result bit for bit, including ragged splits and ranks that receive no clip."""
 import os
+
+import numpy as np
 import socket
 
 import pytest
@@ -56,3 +58,49 @@ def test_shard_bounds():
     assert parallel.shard_bounds(256, 8) == [(32 * i, 32 * i + 32) for i in range(8)]
     assert parallel.shard_bounds(5, 2) == [(0, 3), (3, 5)]
     assert parallel.shard_bounds(2, 3) == [(0, 1), (1, 2), (2, 2)]
+
+
+# ------------------------------------------------------------------------------------------
+# serving front (host logic only: a stub model records what the batcher hands it)
+# ------------------------------------------------------------------------------------------
+class _StubModel:
+    def __init__(self):
+        self.calls = []
+
+    def _draw_noise(self, batch, n_frames, generator):
+        return torch.randn(batch, n_frames, 4, generator=generator)
+
+    def generate_many(self, clips, sr, target, steps, noise=None, max_batch=64):
+        self.calls.append((len(clips), sr, steps, None if noise is None else [tuple(n.shape) for n in noise]))
+        return [torch.from_numpy(np.asarray(c, dtype=np.float32))[None] * 2 for c in clips]
+
+
+def test_batching_server_groups_and_returns_in_order():
+    import threading
+    import numpy as np
+    from flowhigh_amd.serve import BatchingServer
+    m = _StubModel()
+    srv = BatchingServer(m, max_batch=8, max_wait_ms=200)
+    clips = [np.full(120 + 10 * (i % 3), float(i), dtype=np.float32) for i in range(9)]
+    futs = [None] * len(clips)
+
+    def client(i):
+        futs[i] = srv.submit(clips[i], 12000 if i % 2 == 0 else 16000, timestep=1, seed=i)
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(len(clips))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    outs = [f.result(timeout=30) for f in futs]
+    for i, o in enumerate(outs):                         # every caller gets ITS clip back
+        assert o.dtype == np.float32 and o.shape == clips[i].shape and np.all(o == 2 * clips[i])
+    assert sum(c[0] for c in m.calls) == len(clips)
+    assert {c[1] for c in m.calls} == {12000, 16000}     # never mixes input rates in one call
+    assert len(m.calls) <= 4                             # ... and did batch the concurrent requests
+    sr, y = srv.generate((12000, (clips[0] * 100).astype(np.int16)), 48000, 1)     # app.py's signature
+    assert sr == 48000 and y.shape == clips[0].shape
+    with pytest.raises(NotImplementedError):
+        srv.generate((12000, clips[0]), 44100, 1)
+    srv.close()
+    with pytest.raises(RuntimeError):
+        srv.submit(clips[0], 12000)
