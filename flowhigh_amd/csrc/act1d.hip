@@ -287,6 +287,17 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   // phase-major input: chunk q = (phase p, 4 consecutive decimated samples); <= 2 chunks per thread
   const int nq_in = PIN ? ((ACT_XS + din - 1) / din + 3) / 4 : 1;
   const int nq_out = POUT ? ((ACT_TT + dout - 1) / dout + 3) / 4 : 1;
+  // (phase, chunk-in-phase) of this thread's two chunks: constant over the tiles.  All other divisions by the
+  // dilation are done once per tile on wave-uniform values: ceil((x - p) / d) = x / d + (x % d > p), 0 <= p < d.
+  int pin_p[2], pin_k[2], pout_p[2], pout_k[2];
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int f = tid + 256 * rep;
+    pin_p[rep] = f / nq_in;
+    pin_k[rep] = f - pin_p[rep] * nq_in;
+    pout_p[rep] = f / nq_out;
+    pout_k[rep] = f - pout_p[rep] * nq_out;
+  }
 
   struct Tile {                       // wave-uniform description of one flattened tile
     __amdgpu_buffer_rsrc_t rx, ry;
@@ -328,9 +339,10 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     for (int rep = 0; rep < 2; ++rep) {
       const int f = tid + 256 * rep;
       if (PIN) {           // 4 consecutive samples of one phase: 16 bytes at a dword-aligned address
-        const int tb = T.t0 - 8;
-        const int p = f / nq_in, k = f - p * nq_in;
-        const int ul = (tb - p + 9 * din - 1) / din - 8;          // ceil((tb - p) / din), tb >= -8
+        const int tb8 = uni(T.t0 - 8 + 8 * din);                   // >= 0
+        const int qt = uni(tb8 / din), rt = tb8 - qt * din;
+        const int p = pin_p[rep], k = pin_k[rep];
+        const int ul = qt - 8 + (rt > p ? 1 : 0);                  // ceil((t0 - 8 - p) / din)
         const int u = (ul > 0 ? ul : 0) + 4 * k;
         // (past the row: reads a neighbour phase or falls out of range; such samples are not used)
         xr[rep] = __builtin_amdgcn_raw_buffer_load_b128(T.rx, p < din ? (unsigned)((p * lp_in + u) * 4) : 0x80000000u, 0, 0);
@@ -369,11 +381,12 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     const float alpha = T.alpha, inv_beta = T.inv_beta;
     if (PIN) {                 // scatter the phase chunks to their natural positions (stride din, odd: conflict free)
       const int tb = T.t0 - 8;
+      const int tb8 = uni(tb + 8 * din);
+      const int qt = uni(tb8 / din), rt = tb8 - qt * din;
 #pragma unroll
       for (int rep = 0; rep < 2; ++rep) {
-        const int f = tid + 256 * rep;
-        const int p = f / nq_in, k = f - p * nq_in;
-        const int ul = (tb - p + 9 * din - 1) / din - 8;
+        const int p = pin_p[rep], k = pin_k[rep];
+        const int ul = qt - 8 + (rt > p ? 1 : 0);
         const int u = (ul > 0 ? ul : 0) + 4 * k;
         if (p < din) {
 #pragma unroll
@@ -489,12 +502,13 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
         *reinterpret_cast<f32x4*>(ys + o0) = (f32x4){out[0], out[1], out[2], out[3]};
         __syncthreads();
         const int t_end = (t0 + ACT_TT < len ? t0 + ACT_TT : len) - 1;      // last output of this tile
+        const int q0 = uni(t0 / dout), r0 = t0 - q0 * dout;
+        const int qe = uni(t_end / dout), re = t_end - qe * dout;
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
-          const int q = tid + 256 * rep;
-          const int p = q / nq_out, k = q - p * nq_out;
-          const int u = (t0 - p + dout - 1) / dout + 4 * k;                 // t0 - p + dout - 1 >= 0
-          const int u_hi = (p < dout && t_end >= p) ? (t_end - p) / dout : -1;
+          const int p = pout_p[rep], k = pout_k[rep];
+          const int u = q0 + (r0 > p ? 1 : 0) + 4 * k;                      // ceil((t0 - p) / dout) + 4 k
+          const int u_hi = p < dout ? qe - (p > re ? 1 : 0) : -1;           // floor((t_end - p) / dout), -1 if t_end < p
           const unsigned off0 = (unsigned)((p * lp_out + u) * 4);
           if (u + 3 <= u_hi) {
             u32x4 ou;
