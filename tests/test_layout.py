@@ -141,3 +141,29 @@ def test_wino_rule_and_tiles():
     assert V.pick_wino_tile(96) == (1, 96)
     assert V.pick_wino_tile(48)[1] == 64
     assert V.use_wino(768, 5) and V.use_wino(192, 3) and not V.use_wino(24, 1)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/*_bench_line_B1.json is a bench.py output line: the driver's keys, the roofline and cpu_baseline
+    objects, and self-consistent numbers."""
+    import json
+    f = sorted((ROOT / "profiles").glob("*_bench_line_B1.json"))[-1]
+    line = json.loads(f.read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert "model" not in line["config"]
+    rl = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rl, k
+    assert rl["bound"] == "mfma" and rl["unit"] == "TFLOP/s" and rl["peak"] == 157.3
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+    assert rl["mfma_executed"] <= rl["achieved"] and rl["mfma_executed_frac"] < 1.0
+    cb = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["unit"] == line["unit"]
+    secs_per_step = line["ms_per_step"] / 1e3
+    assert abs(line["value"] - line["n_gpus"] * 10.0 / secs_per_step) / line["value"] < 0.02      # B = 1, 10 s clips
