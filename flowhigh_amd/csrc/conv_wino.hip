@@ -51,6 +51,8 @@ constexpr int W_RUN = 8;             // n-blocks of a panel that run together on
 
 // Wave tile = (32 MT) co x (32 NT) tiles; block tile = (32 MT) co x (64 NT) tiles (256 NT outputs).
 //   <2, 2>: 64 x 512 outputs  (C % 64 == 0)        <3, 1>: 96 x 256 outputs  (C = 96)
+//   <2, 1>: 64 x 256 (short dilation phases)      <1, 1>: 32 x 256 (short clips: a launch of a few dozen blocks
+//                                                         is bound by the K loop of ONE block, not by the chip)
 // SUBS = 16-channel chunks per LDS slab buffer: with 2 the block synchronises once per 32 input channels
 // (needs cin % 32 == 0 in every segment; 147 KB of LDS for the <2, 2> tile).
 template <int MT, int NT, int SUBS = 1>
@@ -576,7 +578,9 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
 
 }  // namespace
 
-extern "C" int fh_wino_tile_m(int tile_cfg) { return tile_cfg == 4 ? 64 : (tile_cfg & ~3) ? -1 : (tile_cfg & 1) ? 96 : 64; }
+extern "C" int fh_wino_tile_m(int tile_cfg) {
+  return tile_cfg == 5 ? 32 : tile_cfg == 4 ? 64 : (tile_cfg & ~3) ? -1 : (tile_cfg & 1) ? 96 : 64;
+}
 
 extern "C" int fh_phase_len(int len, int dilation) { return ((len + dilation - 1) / dilation + 3) & ~3; }
 
@@ -592,6 +596,7 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
     case 2: return launch_wino<2, 2, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
     case 3: return launch_wino<3, 1, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
     case 4: return launch_wino<2, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 5: return launch_wino<1, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
   }
   fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
   return FH_E_ARG;

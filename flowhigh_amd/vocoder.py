@@ -144,6 +144,8 @@ def make_act_group(x, y, p):
 
 
 
+# launches with fewer 64 x 256 blocks than this use the 32 x 256 tile (latency of short clips)
+_WINO_SMALL_BLOCKS = int(os.environ.get("FH_WINO_SMALL_BLOCKS", "160"))
 # stage-closing conv (3 K segments in one group): fused only when it yields at least this many blocks
 _WINO_FUSE_MIN_BLOCKS = int(os.environ.get("FH_WINO_FUSE_MIN_BLOCKS", "200"))
 # Winograd F(4,3) weight transform G (6 x 3); interpolation points 0, +-1, +-2, inf
@@ -430,6 +432,8 @@ class Vocoder:
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
         def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False, flops=None):
+            if wcfg in (0, 4) and B * len(groups) * (wpad // WINO_BM) * -(-length // 256) < _WINO_SMALL_BLOCKS:
+                wcfg = 5            # short clips: 32 x 256 tiles, 2-4x the blocks, each with a 2-4x shorter K loop
             if wcfg == 0 and B * len(groups) * (wpad // WINO_BM) * -(-length // 512) < 200:
                 wcfg = 4            # too few 512-wide blocks for 256 CUs (first-stage upsampler at batch 1)
             if wcfg == 0:
