@@ -23,22 +23,26 @@ namespace {
 constexpr int KP = 68;   // K tile pitch (floats): b128 reads conflict free
 constexpr int VP = 64;
 
-// WAVES = 4: 128 queries per block; WAVES = 2: 64 (twice the blocks when the grid would not fill the chip).
-template <int WAVES>
+// WAVES = 4, SPLIT = 1: 128 queries per block.  SPLIT = 2 (small grids): 64 queries per block, the two waves of a
+// 32-query tile take alternate 32-key tiles and merge their (max, sum, O) at the end -- twice the waves and half
+// the dependent MFMA chain per wave when there are fewer query tiles than SIMDs (B = 1: 512 tiles, 1024 SIMDs).
+template <int WAVES, int SPLIT>
 __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __restrict__ qkv,
                                                                float* __restrict__ out, int n, int heads,
                                                                float scale) {
   constexpr int NT = 64 * WAVES;           // threads
-  constexpr int NLD = 512 / NT;            // float4 of K (and of V) staged per thread and tile
-  __shared__ __attribute__((aligned(16))) float Ks[32 * KP];
-  __shared__ __attribute__((aligned(16))) float Vs[32 * VP];
+  constexpr int NLD = 512 * SPLIT / NT;    // float4 of K (and of V) staged per thread and iteration
+  constexpr int KT = 32 * KP, VT = 32 * VP;
+  __shared__ __attribute__((aligned(16))) float Ks[SPLIT * KT];
+  __shared__ __attribute__((aligned(16))) float Vs[SPLIT * VT];
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int inner = heads * 64;
   const size_t ld = (size_t)3 * inner;
   const float* base = qkv + (size_t)b * n * ld + h * 64;
-  const int q0 = blockIdx.x * (32 * WAVES) + wave * 32;
+  const int qt = wave / SPLIT, sp = wave % SPLIT;      // query tile of the block, key-split index
+  const int q0 = blockIdx.x * (32 * WAVES / SPLIT) + qt * 32;
   const int qi = q0 + l31;
 
   // Q fragments: qf[q'][e] = Q[qi][8 q' + 4 lh + e]
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __re
   auto load_kv = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int f = tid + NT * i, key = f >> 4, c4 = f & 15;
+      const int f = tid + NT * i, key = f >> 4, c4 = f & 15;        // key < 32 SPLIT
       f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
       if (k0 + key < n) {
         const float* rowp = base + (size_t)(k0 + key) * ld + 4 * c4;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __re
     }
   };
   load_kv(0);
-  for (int k0 = 0; k0 < n; k0 += 32) {
+  for (int kb = 0; kb < n; kb += 32 * SPLIT) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -82,7 +86,11 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __re
       *reinterpret_cast<f32x4*>(Vs + key * VP + 4 * c4) = vreg[i];
     }
     __syncthreads();
-    if (k0 + 32 < n) load_kv(k0 + 32);
+    if (kb + 32 * SPLIT < n) load_kv(kb + 32 * SPLIT);
+    const int k0 = kb + 32 * sp;                 // this wave's key tile of the iteration
+    const float* Kt = Ks + sp * KT;
+    const float* Vt = Vs + sp * VT;
+    if (k0 >= n) continue;                       // (wave-uniform; the barriers above are outside)
 
     // S^T tile
     f32x16 s;
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __re
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int qq = 0; qq < 8; ++qq) {
-      f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + l31 * KP + 4 * (2 * qq + lh));
+      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + l31 * KP + 4 * (2 * qq + lh));
 #pragma unroll
       for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[qq][e], s, 0, 0, 0);
     }
@@ -125,13 +133,35 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float v0 = Vs[key * VP + l31];
-      const float v1 = Vs[key * VP + 32 + l31];
+      const float v0 = Vt[key * VP + l31];
+      const float v1 = Vt[key * VP + 32 + l31];
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
     }
   }
 
+  if constexpr (SPLIT > 1) {       // merge the key-split partial results into the sp == 0 wave (through the K / V tiles' LDS)
+    __syncthreads();
+    float* X = Ks + qt * (34 * 64);              // per query tile: 32 O values + m + l per lane (SPLIT == 2)
+    static_assert(SPLIT <= 2 && (WAVES / SPLIT) * 34 * 64 <= SPLIT * (KT + VT), "exchange area");
+    if (sp == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { X[r * 64 + lane] = o0[r]; X[(16 + r) * 64 + lane] = o1[r]; }
+      X[32 * 64 + lane] = m_run;
+      X[33 * 64 + lane] = l_run;
+    }
+    __syncthreads();
+    if (sp != 0) return;
+    const float m1 = X[32 * 64 + lane], l1 = X[33 * 64 + lane];
+    const float m = fmaxf(m_run, m1);
+    const float c0 = expf(m_run - m), c1 = expf(m1 - m);      // exp(-inf) = 0: a wave that saw no key contributes nothing
+    l_run = l_run * c0 + l1 * c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] = o0[r] * c0 + X[r * 64 + lane] * c1;
+      o1[r] = o1[r] * c0 + X[(16 + r) * 64 + lane] * c1;
+    }
+  }
   if (qi < n) {
     const float inv = 1.f / l_run;
     float* orow = out + ((size_t)b * n + qi) * inner + h * 64;
@@ -153,10 +183,10 @@ extern "C" int fh_attention_f32(const float* qkv, float* out, int batch, int n, 
   FH_CHECK_ARG(qkv && out && batch > 0 && n > 0 && heads > 0, "fh_attention_f32: bad args");
   if ((long long)fh_cdiv(n, 128) * heads * batch >= 512) {
     dim3 grid(fh_cdiv(n, 128), heads, batch);
-    hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
+    hipLaunchKernelGGL((attention_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
   } else {
     dim3 grid(fh_cdiv(n, 64), heads, batch);
-    hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(128), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
+    hipLaunchKernelGGL((attention_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
   }
   FH_CHECK_LAUNCH("fh_attention_f32");
   return FH_OK;
