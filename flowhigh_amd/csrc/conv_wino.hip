@@ -426,6 +426,21 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       __syncthreads();
+      // first residual of the vector path: issued here so its latency hides under the LDS exchange
+      u32x4 rpre[3];
+      if (vec && nres > 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int idx = tid + W_THREADS * i;
+          const int eh = idx >> 10, row = (idx >> 5) & 31, col = idx & 31;
+          const int co = co0 + mt * 32 + row;
+          const int v0 = tb * (4 * W_BT) + (nt * 64 + eh * 32 + col) * 4;
+          const bool ok = idx < 2048 && co < cout && (v0 + 3) * dil + ph < len;
+          const unsigned off =
+              ok ? ((unsigned)co * (unsigned)opitch + (pm ? (unsigned)(ph * lp) : 0u) + (unsigned)v0) * 4u : 0x80000000u;
+          rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, off, 0, 0);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         E[((th * 6 + xi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * W_EP + l31] = acc[mt][nt][r];
@@ -453,7 +468,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
             const unsigned off = rowok ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
             f32x4 o = {y[0] + bv, y[1] + bv, y[2] + bv, y[3] + bv};
             if (nres > 0) {
-              u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr0, off, 0, 0);
+              u32x4 t = rpre[i];
               f32x4 rs = {__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
               if (nres > 1) {
                 t = __builtin_amdgcn_raw_buffer_load_b128(rr1, off, 0, 0);
