@@ -105,6 +105,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   extern __shared__ __attribute__((aligned(16))) float lds[];      // Cfg::LDS_FLOATS
   unsigned long long* const trace = g_wino_trace;
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
   // ---- block -> (panel, n block); panels = (group, batch, co tile), heavy groups first ----------
   const int panels = n_groups * batch * co_tiles;
@@ -400,10 +401,12 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       ++sg;
     }
   };
+  const unsigned long long t_loop0 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   run_all(std::integral_constant<int, 4>{});
   run_all(std::integral_constant<int, 3>{});
   run_all(std::integral_constant<int, 2>{});
   run_all(std::integral_constant<int, 1>{});
+  const unsigned long long t_loop1 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // ---- epilogue: exchange M_xi through LDS, y = A^T M, bias + residuals, scale, store ----------
   const int nres = uni(G->nres);
@@ -509,11 +512,12 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const unsigned long long slot = atomicAdd(trace, 1ull);
-    unsigned long long* r = trace + 1 + 4 * slot;
+    unsigned long long* r = trace + 1 + 5 * slot;
     r[0] = (unsigned long long)blockIdx.x | ((unsigned long long)(hw & 0xffffff) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
     r[1] = t_start;
     r[2] = __builtin_amdgcn_s_memrealtime();
-    r[3] = (unsigned long long)wave;
+    r[3] = (unsigned long long)wave | ((t_loop0 - t_start) << 8) | ((t_loop1 - t_start) << 36);
+    r[4] = __builtin_amdgcn_s_memtime() - c_start;       // shader clocks: r[4] / (r[2] - r[1]) x 100 MHz
   }
 }
 

@@ -148,6 +148,57 @@ def make_act_group(x, y, p):
 _WINO_SMALL_BLOCKS = int(os.environ.get("FH_WINO_SMALL_BLOCKS", "160"))
 # stage-closing conv (3 K segments in one group): fused only when it yields at least this many blocks
 _WINO_FUSE_MIN_BLOCKS = int(os.environ.get("FH_WINO_FUSE_MIN_BLOCKS", "200"))
+# Winograd tiles (tile_cfg -> rows x outputs) and their measured block time on one CU: _WINO_COST[cfg] = (a, b),
+# a us per K step (16 input channels x one tap group), b us of prologue + epilogue (tools/wino_cfg_sweep.py)
+_WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256)}
+_WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0)}
+_WINO_RUN = 8                      # W_RUN of conv_wino.hip
+_WINO_AUTO = os.environ.get("FH_WINO_AUTO", "1") == "1"
+
+
+def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32):
+    """Estimated duration (us) of one fh_conv_wino_f32 launch: the kernel's block -> (panel, tile) map replayed
+    on 8 XCDs x 32 CUs with in-order dispatch per XCD (block i goes to XCD i % 8).  ksteps: K steps
+    (sum over segments of cin / 16 x tap groups) of each group, launch order.  Blocks of a launch differ up to
+    4 x in length (k = 11 / 7 / 3) and a 10 s clip is only 1-6 blocks per CU, so the block count per tile
+    shape, not the per-tile efficiency, decides between the tile shapes (measured +-10 % at batch 1)."""
+    import heapq
+    bm, bt = _WINO_TILES[cfg]
+    a, b = _WINO_COST[cfg]
+    n_tiles = -(-(-(-length // dil)) // bt) * dil
+    cot = wpad // bm
+    panel_w = [a * k + b for k in ksteps for _ in range(batch * cot)]
+    run_len = -(-n_tiles // -(-n_tiles // _WINO_RUN))
+    rpp = -(-n_tiles // run_len)
+    real = len(panel_w) * n_tiles
+    load = 1.12 if real > 200 else 1.0 + 0.12 * real / 200        # blocks run ~12 % slower on a full chip
+    if real > 16384:                                                  # many blocks per CU: throughput bound
+        return load * sum(panel_w) * n_tiles / (8 * cus_per_xcd)
+    total_runs = len(panel_w) * rpp
+    end = 0.0
+    for x in range(8):
+        cu = [0.0] * cus_per_xcd
+        for run in range(x, total_runs, 8):
+            w = panel_w[run // rpp] * load
+            first = (run % rpp) * run_len
+            for _ in range(min(run_len, n_tiles - first)):
+                heapq.heapreplace(cu, cu[0] + w)
+        end = max(end, max(cu))
+    return end
+
+
+def choose_wino_cfg(ksteps, batch, wpad, length, dil, default=None):
+    """Tile shape with the smallest estimated launch time among those the packed weights (cout_pad) allow;
+    the default shape stays unless another one is estimated at least 3 % faster (the model is good to a few
+    per cent; at large batch every shape is within that and the default has the best steady state)."""
+    cands = [cfg for cfg, (bm, _) in _WINO_TILES.items() if wpad % bm == 0]
+    cost = {cfg: wino_launch_cost(ksteps, batch, wpad, length, dil, cfg) for cfg in cands}
+    best = min(cands, key=lambda cfg: cost[cfg])
+    if default in cost and cost[best] > 0.97 * cost[default]:
+        best = default
+    return best, cost[best]
+
+
 # Winograd F(4,3) weight transform G (6 x 3); interpolation points 0, +-1, +-2, inf
 _WINO_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
            [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
@@ -432,11 +483,14 @@ class Vocoder:
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
         def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False, flops=None):
-            if wcfg in (0, 4) and B * len(groups) * (wpad // WINO_BM) * -(-length // 256) < _WINO_SMALL_BLOCKS:
+            if _WINO_AUTO and wcfg in (0, 1, 4, 5):
+                wcfg, _ = choose_wino_cfg([sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg))
+                                           for g in groups], B, wpad, length, dil, default=wcfg)
+            elif wcfg in (0, 4) and B * len(groups) * (wpad // WINO_BM) * -(-length // 256) < _WINO_SMALL_BLOCKS:
                 wcfg = 5            # short clips: 32 x 256 tiles, 2-4x the blocks, each with a 2-4x shorter K loop
-            if wcfg == 0 and B * len(groups) * (wpad // WINO_BM) * -(-length // 512) < 200:
+            if not _WINO_AUTO and wcfg == 0 and B * len(groups) * (wpad // WINO_BM) * -(-length // 512) < 200:
                 wcfg = 4            # too few 512-wide blocks for 256 CUs (first-stage upsampler at batch 1)
-            if wcfg == 0:
+            if not _WINO_AUTO and wcfg == 0:
                 # 64 x 512-output blocks work on one dilation phase each: a short phase (L / d) can leave the last
                 # block mostly empty; the 64 x 256 tile (cfg 4, ~10 % slower per output) then wins
                 lp_ = -(-length // dil)
@@ -591,7 +645,14 @@ class Vocoder:
                     ents = [st["blocks"][j]["c2"][m] for j in order]
                     wbm, wbn = (96, 256) if st["wcfg"] & 1 else (64, 512)
                     fused_blocks = B * (st["wpad"] // wbm) * -(-L // wbn)
-                    if all("u" in e for e in ents) and fused_blocks < _WINO_FUSE_MIN_BLOCKS and self.nk in (2, 3):
+                    unfuse = fused_blocks < _WINO_FUSE_MIN_BLOCKS
+                    if _WINO_AUTO and all("u" in e for e in ents):
+                        # one launch of nk groups + the averaging pass (4 streams of B c L floats) against one
+                        # group with nk K segments: whichever the launch model says fills the CUs better
+                        ks = [c // 16 * -(-st["blocks"][j]["k"] // 3) for j in order]
+                        unfuse = (choose_wino_cfg(ks, B, st["wpad"], L, 1, st["wcfg"])[1] + 4.0 + B * c * L * 16 / 4.0e6
+                                  < choose_wino_cfg([sum(ks)], B, st["wpad"], L, 1, st["wcfg"])[1])
+                    if all("u" in e for e in ents) and unfuse and self.nk in (2, 3):
                         # one group = too few blocks for 256 CUs: run the nk convs as groups and average after
                         res_conv(ents, [T1[j] for j in order], [st["blocks"][j]["k"] for j in order], 1,
                                  [Y[j][m % 2] for j in order], [e["b"] for e in ents], [[xin[j]] for j in order],

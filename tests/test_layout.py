@@ -143,6 +143,24 @@ def test_wino_rule_and_tiles():
     assert V.use_wino(768, 5) and V.use_wino(192, 3) and not V.use_wino(24, 1)
 
 
+def test_wino_tile_choice_follows_the_launch_model():
+    """Plan-time tile choice (vocoder.choose_wino_cfg): only shapes the packed cout_pad allows, small launches
+    go to small tiles, a one-group launch with too few 64 x 512 blocks is cut finer, and at large batch the
+    default shape stays (hysteresis)."""
+    from flowhigh_amd import vocoder as V
+    ks = lambda c: [c // 16 * g for g in (4, 3, 1)]                    # k = 11 / 7 / 3 residual stacks
+    assert V.choose_wino_cfg(ks(768), 1, 768, 500, 1, 0)[0] == 5       # 0.5 s clip: 36 big blocks -> 32 x 256
+    assert V.choose_wino_cfg(ks(96), 1, 96, 120000, 1, 1)[0] == 1      # cout_pad 96: only 96- and 32-row tiles
+    assert V.choose_wino_cfg(ks(64), 1, 64, 240000, 1, 0)[0] in (0, 4, 5)
+    assert V.choose_wino_cfg([sum(ks(192))], 1, 192, 60000, 1, 0)[0] != 0   # 354 blocks = 1.4 rounds of 256 CUs
+    assert V.choose_wino_cfg(ks(384), 32, 384, 20000, 1, 0)[0] == 0
+    for cfg in (0, 1, 4, 5):                                           # cost grows with the work
+        assert V.wino_launch_cost(ks(384), 2, 384, 20000, 1, cfg) > V.wino_launch_cost(ks(384), 1, 384, 20000, 1, cfg)
+    # one block on one CU = its own model time
+    a, b = V._WINO_COST[0]
+    assert abs(V.wino_launch_cost([10], 1, 64, 512, 1, 0) - (a * 10 + b) * (1 + 0.12 / 200)) < 1e-6
+
+
 def test_committed_bench_line_follows_the_contract():
     """profiles/*_bench_line_B1.json is a bench.py output line: the driver's keys, the roofline and cpu_baseline
     objects, and self-consistent numbers."""

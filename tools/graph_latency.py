@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 from flowhigh_amd import FLowHigh, FlowHighSR, synth
 cfg = synth.SYNTH_CFG
 m = FlowHighSR(FLowHigh(synth.make_state_dict(cfg, 0), cfg, "cuda"), torchdiffeq_ode_method="euler", upsampling_method="hip")
-for secs in (0.5, 1.0, 2.0, 10.0):
+for secs in (0.5, 1.0, 2.0, 5.0, 10.0):
     n_in = int(secs * 12000)
     g = m.capture(1, n_in, 12000, 1)
     x = torch.from_numpy(synth.lowres_clip(0, secs, 12000))[None].cuda()
