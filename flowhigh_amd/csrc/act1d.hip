@@ -425,28 +425,44 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(xs + ACT_PPT * tid + 4 * v);
         xv[4 * v] = t4[0]; xv[4 * v + 1] = t4[1]; xv[4 * v + 2] = t4[2]; xv[4 * v + 3] = t4[3];
       }
-      f32x2 zout[ACT_PPT];
+      // all 4 pairs through the branch-free path first (4 independent chains for the scheduler), the test for
+      // huge arguments once per tile: a branch per pair cost ~12 exec-mask instructions each and kept the
+      // chains apart
+      f32x2 zout[ACT_PPT], zf[ACT_PPT], arg[ACT_PPT];
 #pragma unroll
       for (int r = 0; r < ACT_PPT; ++r) {
         f32x2 z = {0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 7; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + 1 + q]), fu2[q], z);
-#if defined(ACT_ABL) && (ACT_ABL & 2)
-        zout[r] = (f32x2){xv[r + 1], xv[r + 2]} * alpha + inv_beta;
-        continue;
-#endif
-        const f32x2 arg = z * alpha;
-#if defined(ACT_ABL) && (ACT_ABL & 1)
-        f32x2 s2 = arg;
-#else
-        f32x2 s2 = sin_squared2(arg);
-        if (__builtin_expect(fabsf(arg[0]) >= 32768.f || fabsf(arg[1]) >= 32768.f, 0)) {
-          s2[0] = sin_squared_slow(arg[0]);
-          s2[1] = sin_squared_slow(arg[1]);
-        }
-#endif
-        zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2, z);
+        zf[r] = z;
+        arg[r] = z * alpha;
       }
+#if defined(ACT_ABL) && (ACT_ABL & 2)
+#pragma unroll
+      for (int r = 0; r < ACT_PPT; ++r) zout[r] = (f32x2){xv[r + 1], xv[r + 2]} * alpha + inv_beta;
+#else
+      f32x2 s2[ACT_PPT];
+      float amax = 0.f;
+#pragma unroll
+      for (int r = 0; r < ACT_PPT; ++r) {
+#if defined(ACT_ABL) && (ACT_ABL & 1)
+        s2[r] = arg[r];
+#else
+        s2[r] = sin_squared2(arg[r]);
+        amax = fmaxf(amax, fmaxf(fabsf(arg[r][0]), fabsf(arg[r][1])));     // (NaN falls through, as sinf(NaN))
+#endif
+      }
+      if (__builtin_expect(amax >= 32768.f, 0)) {
+#pragma unroll 1
+        for (int r = 0; r < ACT_PPT; ++r)
+          if (fabsf(arg[r][0]) >= 32768.f || fabsf(arg[r][1]) >= 32768.f) {
+            s2[r][0] = sin_squared_slow(arg[r][0]);
+            s2[r][1] = sin_squared_slow(arg[r][1]);
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < ACT_PPT; ++r) zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2[r], zf[r]);
+#endif
       f32x4* zw = reinterpret_cast<f32x4*>(zs + 2 * ACT_PPT * tid);
 #pragma unroll
       for (int v = 0; v < ACT_PPT / 2; ++v)
@@ -475,28 +491,33 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
       float out[ACT_PPT];
       const int zbase = 2 * (t0 - 4);
 #pragma unroll
-      for (int r = 0; r < ACT_PPT; ++r) {
-        const int i = i0 + r;
-        float acc = 0.f;
+      for (int r = 0; r < ACT_PPT; ++r) {       // interior form for every output (reads stay inside zs)
 #if defined(ACT_ABL) && (ACT_ABL & 4)
         out[r] = zv[2 * r + 8];
         continue;
 #endif
-        if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {
-          f32x2 a2 = {0.f, 0.f};
+        f32x2 a2 = {0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 7; ++j)
-            a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
-          acc = a2[0] + a2[1];
-        } else if (i < len && o0 < ACT_TT) {
+        for (int j = 0; j < 7; ++j)
+          a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
+        out[r] = a2[0] + a2[1];
+      }
+      // outputs whose taps leave [0, 2L-1] exist only in the first and the last tile(s) of a row (uniform test)
+      if (t0 == 0 || t0 + ACT_TT + 3 > len) {
+#pragma unroll 1
+        for (int r = 0; r < ACT_PPT; ++r) {
+          const int i = i0 + r;
+          if (!(2 * i - 5 >= 0 && 2 * i + 6 <= zlast) && i < len && o0 < ACT_TT) {
+            float acc = 0.f;
 #pragma unroll
-          for (int k = 0; k < 12; ++k) {
-            int m = 2 * i + k - 5;
-            m = m < 0 ? 0 : (m > zlast ? zlast : m);
-            acc = fmaf(zs[m - zbase], fd[k], acc);
+            for (int k = 0; k < 12; ++k) {
+              int m = 2 * i + k - 5;
+              m = m < 0 ? 0 : (m > zlast ? zlast : m);
+              acc = fmaf(zs[m - zbase], fd[k], acc);
+            }
+            out[r] = acc;
           }
         }
-        out[r] = acc;
       }
       if (POUT) {                // natural order through LDS, then 4 consecutive outputs of one phase per thread
         *reinterpret_cast<f32x4*>(ys + o0) = (f32x4){out[0], out[1], out[2], out[3]};
