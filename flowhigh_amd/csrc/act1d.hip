@@ -279,6 +279,10 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float ys[POUT ? ACT_PAIRS : 4];     // outputs of a tile, natural order
+  // filter taps of the current group as the (even, odd) pairs the packed FMAs take: [0..6] up (x 2), [7..13] down;
+  // rewritten (other buffer) when a tile belongs to another group.  Read as LDS broadcasts: as scalar loads they
+  // cost two s_load round trips, ~10 SGPR moves and 8 packed adds per tile.
+  __shared__ __attribute__((aligned(16))) f32x2 taps[2][16];
   const int tid = threadIdx.x;
   const int zlast = 2 * len - 1;
   const long long g0 = (long long)blockIdx.x * ACT_NTILE;
@@ -302,9 +306,23 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   struct Tile {                       // wave-uniform description of one flattened tile
     __amdgpu_buffer_rsrc_t rx, ry;
     const fh_act_group* G;
-    int t0, c;
+    int t0, c, gi;
     float alpha, inv_beta;            // vector loads, requested one tile ahead together with the tile itself
+    f32x2 tap;                        // thread e < 14: tap pair e of the tile's group (loaded only if the group changes)
   };
+  // byte offsets of this thread's tap pair inside fh_act_group (out of range = 0: the unused end taps)
+  unsigned tap_off0, tap_off1;
+  float tap_scale;
+  {
+    const bool up = tid < 7;
+    const int j = up ? tid : tid - 7;
+    const int i0 = up ? 11 - 2 * j : 2 * j - 1, i1 = up ? 12 - 2 * j : 2 * j;
+    const bool v0 = tid < 14 && (up ? j <= 5 : j > 0), v1 = tid < 14 && (up ? j >= 1 : j < 6);
+    const unsigned base = up ? (unsigned)offsetof(fh_act_group, up_taps) : (unsigned)offsetof(fh_act_group, down_taps);
+    tap_off0 = v0 ? base + 4u * (unsigned)i0 : 0x80000000u;
+    tap_off1 = v1 ? base + 4u * (unsigned)i1 : 0x80000000u;
+    tap_scale = up ? 2.f : 1.f;       // (the 2x of UpSample1d folded in: exact)
+  }
   // position of a flattened tile: (tile in row, channel, batch, group); the first one of the block is found by
   // 32-bit divisions, the following ones by carrying (a 64-bit division per tile cost ~400 scalar instructions)
   struct Pos { int tile, c, bb, gi; };
@@ -318,9 +336,10 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     }
     return p;
   };
-  auto tile_of = [&](const Pos& p, bool ok) {
+  auto tile_of = [&](const Pos& p, bool ok, int gi_before) {
     Tile T;
     T.c = p.c;
+    T.gi = p.gi;
     T.G = groups + p.gi;
     const size_t rowi = (size_t)p.bb * channels + p.c;
     T.rx = make_rsrc(uni(T.G->x) + rowi * (size_t)pitch_in, ok ? (unsigned)pitch_in * 4u : 0u);
@@ -331,6 +350,9 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
         make_rsrc(uni(T.G->alpha), (unsigned)channels * 4u), (unsigned)T.c * 4u, 0, 0));
     T.inv_beta = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
         make_rsrc(uni(T.G->inv_beta), (unsigned)channels * 4u), (unsigned)T.c * 4u, 0, 0));
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc((const float*)T.G, p.gi != gi_before ? (unsigned)sizeof(fh_act_group) : 0u);
+    T.tap[0] = tap_scale * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, tap_off0, 0, 0));
+    T.tap[1] = tap_scale * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, tap_off1, 0, 0));
     return T;
   };
   // x[t0 - 8 + 4 f .. + 3] for f = tid, tid + 256 (258 float4 per tile); out of the row -> 0, patched below
@@ -369,15 +391,22 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     pos.gi = uni((int)(gb / (unsigned)batch));
     pos.bb = uni((int)(gb - (unsigned)pos.gi * (unsigned)batch));
   }
-  Tile T = tile_of(pos, true);
+  Tile T = tile_of(pos, true, -1);
+  int tbuf = 0, gi_prev = -1;
   u32x4 cur[2], nxt[2];
   load_tile(T, cur);
 #pragma unroll
   for (int it = 0; it < ACT_NTILE; ++it) {
     const bool ok_n = g0 + it + 1 < total_tiles;
     if (ok_n) pos = pos_next(pos);                            // (past the end: stay on the last tile, zero-sized descriptors)
-    const Tile Tn = tile_of(pos, ok_n);
+    const Tile Tn = tile_of(pos, ok_n, T.gi);
     const fh_act_group& G = *T.G;
+    if (T.gi != gi_prev) {            // first tile of the block or of a group (uniform): publish its taps
+      tbuf ^= 1;                      // (other buffer: waves may still be in phase 3 of the previous tile)
+      if (tid < 14) taps[tbuf][tid] = T.tap;
+    }
+    gi_prev = T.gi;
+    const f32x2* tp = taps[tbuf];
     const float alpha = T.alpha, inv_beta = T.inv_beta;
     if (PIN) {                 // scatter the phase chunks to their natural positions (stride din, odd: conflict free)
       const int tb = T.t0 - 8;
@@ -415,10 +444,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     {
       f32x2 fu2[7];
 #pragma unroll
-      for (int q = -3; q <= 3; ++q) {
-        fu2[q + 3][0] = q <= 2 ? 2.f * G.up_taps[5 - 2 * q] : 0.f;
-        fu2[q + 3][1] = q >= -2 ? 2.f * G.up_taps[6 - 2 * q] : 0.f;
-      }
+      for (int q = 0; q < 7; ++q) fu2[q] = tp[q];
       float xv[ACT_PPT + 8];
 #pragma unroll
       for (int v = 0; v < ACT_PPT / 4 + 2; ++v) {
@@ -471,15 +497,9 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     __syncthreads();
     // phase 3 (as above); every thread computes, invalid outputs get an out-of-range store offset
     {
-      float fd[12];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) fd[k] = G.down_taps[k];
       f32x2 fdp[7];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        fdp[j][0] = j > 0 ? fd[2 * j - 1] : 0.f;
-        fdp[j][1] = j < 6 ? fd[2 * j] : 0.f;
-      }
+      for (int j = 0; j < 7; ++j) fdp[j] = tp[7 + j];
       const int o0 = ACT_PPT * tid;
       const int i0 = t0 + o0;
       float zv[2 * ACT_PPT + 16];
@@ -513,7 +533,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
             for (int k = 0; k < 12; ++k) {
               int m = 2 * i + k - 5;
               m = m < 0 ? 0 : (m > zlast ? zlast : m);
-              acc = fmaf(zs[m - zbase], fd[k], acc);
+              acc = fmaf(zs[m - zbase], G.down_taps[k], acc);
             }
             out[r] = acc;
           }
