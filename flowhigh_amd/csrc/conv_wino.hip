@@ -422,6 +422,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? uni(G->res[0]) + slab : nullptr, nres > 0 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? uni(G->res[1]) + slab : nullptr, nres > 1 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? uni(G->res[2]) + slab : nullptr, nres > 2 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (unsigned)cout * 4u : 0u);
   const bool vec = (pm || (dil == 1 && (len & 3) == 0)) && ostride == 1;   // 4 outputs of a tile = one aligned 16-byte vector
   float* E = lds;                                    // [th][xi][32][W_EP]
 #pragma unroll
@@ -431,6 +432,12 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       __syncthreads();
       // first residual of the vector path: issued here so its latency hides under the LDS exchange
       u32x4 rpre[3];
+      float bpre[3];           // bias of this thread's 3 output rows, same reason (a dependent load per pass otherwise)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int co = co0 + mt * 32 + (((tid + W_THREADS * i) >> 5) & 31);
+        bpre[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, co < cout ? (unsigned)co * 4u : 0x80000000u, 0, 0));
+      }
       if (vec && nres > 0) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -465,7 +472,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           const int co = co0 + mt * 32 + row;
           const int v0 = tb * (4 * W_BT) + (nt * 64 + eh * 32 + col) * 4;   // decimated index of y[0]
           const bool rowok = co < cout;
-          const float bv = (bias && rowok) ? bias[co] : 0.f;
+          const float bv = bpre[i];
           const unsigned rowoff = (unsigned)co * (unsigned)opitch + (pm ? (unsigned)(ph * lp) : 0u);
           if (vec && (v0 + 3) * dil + ph < len) {
             const unsigned off = rowok ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
