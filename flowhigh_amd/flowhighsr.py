@@ -19,6 +19,8 @@ Extensions over the reference (all keyword-only, defaults keep reference behavio
 import json
 from pathlib import Path
 
+import os
+
 import numpy as np
 import torch
 
@@ -157,6 +159,14 @@ class FlowHighSR:
         return cls.from_local(Path(local_path).parent, device, **kwargs)
 
     # ---- host pre-step (flowhighsr.py:59-86) -----------------------------------------------------
+    def _upload(self, t):
+        """Host tensor -> device through pinned staging, asynchronously: a pageable .to(device) blocks the host
+        until everything queued before it on the stream has run, which serialises the host work of the next
+        request with the GPU work of the current one (generate_many / the batching server)."""
+        if t.device.type != "cpu" or self.device.type != "cuda":
+            return t.to(self.device)
+        return t.pin_memory().to(self.device, non_blocking=True)
+
     def _prepare_cond(self, clips, sr, target_sampling_rate):
         """list of 1-D arrays (equal length) -> cond [B, T48] float32 on device, peak-normalised per clip."""
         if target_sampling_rate != 48000:
@@ -178,9 +188,9 @@ class FlowHighSR:
                 cond = scipy.signal.resample_poly(audio, target_sampling_rate, sr)
                 cond = cond / np.max(np.abs(cond))
                 conds.append(torch.tensor(cond).float())
-            return torch.stack(conds).to(self.device)
+            return self._upload(torch.stack(conds))
         if self.upsampling_method == 'hip':
-            x = torch.from_numpy(np.stack([a.astype(np.float32) for a in prepared])).to(self.device)
+            x = self._upload(torch.from_numpy(np.stack([a.astype(np.float32) for a in prepared])))
             return self.resampler(x, sr, target_sampling_rate)
         raise UnboundLocalError(f"cond: unsupported upsampling_method '{self.upsampling_method}'")
 
@@ -260,7 +270,7 @@ class FlowHighSR:
             cond_mel = cond.reshape(batch * n, -1).contiguous()
         if noise is None:
             noise = self._draw_noise(batch, n, generator)
-        noise = noise.to(self.device, torch.float32).reshape(batch * n, -1).contiguous()
+        noise = self._upload(noise.to(torch.float32)).reshape(batch * n, -1).contiguous()
         cut = None
         if cfm_method == 'basic_cfm':
             y0 = noise
@@ -295,11 +305,14 @@ class FlowHighSR:
 
     @torch.no_grad()
     def generate_many(self, clips, sr, target_sampling_rate=48000, timestep=1, *, noise=None, generator=None,
-                      max_batch=64):
+                      max_batch=64, streams=None):
         """Serving-side entry (the gradio caller of app.py:8-26, many requests at once): clips of ANY lengths,
         int16 or float.  Clips of equal length run as one batch (at most max_batch rows), so every result is
         what generate() returns for that clip alone; the prior noise is drawn in the order of `clips`, as a loop
-        over generate() would.  noise: optional list of [1, N_i, n_mels] tensors.  Returns a list of [1, T48_i]."""
+        over generate() would.  noise: optional list of [1, N_i, n_mels] tensors.  Returns a list of [1, T48_i].
+        streams: batches of different lengths are enqueued round-robin on this many HIP streams (default: up to 4;
+        FH_SERVE_STREAMS), so the launches of a short clip - a few dozen blocks each, a fraction of the 256 CUs -
+        overlap with those of the next one; results do not depend on it (no buffer is shared between shapes)."""
         clips = list(clips)
         if noise is None:
             noise = []
@@ -315,14 +328,36 @@ class FlowHighSR:
             key = (int(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a).shape[-1]), tuple(noise[i].shape))
             buckets.setdefault(key, []).append(i)
         out = [None] * len(clips)
-        for idx in buckets.values():
-            for k in range(0, len(idx), max_batch):
-                part = idx[k:k + max_batch]
-                y = self.generate_batch([clips[i] for i in part], sr, target_sampling_rate, timestep,
-                                        noise=torch.cat([noise[i] for i in part], 0))
-                for r, i in enumerate(part):
-                    out[i] = y[r:r + 1].clone()
+        if streams is None:
+            streams = int(os.environ.get("FH_SERVE_STREAMS", "4"))
+        n_streams = max(1, min(int(streams), len(buckets)))
+        main = torch.cuda.current_stream(self.device)
+        side = self._serve_streams(n_streams) if n_streams > 1 else [main]
+        for s_ in side:
+            if s_ is not main:
+                s_.wait_stream(main)
+        for b, idx in enumerate(buckets.values()):
+            st = side[b % len(side)]
+            with torch.cuda.stream(st):
+                for k in range(0, len(idx), max_batch):
+                    part = idx[k:k + max_batch]
+                    y = self.generate_batch([clips[i] for i in part], sr, target_sampling_rate, timestep,
+                                            noise=noise[part[0]] if len(part) == 1 else
+                                            torch.cat([noise[i] for i in part], 0))
+                    for r, i in enumerate(part):
+                        out[i] = y[r:r + 1].clone()
+                        if st is not main:
+                            out[i].record_stream(main)
+        for s_ in side:
+            if s_ is not main:
+                main.wait_stream(s_)
         return out
+
+    def _serve_streams(self, n):
+        pool = getattr(self, "_side_streams", None)
+        if pool is None or len(pool) < n:
+            pool = self._side_streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        return pool[:n]
 
     @torch.no_grad()
     def generate_from_device(self, x, sr, timestep=1, *, noise):

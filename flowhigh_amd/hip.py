@@ -121,15 +121,35 @@ def lib():
     return L
 
 
-class ShapeCache(dict):
-    """Per-shape workspaces / launch plans, bounded: a service that sees many clip lengths must not
-    accumulate a 645 MB vocoder workspace for each of them.  Evicts the least recently used entry
-    (its device memory returns to torch's caching allocator; in-flight kernels are safe because
-    the allocator reuses memory in stream order)."""
+def _tensor_bytes(obj, seen):
+    """Device bytes held by the tensors reachable from a workspace / plan (containers and plain objects)."""
+    if isinstance(obj, torch.Tensor):
+        st = obj.untyped_storage()
+        if st.data_ptr() in seen:
+            return 0
+        seen.add(st.data_ptr())
+        return st.nbytes()
+    if isinstance(obj, dict):
+        return sum(_tensor_bytes(v, seen) for v in obj.values())
+    if isinstance(obj, (list, tuple)):
+        return sum(_tensor_bytes(v, seen) for v in obj)
+    if hasattr(obj, "__dict__") and not isinstance(obj, type):
+        return sum(_tensor_bytes(v, seen) for v in vars(obj).values())
+    return 0
 
-    def __init__(self, max_entries=6):
+
+class ShapeCache(dict):
+    """Per-shape workspaces / launch plans, bounded by bytes and by count: a service sees many clip lengths
+    (a 1 s clip holds ~65 MB of vocoder workspace, a 10 s clip 645 MB, a batch of 32 of them 20 GB) and a
+    rebuilt plan costs 10-20 ms.  Evicts least recently used entries; an eviction waits for the device first
+    (batches of different shapes may be in flight on several streams, generate_many), then the memory returns
+    to torch's caching allocator.  FH_CACHE_GB (default 24) bounds the bytes of EACH cache."""
+
+    def __init__(self, max_entries=64, max_bytes=None):
         super().__init__()
         self.max_entries = max_entries
+        self.max_bytes = int(float(os.environ.get("FH_CACHE_GB", "24")) * 2 ** 30) if max_bytes is None else max_bytes
+        self._bytes = {}
 
     def __getitem__(self, key):
         v = super().pop(key)
@@ -137,8 +157,18 @@ class ShapeCache(dict):
         return v
 
     def __setitem__(self, key, value):
-        if key not in self and len(self) >= self.max_entries:
-            super().pop(next(iter(self)))
+        if key in self:
+            super().pop(key)
+        self._bytes[key] = _tensor_bytes(value, set())
+        total = sum(self._bytes[k] for k in self) + self._bytes[key]
+        synced = False
+        while len(self) and (len(self) >= self.max_entries or total > self.max_bytes):
+            if not synced and torch.cuda.is_available():
+                torch.cuda.synchronize()
+                synced = True
+            old = next(iter(self))
+            total -= self._bytes.pop(old)
+            super().pop(old)
         super().__setitem__(key, value)
 
 

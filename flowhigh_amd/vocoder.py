@@ -13,6 +13,7 @@ Launch structure per stage (13 launches instead of the reference's ~1700 aten ca
   the accumulator and applies "/ num_kernels" (models.py:181-187) in its epilogue.
 """
 import json
+import functools
 import math
 import os
 
@@ -188,6 +189,11 @@ def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32):
 
 
 def choose_wino_cfg(ksteps, batch, wpad, length, dil, default=None):
+    return _choose_wino_cfg(tuple(ksteps), batch, wpad, length, dil, default)
+
+
+@functools.lru_cache(maxsize=4096)
+def _choose_wino_cfg(ksteps, batch, wpad, length, dil, default):
     """Tile shape with the smallest estimated launch time among those the packed weights (cout_pad) allow;
     the default shape stays unless another one is estimated at least 3 % faster (the model is good to a few
     per cent; at large batch every shape is within that and the default has the best steady state)."""

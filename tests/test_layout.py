@@ -161,6 +161,25 @@ def test_wino_tile_choice_follows_the_launch_model():
     assert abs(V.wino_launch_cost([10], 1, 64, 512, 1, 0) - (a * 10 + b) * (1 + 0.12 / 200)) < 1e-6
 
 
+def test_shape_cache_is_bounded_by_bytes_and_count():
+    """hip.ShapeCache: LRU over launch plans / workspaces, bounded by the device bytes they hold."""
+    from flowhigh_amd.hip import ShapeCache
+    c = ShapeCache(max_entries=3, max_bytes=4000)
+    mk = lambda n: dict(a=torch.empty(n, dtype=torch.uint8), keep=[torch.empty(n, dtype=torch.uint8)])
+    c["x"] = mk(500)
+    c["y"] = mk(500)
+    _ = c["x"]                                  # x is now the most recent
+    c["z"] = mk(500)
+    assert list(c) == ["y", "x", "z"]
+    c["w"] = mk(500)                            # count bound: the least recent goes
+    assert list(c) == ["x", "z", "w"]
+    c["big"] = mk(1600)                         # 3200 bytes: only 800 more fit
+    assert list(c) == ["big"] or list(c) == ["w", "big"]
+    assert sum(c._bytes[k] for k in c) <= 4000
+    c["huge"] = mk(5000)                        # larger than the budget: kept alone
+    assert list(c) == ["huge"]
+
+
 def test_committed_bench_line_follows_the_contract():
     """profiles/*_bench_line_B1.json is a bench.py output line: the driver's keys, the roofline and cpu_baseline
     objects, and self-consistent numbers."""

@@ -1,0 +1,37 @@
+"""Serving mix: N clips of random lengths (0.5 .. 4 s, 12 kHz) through generate_many with 1 and with 4 streams.
+python tools/serve_bench.py [n_clips]"""
+import sys, time
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from flowhigh_amd import FLowHigh, FlowHighSR, synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+dev = torch.device("cuda:0")
+cfg = synth.SYNTH_CFG
+model = FlowHighSR(FLowHigh(synth.make_state_dict(cfg, 0), cfg, dev), torchdiffeq_ode_method="euler",
+                   upsampling_method="hip")
+rng = np.random.default_rng(0)
+lens = [int(rng.integers(5, 41)) * 1200 for _ in range(n)]          # multiples of 0.1 s
+clips = [synth.lowres_clip(i, L / 12000, 12000) for i, L in enumerate(lens)]
+noise = [synth.prior_noise(i, L * 4 // 480) for i, L in enumerate(lens)]
+audio_s = sum(lens) / 12000
+ref = None
+for streams in (1, 4, 1, 4):
+    model.generate_many(clips, 12000, noise=noise, streams=streams)           # plans for every shape
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    out = model.generate_many(clips, 12000, noise=noise, streams=streams)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    if ref is None:
+        ref = out
+    same = all(torch.equal(a, b) for a, b in zip(ref, out))
+    print(f"{n} clips, {audio_s:.1f} s of audio, {len(set(lens))} lengths, streams={streams}: {dt * 1e3:7.1f} ms "
+          f"= {audio_s / dt:6.1f} x real time, identical to the first run: {same}")
+if len(sys.argv) > 2:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    model.generate_many(clips, 12000, noise=noise, streams=1)
+    torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
