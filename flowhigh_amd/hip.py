@@ -129,11 +129,14 @@ def _tensor_bytes(obj, seen):
             return 0
         seen.add(st.data_ptr())
         return st.nbytes()
+    if isinstance(obj, (str, bytes, int, float, bool, type(None), type)) or ("id", id(obj)) in seen:
+        return 0
+    seen.add(("id", id(obj)))                   # (cycles, shared sub-objects)
     if isinstance(obj, dict):
         return sum(_tensor_bytes(v, seen) for v in obj.values())
-    if isinstance(obj, (list, tuple)):
+    if isinstance(obj, (list, tuple, set)):
         return sum(_tensor_bytes(v, seen) for v in obj)
-    if hasattr(obj, "__dict__") and not isinstance(obj, type):
+    if hasattr(obj, "__dict__"):
         return sum(_tensor_bytes(v, seen) for v in vars(obj).values())
     return 0
 
