@@ -53,8 +53,9 @@ constexpr int W_RUN = 8;             // n-blocks of a panel that run together on
 //   <2, 2>: 64 x 512 outputs  (C % 64 == 0)        <3, 1>: 96 x 256 outputs  (C = 96)
 //   <2, 1>: 64 x 256 (short dilation phases)      <1, 1>: 32 x 256 (short clips: a launch of a few dozen blocks
 //                                                         is bound by the K loop of ONE block, not by the chip)
-// SUBS = 16-channel chunks per LDS slab buffer: with 2 the block synchronises once per 32 input channels
-// (needs cin % 32 == 0 in every segment; 147 KB of LDS for the <2, 2> tile).
+//   <4, 1>: 128 x 256 (half the B-fragment work per MFMA, twice the weight bytes per block)
+// SUBS = 16-channel chunks per LDS slab buffer; only 1 is instantiated (2 = one block barrier per 32 input
+// channels measured 0 % and its dword loader was never finished for multi-tap-group segments).
 template <int MT, int NT, int SUBS = 1>
 struct WCfg {
   static constexpr int BM = 32 * MT;                    // output channels per block
@@ -605,7 +606,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
 }  // namespace
 
 extern "C" int fh_wino_tile_m(int tile_cfg) {
-  return tile_cfg == 5 ? 32 : tile_cfg == 4 ? 64 : (tile_cfg & ~3) ? -1 : (tile_cfg & 1) ? 96 : 64;
+  return tile_cfg == 6 ? 128 : tile_cfg == 5 ? 32 : tile_cfg == 4 ? 64 : tile_cfg == 1 ? 96 : tile_cfg == 0 ? 64 : -1;
 }
 
 extern "C" int fh_phase_len(int len, int dilation) { return ((len + dilation - 1) / dilation + 3) & ~3; }
@@ -619,10 +620,9 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
   switch (tile_cfg) {
     case 0: return launch_wino<2, 2, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
     case 1: return launch_wino<3, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
-    case 2: return launch_wino<2, 2, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
-    case 3: return launch_wino<3, 1, 2>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
     case 4: return launch_wino<2, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
     case 5: return launch_wino<1, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 6: return launch_wino<4, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
   }
   fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
   return FH_E_ARG;

@@ -151,8 +151,13 @@ _WINO_SMALL_BLOCKS = int(os.environ.get("FH_WINO_SMALL_BLOCKS", "160"))
 _WINO_FUSE_MIN_BLOCKS = int(os.environ.get("FH_WINO_FUSE_MIN_BLOCKS", "200"))
 # Winograd tiles (tile_cfg -> rows x outputs) and their measured block time on one CU: _WINO_COST[cfg] = (a, b),
 # a us per K step (16 input channels x one tap group), b us of prologue + epilogue (tools/wino_cfg_sweep.py)
-_WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256)}
-_WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0)}
+_WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256)}
+_WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0), 6: (2.75, 20.0)}
+# 128-row tiles halve the LDS reads and transform instructions per MFMA (one B fragment feeds 4 MFMAs) but
+# double the weight bytes a block streams: beyond this panel size (6 x 128 rows x K, bytes) a chip full of
+# such blocks thrashes the 4 MB L2s (C = 768: 857 us against 732 us with 64 x 512 tiles)
+_WINO_WIDE_PANEL_MAX = 6 * 2 ** 20
+_WINO_TILES_OFF = {int(v) for v in os.environ.get("FH_WINO_TILES_OFF", "").split(",") if v}    # (A/B experiments)
 _WINO_RUN = 8                      # W_RUN of conv_wino.hip
 _WINO_AUTO = os.environ.get("FH_WINO_AUTO", "1") == "1"
 
@@ -173,6 +178,8 @@ def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32):
     rpp = -(-n_tiles // run_len)
     real = len(panel_w) * n_tiles
     load = 1.12 if real > 200 else 1.0 + 0.12 * real / 200        # blocks run ~12 % slower on a full chip
+    if cfg == 6 and real > 8 * cus_per_xcd and max(ksteps) * 16 * 6 * bm * 4 > _WINO_WIDE_PANEL_MAX:
+        load *= 1.4
     if real > 16384:                                                  # many blocks per CU: throughput bound
         return load * sum(panel_w) * n_tiles / (8 * cus_per_xcd)
     total_runs = len(panel_w) * rpp
@@ -197,7 +204,7 @@ def _choose_wino_cfg(ksteps, batch, wpad, length, dil, default):
     """Tile shape with the smallest estimated launch time among those the packed weights (cout_pad) allow;
     the default shape stays unless another one is estimated at least 3 % faster (the model is good to a few
     per cent; at large batch every shape is within that and the default has the best steady state)."""
-    cands = [cfg for cfg, (bm, _) in _WINO_TILES.items() if wpad % bm == 0]
+    cands = [cfg for cfg, (bm, _) in _WINO_TILES.items() if wpad % bm == 0 and cfg not in _WINO_TILES_OFF]
     cost = {cfg: wino_launch_cost(ksteps, batch, wpad, length, dil, cfg) for cfg in cands}
     best = min(cands, key=lambda cfg: cost[cfg])
     if default in cost and cost[best] > 0.97 * cost[default]:
@@ -212,13 +219,11 @@ WINO_BM = 64
 
 
 def pick_wino_tile(c):
-    """(tile_cfg, cout_pad) of the Winograd kernel: 96-row tiles where they divide c and 64-row tiles do not;
-    + 2 = 32-channel LDS slabs (half the block barriers; FH_WINO_SLAB32=1, measured 0 %: the per-chunk cost is
-    the slab's load / store instructions, not the barrier)."""
-    wide = 2 if c % 32 == 0 and os.environ.get("FH_WINO_SLAB32", "0") == "1" else 0
+    """Default (tile_cfg, cout_pad) of the Winograd kernel: 96-row tiles where they divide c and 64-row tiles do
+    not (the launch plan may pick another shape that divides cout_pad: choose_wino_cfg)."""
     if c % 64 and c % 96 == 0:
-        return 1 + wide, c
-    return 0 + wide, -(-c // WINO_BM) * WINO_BM
+        return 1, c
+    return 0, -(-c // WINO_BM) * WINO_BM
 
 
 def pack_wino_weight(w, cout_pad):

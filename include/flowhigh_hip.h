@@ -131,9 +131,9 @@ typedef struct {
 
 int fh_sizeof_wino_group(void);
 /* tile_cfg: 0 = 64 co x 512 outputs per block, 1 = 96 co x 256 outputs (cout_pad % fh_wino_tile_m == 0);
- * + 2: the same tiles with 32-channel LDS slabs (one block barrier per 32 input channels; every segment's
- * cin % 32 == 0); 4 = 64 co x 256 outputs (short rows: less padding of the last block of a dilation phase);
- * 5 = 32 co x 256 outputs (short clips: more, shorter blocks) */
+ * 4 = 64 co x 256 outputs (short rows: less padding of the last block of a dilation phase);
+ * 5 = 32 co x 256 outputs (short clips: more, shorter blocks); 6 = 128 co x 256 outputs.  Every shape gives the
+ * same bits (same accumulation order); which one is fastest depends on the block count (vocoder.choose_wino_cfg). */
 int fh_wino_tile_m(int tile_cfg);
 /* Phase-major layout of a [B, C, len] tensor for dilation d: every (batch, channel) row holds its d decimated
  * phases one after the other, x[b, c, p + d u] at row + p * fh_phase_len(len, d) + u, row pitch

@@ -131,6 +131,28 @@ def test_conv_wino(c, k, d, L, B):
     del keep
 
 
+@pytest.mark.parametrize("wcfg", [0, 4, 5, 6])
+@pytest.mark.parametrize("k,d,L,pm", [(11, 1, 1000, False), (7, 3, 777, True), (3, 5, 2049, False)])
+def test_conv_wino_every_tile_shape_gives_the_same_bits(wcfg, k, d, L, pm):
+    """The tile shape is a launch-plan choice (vocoder.choose_wino_cfg): all of them accumulate in the same
+    order, so the result must not depend on it - compared bit for bit with the 96 x 256 tile (cfg 1)."""
+    c, B = 384, 2
+    x, w, b = rnd(B, c, L, seed=200), rnd(c, c, k, seed=201, scale=1.0 / (c * k) ** 0.5), rnd(c, seed=202)
+    xd = (V.to_phase_major(x, d) if pm else x).to(DEV)
+    ud, bd = V.pack_wino_weight(w, c).to(DEV), b.to(DEV)
+    outs = []
+    for cfg in (1, wcfg):
+        out = torch.full_like(xd, float("nan"))
+        g = V.make_wino_group([V.make_wino_seg(xd, ud, c, k)], bd, [], out, c, c, L)
+        keep = V.conv_wino([g], B, c, L, d, DEV, cfg, phase_major=pm)
+        torch.cuda.synchronize()
+        outs.append(V.from_phase_major(out.cpu(), d, L) if pm else out.cpu())
+        del keep
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv1d(x.double(), w.double(), b.double(), dilation=d, padding=(k - 1) // 2 * d).float()
+    assert maxdiff(outs[1], ref) <= 6e-5          # |out| ~ 4, K = 384 x 11 terms
+
+
 @pytest.mark.parametrize("c,k,d,L,B", [(64, 11, 3, 1000, 2), (96, 7, 5, 1001, 1), (128, 3, 3, 5000, 1), (64, 7, 5, 23, 2)])
 def test_conv_wino_phase_major(c, k, d, L, B):
     """Dilated Winograd conv on phase-major tensors (contiguous runs per decimated phase)."""

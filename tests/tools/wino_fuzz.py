@@ -27,9 +27,7 @@ for case in range(n_cases):
     ref = ((ref + bias.double().view(1, -1, 1) + sum(r.double() for r in res)) * scale).float()
     wcfg, cpad = V.pick_wino_tile(c)
     if wcfg == 0 and rng.random() < 0.3:
-        wcfg = rng.choice([4, 5])
-    if wcfg in (0, 1) and c % 32 == 0 and rng.random() < 0.2:
-        wcfg += 2
+        wcfg = rng.choice([4, 5, 6] if cpad % 128 == 0 else [4, 5])
     conv = lambda t: (V.to_phase_major(t, d) if pm else t).to(DEV)
     xd = [conv(x) for x in xs]
     rd = [conv(r) for r in res]

@@ -29,7 +29,7 @@ print(f"{'#':>3} {'tile':>8} {'grp':>3} {'cpad':>5} {'n_len':>7} {'blocks':>6} {
 for i, s in enumerate(convs):
     if s[0] == 'wino':
         _, d, ng, cpad, n_len, dil, fl, wcfg, _pm = s
-        bm, bn = (32, 256) if wcfg == 5 else (64, 256) if wcfg == 4 else (96, 256) if wcfg & 1 else (64, 512)
+        bm, bn = (128, 256) if wcfg == 6 else (32, 256) if wcfg == 5 else (64, 256) if wcfg == 4 else (96, 256) if wcfg & 1 else (64, 512)
         blocks = ng * B * (cpad // bm) * -(-(-(-n_len // dil)) // bn) * dil
     else:
         _, d, ng, cpad, n_len, tcfg, ck, fl = s

@@ -36,14 +36,23 @@ def shape(c, L, closing, B=1):
               for i, k in enumerate(KS)]
     dw = hip.to_device_struct_array(gw, DEV)
     row = []
-    for cfg, (bm, bt) in ((0, (64, 512)), (1, (96, 256)), (4, (64, 256)), (5, (32, 256))):
+    ref = None
+    for cfg, (bm, bt) in ((0, (64, 512)), (1, (96, 256)), (4, (64, 256)), (5, (32, 256)), (6, (128, 256))):
+        if wpad % bm:
+            continue
         blocks = B * len(gw) * (wpad // bm) * -(-L // bt)
-        row.append(f"cfg{cfg} {blocks:5d} blk {time_launch(dw, len(gw), B, wpad, L, 1, cfg):7.1f} us")
+        t = time_launch(dw, len(gw), B, wpad, L, 1, cfg)
+        if ref is None:
+            ref = [o.clone() for o in outs]
+        err = max(float((o - r).abs().max()) for o, r in zip(outs, ref))
+        row.append(f"cfg{cfg} {blocks:5d} blk {t:7.1f} us" + (f" (diff {err:.1e})" if cfg else ""))
     print(f"c={c:4d} L={L:6d} {'closing' if closing else 'stack  '} | " + " | ".join(row), flush=True)
 
 
-for secs in (10, 5, 2, 1):
+for secs in (10, 5):
     n = secs * 100
     for c, up in ((768, 5), (384, 20), (192, 60)):
         for closing in (False, True):
             shape(c, n * up, closing)
+shape(768, 5000, False, 8)
+shape(384, 20000, False, 8)
