@@ -306,6 +306,36 @@ def test_act1d_phase_major(L, din, dout):
 
 
 
+@pytest.mark.parametrize("din,dout", [(1, 1), (3, 1), (1, 5)])
+def test_act1d_huge_arguments_take_the_accurate_sine(din, dout):
+    """|x alpha| >= 32768 leaves the range of the kernel's Cody-Waite reduction: those pairs are recomputed
+    with sinf (one test per tile).  A few such samples among ordinary ones, all layouts, vs the oracle
+    (the tolerance is the rounding of the float32 argument itself, ~|arg| 2^-24 per tap)."""
+    B, C, L = 1, 3, 2100
+    filt = synth.kaiser_sinc_filter()
+    x = rnd(B, C, L, seed=190, scale=1.0)
+    for c, t, v in ((0, 7, 3.0e5), (1, 1030, -4.1e4), (2, 2099, 9.9e4), (2, 0, 5.0e4)):
+        x[0, c, t] = v
+    al, be = torch.zeros(C), torch.zeros(C)                   # alpha = beta = 1
+    h = {"activation": "snakebeta", "snake_logscale": True}
+    sd = {"a.act.alpha": al, "a.act.beta": be, "a.upsample.filter": filt, "a.downsample.lowpass.filter": filt}
+    ref = ref_cpu.activation1d(sd, "a.", x, h)
+    p = dict(alpha=torch.ones(C, device=DEV), inv_beta=torch.ones(C, device=DEV) / (1 + 1e-9),
+             up=filt.flatten().tolist(), down=filt.flatten().tolist())
+    xd = (V.to_phase_major(x, din) if din > 1 else x).to(DEV)
+    yd = torch.full((B, C, dout * V.phase_len(L, dout) if dout > 1 else L), float("nan"), device=DEV)
+    keep = V.act1d_grouped([V.make_act_group(xd, yd, p)], B, C, L, DEV, din, dout)
+    torch.cuda.synchronize()
+    got = V.from_phase_major(yd.cpu(), dout, L) if dout > 1 else yd.cpu()
+    big = torch.zeros(B, C, L, dtype=torch.bool)
+    for c, t in ((0, 7), (1, 1030), (2, 2099), (2, 0)):
+        big[0, c, max(0, t - 8):t + 9] = True
+    assert maxdiff(got[~big], ref[~big]) <= 3e-6              # ordinary samples: untouched by the patch
+    assert maxdiff(got[big], ref[big]) <= 0.08                # sin^2 of an argument known to ~0.02 (3e5 x 2^-24 x taps)
+    assert bool(torch.isfinite(got).all())
+    del keep
+
+
 @pytest.mark.parametrize("L", [1, 5, 41, 506, 507, 1500])
 @pytest.mark.parametrize("kind", ["snakebeta_log", "snake_lin"])
 def test_act1d(L, kind):
