@@ -268,7 +268,10 @@ __global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const fh_act_group* 
 // of the flattened (row, tile) space and requests tile i + 1 before it computes tile i.  All global
 // accesses are unconditional buffer operations (invalid = out-of-range offset), so the compiler's
 // s_waitcnt are exact: the wait for the prefetched tile does not drain the stores issued after it.
-constexpr int ACT_NTILE = 4;
+#ifndef ACT_NTILE_N
+#define ACT_NTILE_N 4
+#endif
+constexpr int ACT_NTILE = ACT_NTILE_N;
 
 // PIN / POUT: input / output rows are phase-major for dilation din / dout (see act1d_kernel).
 template <bool VEC, bool PIN, bool POUT>
