@@ -552,6 +552,39 @@ extern "C" int fh_mean_f32(const float* a, const float* b, const float* c, float
   return FH_OK;
 }
 
+// out = (((p0 + p1) + p2) + ...) * scale over up to 12 tensors (split-K partial outputs: fixed order of addition)
+namespace {
+struct SumArgs {
+  const f32x4* p[12];
+  int n;
+};
+__global__ __launch_bounds__(256) void sum_kernel(SumArgs a, f32x4* __restrict__ out, long long n4, float scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = a.p[0][i];
+#pragma unroll
+  for (int k = 1; k < 12; ++k)
+    if (k < a.n) v += a.p[k][i];
+  out[i] = v * scale;
+}
+}  // namespace
+
+extern "C" int fh_sum_f32(const float* const* srcs, int n_srcs, float* out, long long n, float scale, void* stream) {
+  FH_CHECK_ARG(srcs && n_srcs >= 1 && n_srcs <= 12 && out && n > 0 && n % 4 == 0,
+               "fh_sum_f32: bad args (1..12 sources, n a multiple of 4)");
+  SumArgs a;
+  a.n = n_srcs;
+  for (int k = 0; k < 12; ++k) {
+    a.p[k] = (const f32x4*)(k < n_srcs ? srcs[k] : srcs[0]);
+    FH_CHECK_ARG(a.p[k] && (((size_t)a.p[k]) & 15) == 0, "fh_sum_f32: source %d is null or not 16-byte aligned", k);
+  }
+  FH_CHECK_ARG((((size_t)out) & 15) == 0, "fh_sum_f32: out must be 16-byte aligned");
+  hipLaunchKernelGGL(sum_kernel, dim3(fh_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, (f32x4*)out, n / 4,
+                     scale);
+  FH_CHECK_LAUNCH("fh_sum_f32");
+  return FH_OK;
+}
+
 extern "C" int fh_debug_set_wino_trace(void* buf) {
   unsigned long long* p = (unsigned long long*)buf;
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &p, sizeof(p));

@@ -310,9 +310,11 @@ class FlowHighSR:
         int16 or float.  Clips of equal length run as one batch (at most max_batch rows), so every result is
         what generate() returns for that clip alone; the prior noise is drawn in the order of `clips`, as a loop
         over generate() would.  noise: optional list of [1, N_i, n_mels] tensors.  Returns a list of [1, T48_i].
-        streams: batches of different lengths are enqueued round-robin on this many HIP streams (default: up to 4;
-        FH_SERVE_STREAMS), so the launches of a short clip - a few dozen blocks each, a fraction of the 256 CUs -
-        overlap with those of the next one; results do not depend on it (no buffer is shared between shapes)."""
+        streams: batches of different lengths can be enqueued round-robin on several HIP streams (FH_SERVE_STREAMS,
+        default 1), so that the launches of a short clip - a few dozen blocks each, a fraction of the 256 CUs - overlap
+        with those of the next one; results do not depend on it (no buffer is shared between shapes).  Measured on a
+        mix of 0.5-4 s clips: between -15 % and +40 % of the single-stream time from run to run (the host enqueues
+        ~120 launches per clip and is the bottleneck either way), hence off by default."""
         clips = list(clips)
         if noise is None:
             noise = []
@@ -329,7 +331,7 @@ class FlowHighSR:
             buckets.setdefault(key, []).append(i)
         out = [None] * len(clips)
         if streams is None:
-            streams = int(os.environ.get("FH_SERVE_STREAMS", "4"))
+            streams = int(os.environ.get("FH_SERVE_STREAMS", "1"))
         n_streams = max(1, min(int(streams), len(buckets)))
         main = torch.cuda.current_stream(self.device)
         side = self._serve_streams(n_streams) if n_streams > 1 else [main]

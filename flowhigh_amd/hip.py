@@ -66,6 +66,7 @@ _SIGS = {
     "fh_phase_len": [_I, _I],
     "fh_conv_wino_f32": [_P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fh_mean_f32": [_P, _P, _P, _P, C.c_longlong, _F, _P],
+    "fh_sum_f32": [_P, C.c_int, _P, C.c_longlong, _F, _P],
     "fh_debug_set_conv_trace": [_P],
     "fh_debug_set_wino_trace": [_P],
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

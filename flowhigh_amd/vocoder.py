@@ -13,6 +13,7 @@ Launch structure per stage (13 launches instead of the reference's ~1700 aten ca
   the accumulator and applies "/ num_kernels" (models.py:181-187) in its epilogue.
 """
 import json
+import ctypes as C
 import functools
 import math
 import os
@@ -243,9 +244,38 @@ def pack_wino_weight(w, cout_pad):
     return p.contiguous()
 
 
+def _addr(t):
+    """Device address of a tensor, or an address computed by the caller (a channel slice of a batch item)."""
+    return t if isinstance(t, int) else hip.ptr(t)
+
+
+def wino_split_k(ks, c, wpad, length, dil, default_cfg):
+    """Number of input-channel slices (1, 2 or 3) of a residual-stack launch (one group per kernel size in ks)."""
+    return wino_split_steps([c // 16 * -(-k // 3) for k in ks], c, wpad, length, dil, default_cfg)
+
+
+def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg):
+    """Number of input-channel slices (1, 2 or 3) of a Winograd launch whose groups have `ksteps` K steps
+    (cin / 16 x tap groups) each: more than one only where the batch-1 launch model says the blocks are too few and
+    too long (clips under ~2 s); never a function of the batch size, so a clip gives the same bits alone and inside a
+    batch.  FH_WINO_SPLITK=0 switches it off."""
+    if not _WINO_AUTO or os.environ.get("FH_WINO_SPLITK", "1") == "0":
+        return 1
+    base = choose_wino_cfg(ksteps, 1, wpad, length, dil, default_cfg)[1]
+    best, n = base, 1
+    for ns in (2, 3):
+        if cin % (16 * ns):
+            continue
+        cost = choose_wino_cfg([k // ns for k in ksteps for _ in range(ns)], 1, wpad, length, dil,
+                               default_cfg)[1] + 7.0 * len(ksteps)          # + the adds of the partial outputs
+        if cost < 0.85 * base and cost < best:
+            best, n = cost, ns
+    return n
+
+
 def make_wino_seg(x, u, cin, k, center=None):
     s = hip.WinoSeg()
-    s.x, s.u, s.cin, s.ngrp = hip.ptr(x), hip.ptr(u), cin, -(-k // 3)
+    s.x, s.u, s.cin, s.ngrp = _addr(x), _addr(u), cin, -(-k // 3)
     s.center = (k - 1) // 2 if center is None else center
     return s
 
@@ -256,10 +286,10 @@ def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0, stride=
     for i, s in enumerate(sorted(segs, key=lambda s: -s.ngrp)):
         g.seg[i] = s
     g.nseg, g.nres = len(segs), len(res)
-    g.bias = hip.ptr(bias)
+    g.bias = _addr(bias)
     for i, r in enumerate(res):
-        g.res[i] = hip.ptr(r)
-    g.out = hip.ptr(out)
+        g.res[i] = _addr(r)
+    g.out = _addr(out)
     if max(cout * stride, max(s.cin for s in segs)) * length * 4 >= 2 ** 31:
         raise NotImplementedError("per-clip tensor exceeds the 2 GiB range of a buffer descriptor")
     g.cout, g.cout_pad, g.len, g.scale = cout, cpad, length, scale
@@ -474,6 +504,7 @@ class Vocoder:
             return self._plans[key]
         dev = self.device
         B, N = batch, n_frames
+        B_ = B
         f32 = dict(dtype=torch.float32, device=dev)
         steps = []          # (kind, device descriptor tensor, n_groups, args...)
         executed = [0.0]    # FLOPs issued to the matrix cores by all conv launches (Winograd: 1.5 G / k of the algorithmic)
@@ -493,7 +524,8 @@ class Vocoder:
             executed[0] += flops
             (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
 
-        def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False, flops=None):
+        def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False, flops=None, batch=None):
+            B = B_ if batch is None else batch          # (split-K launches carry one group per batch item)
             if _WINO_AUTO and wcfg in (0, 1, 4, 5):
                 wcfg, _ = choose_wino_cfg([sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg))
                                            for g in groups], B, wpad, length, dil, default=wcfg)
@@ -515,11 +547,44 @@ class Vocoder:
             # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
             executed[0] += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
                                for g in groups for i in range(g.nseg))
-            (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm)))
+            (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B))
 
-        def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None, wcfg=0, pm=False):
-            """One launch of the same conv position in the nk AMP blocks (one group per block)."""
-            if all("u" in e for e in ents):
+        parts = []                  # split-K partial outputs, allocated by the first launch that needs them
+
+        def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None, wcfg=0, pm=False,
+                     split=True, defer_sum=False):
+            """One launch of the same conv position in the nk AMP blocks (one group per block).  Returns, per
+            block, the tensors whose sum is the conv's output (more than one: split-K partial outputs that the
+            caller adds, defer_sum)."""
+            nsplit = wino_split_k(ks, c, wpad, L, dil, wcfg) if split and sink is None and all("u" in e for e in ents) else 1
+            if nsplit > 1:
+                # Short clips: a launch of a few dozen blocks is bound by the K loop of ONE block.  The input channels
+                # are cut into nsplit slices, one group each (first slice: bias and residual), and the partial
+                # outputs are added in a fixed order.  Decided from the clip length alone, so a clip gives the same
+                # bits alone and inside a batch; one group per batch item (a slice is not a whole [B, C, L] tensor).
+                if not parts:
+                    parts.append(torch.empty(2 * self.nk, B_ * max_elems, **f32))
+                    keep.append(parts[0])
+                pitch = dil * phase_len(L, dil) if pm else L
+                cs = c // nsplit
+                at = lambda t, b, ch: t.data_ptr() + 4 * (b * c + ch) * pitch
+                groups = []
+                for i, e in enumerate(ents):
+                    for sl in range(nsplit):
+                        dst = outs[i] if sl == 0 else parts[0][2 * i + sl - 1]
+                        for b in range(B_):
+                            seg = make_wino_seg(at(xs_in[i], b, sl * cs), e["u"][sl * cs // 16:], cs, ks[i])
+                            groups.append(make_wino_group([seg], biases[i] if sl == 0 else None,
+                                                          [at(r, b, 0) for r in res[i]] if sl == 0 else [],
+                                                          at(dst, b, 0), c, wpad, L))
+                wino_step(groups, wpad, L, dil, wcfg, None, pm, batch=1,
+                          flops=sum(2.0 * c * c * k * L * B_ for k in ks))
+                pieces = [[outs[i]] + [parts[0][2 * i + sl] for sl in range(nsplit - 1)] for i in range(len(ents))]
+                if not defer_sum:
+                    for i in range(len(ents)):
+                        steps.append(("sum", pieces[i], outs[i], B_ * c * pitch, 1.0))
+                return pieces
+            elif all("u" in e for e in ents):
                 wino_step([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i])], biases[i],
                                            res[i], outs[i], c, wpad, L) for i in range(len(ents))],
                           wpad, L, dil, wcfg, sink, pm)
@@ -530,6 +595,7 @@ class Vocoder:
                     groups.append(make_conv_group([make_conv_seg(xs_in[i], e["w"], c, offs)], biases[i], res[i],
                                                   outs[i], c, cpad, L, L, L))
                 conv_step(groups, cpad, L, tcfg, ck, sink)
+            return [[o] for o in outs]
 
         def act_step(groups, c, length, sink=None, din=1, dout=1):
             d = hip.to_device_struct_array(groups, dev)
@@ -561,11 +627,27 @@ class Vocoder:
             X = view(0)
             S = view(1)
             if st["up_wino"] is not None:
-                groups = [make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"])], st["up_b"], [],
-                                          X, c, st["wpad"], lin, stride=u, phase=r)
-                          for r, ph in enumerate(st["up_wino"])]
-                wino_step(groups, st["wpad"], lin, 1, st["wcfg"],
-                          flops=sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"]))
+                up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
+                nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"],
+                                          st["wpad"], lin, 1, st["wcfg"])
+                if nsplit > 1:              # short clips: input channels in slices, as in res_conv
+                    if not parts:
+                        parts.append(torch.empty(2 * self.nk, B * max_elems, **f32))
+                        keep.append(parts[0])
+                    cs = st["cin"] // nsplit
+                    dsts = [X] + [parts[0][sl] for sl in range(nsplit - 1)]
+                    groups = [make_wino_group([make_wino_seg(cur.data_ptr() + 4 * (b * st["cin"] + sl * cs) * lin,
+                                                             ph["u"][sl * cs // 16:], cs, ph["k"], ph["center"])],
+                                              st["up_b"] if sl == 0 else None, [], dsts[sl].data_ptr() + 4 * b * c * L,
+                                              c, st["wpad"], lin, stride=u, phase=r)
+                              for r, ph in enumerate(st["up_wino"]) for sl in range(nsplit) for b in range(B)]
+                    wino_step(groups, st["wpad"], lin, 1, st["wcfg"], flops=up_flops, batch=1)
+                    steps.append(("sum", dsts, X, B * c * L, 1.0))
+                else:
+                    groups = [make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"])], st["up_b"],
+                                              [], X, c, st["wpad"], lin, stride=u, phase=r)
+                              for r, ph in enumerate(st["up_wino"])]
+                    wino_step(groups, st["wpad"], lin, 1, st["wcfg"], flops=up_flops)
             else:
                 groups = [make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X,
                                            c, cpad, lin, L, lin, stride=u, phase=r)
@@ -661,16 +743,23 @@ class Vocoder:
                         # one launch of nk groups + the averaging pass (4 streams of B c L floats) against one
                         # group with nk K segments: whichever the launch model says fills the CUs better
                         ks = [c // 16 * -(-st["blocks"][j]["k"] // 3) for j in order]
-                        unfuse = (choose_wino_cfg(ks, B, st["wpad"], L, 1, st["wcfg"])[1] + 4.0 + B * c * L * 16 / 4.0e6
-                                  < choose_wino_cfg([sum(ks)], B, st["wpad"], L, 1, st["wcfg"])[1])
+                        # (for ONE clip, whatever the batch: the two forms round differently, and a clip must give
+                        # the same bits alone and inside a batch)
+                        unfuse = (choose_wino_cfg(ks, 1, st["wpad"], L, 1, st["wcfg"])[1] + 4.0 + c * L * 16 / 4.0e6
+                                  < choose_wino_cfg([sum(ks)], 1, st["wpad"], L, 1, st["wcfg"])[1])
                     if all("u" in e for e in ents) and unfuse and self.nk in (2, 3):
                         # one group = too few blocks for 256 CUs: run the nk convs as groups and average after
-                        res_conv(ents, [T1[j] for j in order], [st["blocks"][j]["k"] for j in order], 1,
-                                 [Y[j][m % 2] for j in order], [e["b"] for e in ents], [[xin[j]] for j in order],
-                                 c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
-                        ys = [Y[j][m % 2] for j in range(self.nk)]          # block order = the reference's xs += order
-                        steps.append(("mean", ys[0], ys[1], ys[2] if self.nk == 3 else None, S, B * c * L,
-                                      1.0 / self.nk))
+                        pieces = res_conv(ents, [T1[j] for j in order], [st["blocks"][j]["k"] for j in order], 1,
+                                          [Y[j][m % 2] for j in order], [e["b"] for e in ents], [[xin[j]] for j in order],
+                                          c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"], defer_sum=True)
+                        if len(pieces[0]) > 1:                              # split-K: all partial outputs in one pass
+                            by_block = {j: pieces[n_] for n_, j in enumerate(order)}
+                            steps.append(("sum", [t for j in range(self.nk) for t in by_block[j]], S, B * c * L,
+                                          1.0 / self.nk))
+                        else:
+                            ys = [Y[j][m % 2] for j in range(self.nk)]      # block order = the reference's xs += order
+                            steps.append(("mean", ys[0], ys[1], ys[2] if self.nk == 3 else None, S, B * c * L,
+                                          1.0 / self.nk))
                     elif all("u" in e for e in ents):
                         segs = [make_wino_seg(T1[j], st["blocks"][j]["c2"][m]["u"], c, st["blocks"][j]["k"]) for j in order]
                         wino_step([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, st["wpad"], L,
@@ -719,12 +808,12 @@ class Vocoder:
                 e1.record()
                 timing.append((e0, e1))
         elif s[0] == "wino":
-            _, d, ng, wpad, length, dil, _flops, wcfg, pm = s
+            _, d, ng, wpad, length, dil, _flops, wcfg, pm, bb = s
             timing = self.conv_timing
             if timing is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, B, wpad, length, dil, pm, wcfg, st), "fh_conv_wino_f32")
+            hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, wcfg, st), "fh_conv_wino_f32")
             if timing is not None:
                 e1.record()
                 timing.append((e0, e1))
@@ -732,6 +821,10 @@ class Vocoder:
             _, a, b_, c_, out, n, scale = s
             hip.check(L.fh_mean_f32(a.data_ptr(), b_.data_ptr(), c_.data_ptr() if c_ is not None else None,
                                     out.data_ptr(), n, scale, st), "fh_mean_f32")
+        elif s[0] == "sum":
+            _, srcs, out, n, scale = s
+            arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+            hip.check(L.fh_sum_f32(arr, len(srcs), out.data_ptr(), n, scale, st), "fh_sum_f32")
         elif s[0] == "act":
             _, d, ng, c, length, din, dout = s
             hip.check(L.fh_act1d_grouped_pm_f32(d.data_ptr(), ng, B, c, length, din, dout, st), "fh_act1d_grouped_pm_f32")

@@ -149,6 +149,10 @@ int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int c
  * stages whose closing conv is not fused (too few blocks to fill the chip at batch 1). */
 int fh_mean_f32(const float* a, const float* b, const float* c, float* out, long long n, float scale,
                 void* stream);
+/* out = (((srcs[0] + srcs[1]) + ...) + srcs[n_srcs-1]) * scale, n floats each (n % 4 == 0, 16-byte aligned); srcs is a
+ * HOST array of 1..12 device pointers.  Adds the partial outputs of a conv whose input channels were cut into
+ * slices (one fh_wino_group per slice; short clips, vocoder.wino_split_k) in a fixed order; out may be srcs[0]. */
+int fh_sum_f32(const float* const* srcs, int n_srcs, float* out, long long n, float scale, void* stream);
 
 /* Debug: per-block timeline of the conv kernel.  buf = device array of uint64, buf[0] = record
  * counter (zero it), then 4 words per block {blockIdx | hw_id << 32 | xcc << 56, start, end

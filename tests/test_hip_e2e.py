@@ -236,6 +236,32 @@ def test_baseline_config5_long_clip_multi_nfe():
     assert torch.allclose(out1.abs().amax(dim=1).cpu(), torch.full((2,), 0.99), atol=1e-6)
 
 
+def test_short_clip_split_k_launches(monkeypatch):
+    """Clips under ~2 s: the wide stages cut their input channels into slices (vocoder.wino_split_k) and add the
+    partial outputs with fh_sum_f32.  The plan really does that for a 0.5 s clip, the result matches the oracle
+    (also checked by test_generate_synth_cfg_vs_oracle), it is bit-identical alone and inside a batch, and it
+    agrees with the unsplit launches to rounding."""
+    cfg = synth.SYNTH_CFG
+    m, sd = model_for(cfg, 0, "euler")
+    voc = m.flowhigh.vocoder
+    voc._plans.clear()
+    kinds = [s_[0] for s_ in voc.plan(1, 50)["steps"]]
+    assert kinds.count("sum") >= 5
+    a, b = synth.lowres_clip(70, 0.5, 12000), synth.lowres_clip(71, 0.5, 12000)
+    na, nb = synth.prior_noise(70, 50), synth.prior_noise(71, 50)
+    one = m.generate_batch([a], 12000, 48000, 1, noise=na)
+    two = m.generate_batch([b, a], 12000, 48000, 1, noise=torch.cat([nb, na], 0))
+    assert torch.equal(one[0], two[1])
+    ref = ref_cpu.generate(sd, cfg, a, 12000, na, 1, "euler")
+    assert (one.cpu() - ref).abs().max().item() <= TOL_WAVEFORM
+    monkeypatch.setenv("FH_WINO_SPLITK", "0")
+    voc._plans.clear()
+    assert "sum" not in [s_[0] for s_ in voc.plan(1, 50)["steps"]]
+    plain = m.generate_batch([a], 12000, 48000, 1, noise=na)
+    voc._plans.clear()
+    assert (plain - one).abs().max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("secs,sr_in,B", [(0.05, 12000, 1), (0.113, 16000, 3), (0.31, 8000, 2)])
 def test_short_and_odd_length_clips_vs_oracle(secs, sr_in, B):
     """Few-frame clips, lengths that are not multiples of the hop, the vector width or the tile sizes."""

@@ -28,9 +28,9 @@ tot_f = tot_t = 0.0
 print(f"{'#':>3} {'tile':>8} {'grp':>3} {'cpad':>5} {'n_len':>7} {'blocks':>6} {'GFLOP':>8} {'us':>8} {'TF/s':>7}")
 for i, s in enumerate(convs):
     if s[0] == 'wino':
-        _, d, ng, cpad, n_len, dil, fl, wcfg, _pm = s
+        _, d, ng, cpad, n_len, dil, fl, wcfg, _pm = s[:9]
         bm, bn = (128, 256) if wcfg == 6 else (32, 256) if wcfg == 5 else (64, 256) if wcfg == 4 else (96, 256) if wcfg & 1 else (64, 512)
-        blocks = ng * B * (cpad // bm) * -(-(-(-n_len // dil)) // bn) * dil
+        blocks = ng * s[9] * (cpad // bm) * -(-(-(-n_len // dil)) // bn) * dil
     else:
         _, d, ng, cpad, n_len, tcfg, ck, fl = s
         bm, bn = TILES[tcfg]
