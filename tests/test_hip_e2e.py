@@ -236,6 +236,20 @@ def test_baseline_config5_long_clip_multi_nfe():
     assert torch.allclose(out1.abs().amax(dim=1).cpu(), torch.full((2,), 0.99), atol=1e-6)
 
 
+def test_generate_randomised_shapes_vs_oracle():
+    """tests/tools/e2e_fuzz.py as a test: random clip lengths (0.01-3 s), input rates, batch sizes, solvers and
+    resamplers through the full-width vocoder - every plan-time choice depends on the shape - vs the CPU oracle."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tests" / "tools" / "e2e_fuzz.py"), "12", "3"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "FAIL" not in r.stdout, r.stdout[-2000:]
+    assert "12 cases" in r.stdout
+
+
 def test_short_clip_split_k_launches(monkeypatch):
     """Clips under ~2 s: the wide stages cut their input channels into slices (vocoder.wino_split_k) and add the
     partial outputs with fh_sum_f32.  The plan really does that for a 0.5 s clip, the result matches the oracle
