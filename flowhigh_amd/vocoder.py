@@ -268,7 +268,7 @@ def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg):
             continue
         cost = choose_wino_cfg([k // ns for k in ksteps for _ in range(ns)], 1, wpad, length, dil,
                                default_cfg)[1] + 7.0 * len(ksteps)          # + the adds of the partial outputs
-        if cost < 0.85 * base and cost < best:
+        if cost < float(os.environ.get("FH_WINO_SPLIT_GAIN", "0.95")) * base and cost < best:
             best, n = cost, ns
     return n
 
