@@ -162,6 +162,23 @@ def test_wino_tile_choice_follows_the_launch_model():
     assert abs(V.wino_launch_cost([10], 1, 64, 512, 1, 0) - (a * 10 + b) * (1 + 0.12 / 200)) < 1e-6
 
 
+def test_split_k_is_for_short_clips_only(monkeypatch):
+    """vocoder.wino_split_k: input-channel slices where ONE block's K loop bounds the launch (clips under ~2 s at
+    C = 768), none for the 10 s headline shape; off with FH_WINO_SPLITK=0; never more slices than divide C / 16."""
+    from flowhigh_amd import vocoder as V
+    monkeypatch.delenv("FH_WINO_SPLITK", raising=False)
+    monkeypatch.delenv("FH_WINO_SPLIT_GAIN", raising=False)
+    ks = [11, 7, 3]
+    assert V.wino_split_k(ks, 768, 768, 250, 1, 0) == 3          # 0.5 s clip, first stage
+    assert V.wino_split_k(ks, 768, 768, 500, 1, 0) >= 2          # 1 s
+    for c, up in ((768, 5), (384, 20), (192, 60), (96, 120)):
+        for d in (1, 3, 5):
+            assert V.wino_split_k(ks, c, V.pick_wino_tile(c)[1], 1000 * up, d, V.pick_wino_tile(c)[0]) == 1
+    assert V.wino_split_k(ks, 80, 128, 100, 1, 0) == 1            # 80 / 16 = 5 chunks: neither 2 nor 3 slices
+    monkeypatch.setenv("FH_WINO_SPLITK", "0")
+    assert V.wino_split_k(ks, 768, 768, 250, 1, 0) == 1
+
+
 def test_shape_cache_is_bounded_by_bytes_and_count():
     """hip.ShapeCache: LRU over launch plans / workspaces, bounded by the device bytes they hold."""
     from flowhigh_amd.hip import ShapeCache
