@@ -406,6 +406,39 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __rest
   out[(size_t)b * len + t] = tanhf(acc);
 }
 
+// len % 4 == 0 (rows 16-byte aligned): 4 consecutive outputs per thread from 3 aligned float4 loads per channel
+// (7 taps: x[t-3 .. t+6] lies inside x[t-4 .. t+7]) instead of 7 dword loads per output.
+__global__ __launch_bounds__(256) void conv_post_tanh_vec_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int cin, int len) {
+  extern __shared__ float wl[];   // cin * 7
+  for (int i = threadIdx.x; i < cin * 7; i += 256) wl[i] = w[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= len) return;
+  const float* xb = x + (size_t)b * cin * len;
+  const float b0 = bias[0];
+  f32x4 acc = {b0, b0, b0, b0};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < cin; ++c) {
+    const float* xr = xb + (size_t)c * len + t;
+    const f32x4 lo = t >= 4 ? *reinterpret_cast<const f32x4*>(xr - 4) : zero;
+    const f32x4 mid = *reinterpret_cast<const f32x4*>(xr);
+    const f32x4 hi = t + 4 < len ? *reinterpret_cast<const f32x4*>(xr + 4) : zero;
+    const float v[12] = {lo[0], lo[1], lo[2], lo[3], mid[0], mid[1], mid[2], mid[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int jj = 0; jj < 7; ++jj) {
+      const float wv = wl[c * 7 + jj];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = fmaf(wv, v[r + jj + 1], acc[r]);     // x[t + r + jj - 3] = v[r + jj + 1]
+    }
+  }
+  const f32x4 o = {tanhf(acc[0]), tanhf(acc[1]), tanhf(acc[2]), tanhf(acc[3])};
+  *reinterpret_cast<f32x4*>(out + (size_t)b * len + t) = o;
+}
+
 struct TileInfo { int bm, bn; };
 constexpr TileInfo kTiles[] = {{128, 128}, {192, 128}, {96, 256}, {64, 256}, {32, 512}, {128, 64}, {96, 128}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
@@ -458,9 +491,14 @@ extern "C" int fh_conv_post_tanh_f32(const float* x, const float* w, const float
                                      int batch, int cin, int len, int ksz, void* stream) {
   FH_CHECK_ARG(x && w && bias && out && batch > 0 && cin > 0 && len > 0, "fh_conv_post_tanh_f32: bad args");
   FH_CHECK_ARG((ksz & 1) && ksz <= 15, "fh_conv_post_tanh_f32: ksz %d unsupported", ksz);
-  dim3 grid(fh_cdiv(len, 256), batch);
-  hipLaunchKernelGGL(conv_post_tanh_kernel, grid, dim3(256), cin * ksz * sizeof(float),
-                     (hipStream_t)stream, x, w, bias, out, cin, len, ksz);
+  if (ksz == 7 && len % 4 == 0 && ((((size_t)x) | ((size_t)out)) & 15) == 0) {
+    hipLaunchKernelGGL(conv_post_tanh_vec_kernel, dim3(fh_cdiv(len, 1024), batch), dim3(256), cin * 7 * sizeof(float),
+                       (hipStream_t)stream, x, w, bias, out, cin, len);
+  } else {
+    dim3 grid(fh_cdiv(len, 256), batch);
+    hipLaunchKernelGGL(conv_post_tanh_kernel, grid, dim3(256), cin * ksz * sizeof(float),
+                       (hipStream_t)stream, x, w, bias, out, cin, len, ksz);
+  }
   FH_CHECK_LAUNCH("fh_conv_post_tanh_f32");
   return FH_OK;
 }
