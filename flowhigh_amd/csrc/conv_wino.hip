@@ -47,7 +47,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int W_CK = 16;             // input channels per chunk
 constexpr int W_THREADS = 768;       // 12 waves = 6 transform points x 2 tile halves
 constexpr int W_EP = 33;             // pitch of the epilogue exchange tiles
-constexpr int W_RUN = 8;             // n-blocks of a panel that run together on one XCD
+#ifndef W_RUN_N
+#define W_RUN_N 8
+#endif
+constexpr int W_RUN = W_RUN_N;             // n-blocks of a panel that run together on one XCD
 
 // Wave tile = (32 MT) co x (32 NT) tiles; block tile = (32 MT) co x (64 NT) tiles (256 NT outputs).
 //   <2, 2>: 64 x 512 outputs  (C % 64 == 0)        <3, 1>: 96 x 256 outputs  (C = 96)
