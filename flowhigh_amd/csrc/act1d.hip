@@ -274,10 +274,13 @@ __global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const fh_act_group* 
 constexpr int ACT_NTILE = ACT_NTILE_N;
 
 // PIN / POUT: input / output rows are phase-major for dilation din / dout (see act1d_kernel).
-template <bool VEC, bool PIN, bool POUT>
+// DIL > 0: the dilation of the phase-major side is this compile-time value (3 and 5 are instantiated: the per-tile
+// divisions by it become multiplies); 0: run-time value.
+template <bool VEC, bool PIN, bool POUT, int DIL = 0>
 __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __restrict__ groups, int batch,
                                                           int channels, int len, int tiles_per_row,
-                                                          long long total_tiles, int din, int dout) {
+                                                          long long total_tiles, int din_arg, int dout_arg) {
+  const int din = (DIL > 0 && PIN) ? DIL : din_arg, dout = (DIL > 0 && POUT) ? DIL : dout_arg;
   static_assert(ACT_THREADS == 256 && ACT_PPT == 4, "strip kernel is written for 256 threads x 4 outputs");
   __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
@@ -601,10 +604,22 @@ extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups,
 #define FH_ACT_LAUNCH(V, PI, PO)                                                                              \
   hipLaunchKernelGGL((act1d_strip_kernel<V, PI, PO>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
                      groups, batch, channels, len, tiles, blocks, din, dout)
+#define FH_ACT_LAUNCH_D(PI, PO, D)                                                                            \
+  hipLaunchKernelGGL((act1d_strip_kernel<true, PI, PO, D>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
+                     groups, batch, channels, len, tiles, blocks, din, dout)
     if (din > 1 && dout > 1) FH_ACT_LAUNCH(false, true, true);
-    else if (din > 1) { if (vec) FH_ACT_LAUNCH(true, true, false); else FH_ACT_LAUNCH(false, true, false); }
-    else if (dout > 1) { if (vec) FH_ACT_LAUNCH(true, false, true); else FH_ACT_LAUNCH(false, false, true); }
-    else { if (vec) FH_ACT_LAUNCH(true, false, false); else FH_ACT_LAUNCH(false, false, false); }
+    else if (din > 1) {
+      if (vec && din == 3) FH_ACT_LAUNCH_D(true, false, 3);
+      else if (vec && din == 5) FH_ACT_LAUNCH_D(true, false, 5);
+      else if (vec) FH_ACT_LAUNCH(true, true, false);
+      else FH_ACT_LAUNCH(false, true, false);
+    } else if (dout > 1) {
+      if (vec && dout == 3) FH_ACT_LAUNCH_D(false, true, 3);
+      else if (vec && dout == 5) FH_ACT_LAUNCH_D(false, true, 5);
+      else if (vec) FH_ACT_LAUNCH(true, false, true);
+      else FH_ACT_LAUNCH(false, false, true);
+    } else { if (vec) FH_ACT_LAUNCH(true, false, false); else FH_ACT_LAUNCH(false, false, false); }
+#undef FH_ACT_LAUNCH_D
 #undef FH_ACT_LAUNCH
     FH_CHECK_LAUNCH("fh_act1d_grouped_f32");
     return FH_OK;
