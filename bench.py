@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- headline metric of BASELINE.json on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config {2,4}] [--no-cpu-baseline]
 
 A "step" is one pass of FlowHighSR.generate() over one batch of synthetic clips whose low-rate
 input and prior noise are already resident in HBM (device resampler -> log-mel -> `time_step`
 vector-field evaluations -> BigVGAN -> STFT post-processing), ending with the 48 kHz waveform in HBM.
-Workload at N = 1: BASELINE.json configs[1] (B = 1, one 10 s clip, 12 -> 48 kHz, time_step = 1 euler,
-transformer 2 x 16 x 64, SYNTH-CFG BigVGAN-48k-256band; random-init weights, synthetic audio).
-For N > 1 every rank runs the same per-GPU workload on its own clips (independent clips, no
-data-path collective: weak scaling); launched by torch.distributed.run, one rank per GPU.
 
-Prints ONE JSON line on rank 0.
+--config 2 (default): BASELINE.json configs[1] on every GPU (B = 1, one 10 s clip, 12 -> 48 kHz, time_step = 1
+    euler, transformer 2 x 16 x 64, SYNTH-CFG BigVGAN-48k-256band; random-init weights, synthetic audio).
+    For N > 1 every rank runs that workload on its own clips (independent clips, no data-path collective:
+    weak scaling); after the timed region the clips of all ranks go once through the RCCL scatter / gather path
+    (flowhigh_amd.parallel.generate_sharded) and rank 0 checks the result against its own runs.
+--config 4: BASELINE.json configs[3]: 32 N clips of 10 s, 8 -> 48 kHz, euler x 1, live on rank 0; a step is
+    scatter (RCCL P2P over xGMI) -> generate on every rank -> gather on rank 0 (256 clips over 8 GPUs).
+
+`--gpus N` with N > 1 works both ways: under torch.distributed.run (RANK / WORLD_SIZE in the environment: one
+rank per GPU), or invoked directly, in which case this script starts that launcher as a child process BEFORE
+anything touches a GPU and exits with its code.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -25,18 +34,23 @@ sys.path.insert(0, str(ROOT))
 
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-SECS, SR_IN, STEPS_ODE, METHOD = 10.0, 12000, 1, "euler"
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+SECS, STEPS_ODE, METHOD = 10.0, 1, "euler"
+CONFIGS = {2: dict(sr_in=12000, per_gpu=1, sharded=False, name="BASELINE configs[1]"),
+           4: dict(sr_in=8000, per_gpu=32, sharded=True, name="BASELINE configs[3]")}
+EVENT_EVERY = 8          # HIP events bracket the conv / activation launches of every 8th timed step
 
 
-def cpu_baseline(sd, cfg):
-    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload:
-    one 2 s clip (1/5 of the 10 s clip), same weights, all host threads."""
+def cpu_baseline(sd, cfg, sr_in):
+    """The oracle (CPU restatement, kind 'port') on the metric's own unit of work: ONE 10 s clip of the workload,
+    same weights and path, one warm-up run, then the median of 3.  Bounded: if the warm-up
+    says three more runs would take over ~40 s, a single timed run is reported instead (and said so)."""
     from flowhigh_amd import synth
     from oracle import ref_cpu
-    secs = 2.0
-    audio = synth.lowres_clip(0, secs, SR_IN)
-    noise = synth.prior_noise(0, int(secs * 100))
+    audio = synth.lowres_clip(0, SECS, sr_in)
+    noise = synth.prior_noise(0, int(SECS * 100))
     # torch's intra-op pool degrades badly past a few dozen threads on these small convs (256 threads
     # on the GPU box's host: 50x slower than 16), so the baseline uses at most 16 threads and says so.
     try:
@@ -46,36 +60,51 @@ def cpu_baseline(sd, cfg):
     threads = max(1, min(16, avail))
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
-    ref_cpu.generate(sd, cfg, synth.lowres_clip(1, 0.25, SR_IN), SR_IN, synth.prior_noise(1, 25), STEPS_ODE, METHOD)
-    probe = time.perf_counter() - t0
-    if probe * 8 > 40.0:                    # keep the baseline leg bounded (~10-30 s of CPU work)
-        secs = 0.5
-        audio, noise = synth.lowres_clip(0, secs, SR_IN), synth.prior_noise(0, int(secs * 100))
+    ref_cpu.generate(sd, cfg, audio, sr_in, noise, STEPS_ODE, METHOD)
+    warm = time.perf_counter() - t0
+    runs = 3 if warm * 3 <= 40.0 else 1
     times = []
-    for _ in range(2):
+    for _ in range(runs):
         t0 = time.perf_counter()
-        ref_cpu.generate(sd, cfg, audio, SR_IN, noise, STEPS_ODE, METHOD)
+        ref_cpu.generate(sd, cfg, audio, sr_in, noise, STEPS_ODE, METHOD)
         times.append(time.perf_counter() - t0)
-    return {"value": round(secs / min(times), 4), "unit": "audio-seconds/s", "cores": threads, "kind": "port",
-            "sample": f"one {secs:g} s clip of the 10 s workload, same weights and path, best of 2, "
-                      f"{threads} torch threads of {avail} visible host CPUs"}
+    return {"value": round(SECS / statistics.median(times), 4), "unit": "audio-seconds/s", "cores": threads,
+            "kind": "port",
+            "sample": f"one {SECS:g} s clip = one batch-1 step of this workload, same weights and path, 1 warm-up "
+                      f"({warm:.1f} s) + median of {runs} run(s), {threads} torch threads of {avail} visible host CPUs"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (never exec:
+    nothing here has touched a GPU yet, and nothing will in this process)."""
+    n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="clips per GPU")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 1 for --config 2, 32 for --config 4)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -84,18 +113,35 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from flowhigh_amd import FLowHigh, FlowHighSR, synth
+    from flowhigh_amd import FLowHigh, FlowHighSR, parallel, synth
+    conf = CONFIGS[args.config]
+    sr_in = conf["sr_in"]
     cfg = synth.SYNTH_CFG
     sd = synth.make_state_dict(cfg, 0)
     model = FlowHighSR(FLowHigh(sd, cfg, dev), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
-    B = args.batch
+    B = args.batch if args.batch is not None else conf["per_gpu"]
     n_frames = int(SECS * 100)
-    clips = [synth.lowres_clip(rank * B + i, SECS, SR_IN) for i in range(B)]
-    x = torch.stack([torch.from_numpy(c) for c in clips]).to(dev)
-    noise = torch.cat([synth.prior_noise(rank * B + i, n_frames) for i in range(B)], 0).to(dev).contiguous()
+    n_in, t48 = int(SECS * sr_in), int(SECS * 48000)
 
-    def step():
-        return model.generate_from_device(x, SR_IN, STEPS_ODE, noise=noise)
+    def make_inputs(indices):
+        x = torch.stack([torch.from_numpy(synth.lowres_clip(i, SECS, sr_in)) for i in indices])
+        z = torch.cat([synth.prior_noise(i, n_frames) for i in indices], 0)
+        return x.to(dev), z.to(dev).contiguous()
+
+    def gen(xs, ns):
+        return model.generate_from_device(xs, sr_in, STEPS_ODE, noise=ns)
+
+    if conf["sharded"]:
+        # every clip of the job lives on rank 0; a step scatters them, runs them, gathers the waveforms
+        x_all, z_all = make_inputs(range(world * B)) if rank == 0 else (None, None)
+
+        def step():
+            return parallel.generate_sharded(gen, x_all, z_all, n_in, n_frames, device=dev, n_total=world * B, t48=t48)
+    else:
+        x, z = make_inputs(range(rank * B, rank * B + B))
+
+        def step():
+            return gen(x, z)
 
     def barrier():
         torch.cuda.synchronize()
@@ -106,64 +152,121 @@ def main():
     for _ in range(args.warmup):
         out = step()
     voc = model.flowhigh.vocoder
-    # HIP events bracket every conv launch of every 4th timed step (an event pair costs ~6 us of
-    # stream time; sampling keeps the instrumentation under 0.5 % of the timed region)
-    events, timed_steps = [], 0
+    # HIP events (on the launch stream = torch's current stream) around every conv and every Activation1d launch
+    # of every 8th timed step: an event pair costs ~6 us of stream time, sampling keeps that under 0.5 %
+    conv_ev, act_ev, timed_steps = [], [], 0
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        voc.conv_timing = events if i % 4 == 0 else None
-        timed_steps += i % 4 == 0
+        sampled = i % EVENT_EVERY == 0
+        voc.conv_timing = conv_ev if sampled else None
+        voc.act_timing = act_ev if sampled else None
+        timed_steps += sampled
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    voc.conv_timing = None
-    assert tuple(out.shape) == (B, int(SECS * 48000)) and bool(torch.isfinite(out).all())
+    voc.conv_timing = voc.act_timing = None
+    if not conf["sharded"] or rank == 0:
+        rows = world * B if conf["sharded"] else B
+        assert tuple(out.shape) == (rows, t48) and bool(torch.isfinite(out).all())
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    conv_ms = sum(a.elapsed_time(b) for a, b in events)            # conv launches of the sampled timed steps
-    n_launch = len(events)
-    flops_per_step = voc.conv_flops_per_frame() * n_frames * B
-    avg_launch_s = conv_ms / 1e3 / max(n_launch, 1)
-    flops_per_launch = flops_per_step * timed_steps / max(n_launch, 1)
-    achieved = flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-    # FLOPs the matrix cores execute (the Winograd launches do 1.5 ceil(k/3) instead of k MACs per output)
-    executed = voc.plan(B, n_frames)["conv_executed_flops"] * timed_steps / (conv_ms / 1e3) / 1e12 if conv_ms > 0 else 0.0
+    # ---- the scatter / gather path against rank-0-only runs (outside the timed region) ---------------------------
+    sharded_check = None
+    if world > 1:
+        try:
+            if conf["sharded"]:
+                xa, za, got = x_all, z_all, out
+            else:
+                xa, za = make_inputs(range(world * B)) if rank == 0 else (None, None)
+                got = parallel.generate_sharded(gen, xa, za, n_in, n_frames, device=dev, n_total=world * B, t48=t48)
+            if rank == 0:
+                got = got.clone()
+                same = all(torch.equal(gen(xa[s:s + B], za[s:s + B]), got[s:s + B]) for s in range(0, world * B, B))
+                sharded_check = (f"{world * B} clips over {world} ranks through RCCL scatter/gather: "
+                                 + ("bit-identical to rank-0-only runs" if same else "MISMATCH against rank-0-only runs"))
+                assert same, sharded_check
+        except AssertionError:
+            raise
+        except Exception as e:                   # noqa: BLE001  (report, keep the measured line)
+            sharded_check = f"failed: {type(e).__name__}: {e}"
+
+    # ---- roofline of the dominant kernels ---------------------------------------------------------------------------
+    plan = voc.plan(B, n_frames)
+    conv_ms = sum(a.elapsed_time(b) for a, b in conv_ev)          # conv launches of the sampled timed steps
+    act_ms = sum(a.elapsed_time(b) for a, b in act_ev)
+    n_conv, n_act = len(conv_ev), len(act_ev)
+    conv_s, act_s = conv_ms / 1e3 / max(n_conv, 1), act_ms / 1e3 / max(n_act, 1)
+    # FLOPs the matrix cores execute per launch (Winograd F(4,3): 1.5 ceil(k/3) instead of k MACs per output) and the
+    # direct-form ("algorithmic") FLOPs of the same convs (2 622.6 MFLOP per frame)
+    exec_per_launch = plan["conv_executed_flops"] * timed_steps / max(n_conv, 1)
+    alg_per_launch = voc.conv_flops_per_frame() * n_frames * B * timed_steps / max(n_conv, 1)
+    executed = exec_per_launch / conv_s / 1e12 if conv_s > 0 else 0.0
+    alg_equiv = alg_per_launch / conv_s / 1e12 if conv_s > 0 else 0.0
+    act_bytes_per_launch = plan["act_bytes"] * timed_steps / max(n_act, 1)
+    act_gbs = act_bytes_per_launch / act_s / 1e9 if act_s > 0 else 0.0
 
     if rank == 0:
-        traffic = None
-        pmc = ROOT / "profiles" / "conv_hbm_bytes_per_launch.json"
-        if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get("bytes_per_launch")
+        def pmc(name):
+            f = ROOT / "profiles" / name
+            return json.loads(f.read_text()).get("bytes_per_launch") if f.exists() else None
+        metric = "48 kHz audio-seconds/sec (real-time factor), 12→48 kHz, 10 s clips, 1/2/4/8 MI355X"
+        if args.config == 4:
+            metric = "48 kHz audio-seconds/sec (real-time factor), 8→48 kHz, 10 s clips, clips scattered from / gathered on rank 0"
+        n_clips = world * B
         line = {
-            "metric": "48 kHz audio-seconds/sec (real-time factor), 12->48 kHz, 10 s clips",
-            "value": round(world * B * SECS * args.steps / elapsed, 3),
+            "metric": metric,
+            "value": round(n_clips * SECS * args.steps / elapsed, 3),
             "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"B={B} per GPU x 10 s clip, 12->48 kHz, time_step=1 euler, transformer 2x16x64, "
-                                   "BigVGAN-48k-256band SYNTH-CFG (rates 5,4,3,2,2,2; C0 1536), random-init weights",
-                       "clips_per_gpu": B, "frames_per_clip": n_frames, "parallelism": f"clip-sharded x{world}"},
+            "config": {"workload": f"{conf['name']}: B={B} per GPU x 10 s clip, {sr_in // 1000}->48 kHz, time_step=1 euler, "
+                                   "transformer 2x16x64, BigVGAN-48k-256band SYNTH-CFG (rates 5,4,3,2,2,2; C0 1536), "
+                                   "random-init weights",
+                       "clips_per_gpu": B, "frames_per_clip": n_frames,
+                       "parallelism": (f"{n_clips} clips on rank 0, RCCL P2P scatter -> generate -> gather, x{world}"
+                                       if conf["sharded"] else f"clip-sharded x{world}, no data-path collective"),
+                       "rccl_world_size": world if dist is not None else None,
+                       "sharded_check": sharded_check},
             "roofline": {"bound": "mfma",
-                         "kernel": "conv_wino_kernel + conv_mfma_kernel (all conv launches of BigVGAN)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "note": "achieved = algorithmic (direct-form) FLOPs / time; the Winograd F(4,3) launches "
-                                 "execute fewer: see mfma_executed",
-                         "mfma_executed": round(executed, 2),
-                         "mfma_executed_frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "launches_per_step": n_launch // max(timed_steps, 1),
-                         "avg_launch_us": round(avg_launch_s * 1e6, 2),
-                         "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                         "kernel": "conv_wino_kernel + conv_mfma_kernel (all conv launches of BigVGAN: 97 % of the path's FLOPs)",
+                         "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": pmc("conv_hbm_bytes_per_launch.json"),
+                         "traffic_source": "profiles/conv_hbm_bytes_per_launch.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                           "passes of an earlier run of this command (tools/profile_round.sh), NOT measured "
+                                           "by this run; bytes per conv launch at B = 1",
+                         "note": "achieved = FLOPs issued to the matrix cores (Winograd F(4,3) launches: 1.5 ceil(k/3) MACs per "
+                                 "output and channel pair instead of k) / HIP-event time of the conv launches; "
+                                 "algorithmic_equiv = direct-form FLOPs of the same convs (SURVEY.md 8d) / the same time",
+                         "algorithmic_equiv": round(alg_equiv, 2),
+                         "algorithmic_equiv_frac": round(alg_equiv / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "launches_per_step": n_conv // max(timed_steps, 1),
+                         "avg_launch_us": round(conv_s * 1e6, 2),
+                         "executed_gflop_per_launch": round(exec_per_launch / 1e9, 3),
+                         "algorithmic_gflop_per_launch": round(alg_per_launch / 1e9, 3),
                          "conv_ms_per_step": round(conv_ms / max(timed_steps, 1), 3)},
+            "roofline_hbm": {"bound": "hbm",
+                             "kernel": "act1d_strip_kernel (all Activation1d launches: up2x -> Snake(Beta) -> down2x)",
+                             "achieved": round(act_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(act_gbs / PEAK_HBM_GBS, 4),
+                             "traffic": pmc("act_hbm_bytes_per_launch.json"),
+                             "traffic_source": "profiles/act_hbm_bytes_per_launch.json (rocprofv3 --pmc passes of an earlier "
+                                               "run, as above)",
+                             "note": "achieved = algorithmic bytes (each site reads and writes its [B, C, L] tensor once: "
+                                     "8 B per sample) / HIP-event time of the activation launches",
+                             "launches_per_step": n_act // max(timed_steps, 1),
+                             "avg_launch_us": round(act_s * 1e6, 2),
+                             "algorithmic_mb_per_launch": round(act_bytes_per_launch / 1e6, 2),
+                             "act_ms_per_step": round(act_ms / max(timed_steps, 1), 3)},
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(sd, cfg)
+        if not args.no_cpu_baseline and world == 1 and args.config == 2:
+            line["cpu_baseline"] = cpu_baseline(sd, cfg, sr_in)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

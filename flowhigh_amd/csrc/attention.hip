@@ -23,25 +23,46 @@ namespace {
 constexpr int KP = 68;   // K tile pitch (floats): b128 reads conflict free
 constexpr int VP = 64;
 
-// WAVES = 4, SPLIT = 1: 128 queries per block.  SPLIT = 2 (small grids): 64 queries per block, the two waves of a
-// 32-query tile take alternate 32-key tiles and merge their (max, sum, O) at the end -- twice the waves and half
-// the dependent MFMA chain per wave when there are fewer query tiles than SIMDs (B = 1: 512 tiles, 1024 SIMDs).
+// Every query row is reduced as TWO interleaved online-softmax streams -- stream 0 takes the even 32-key tiles,
+// stream 1 the odd ones -- merged once at the end by merge_streams().  The two kernel shapes differ only in who
+// runs the streams, never in the arithmetic, so a clip gives the same bits whatever else is in the batch:
+//   SPLIT = 2 (small grids): 64 queries per block, the two waves of a 32-query tile take one stream each -- twice
+//                            the waves and half the dependent MFMA chain per wave when there are fewer query tiles
+//                            than SIMDs (B = 1, n = 1000: 512 tiles, 1024 SIMDs);
+//   SPLIT = 1 (large grids): 128 queries per block, every wave runs both streams of its tile one after the other
+//                            (half the K / V staging traffic per query).
+struct Stream {
+  f32x16 o0, o1;
+  float m, l;
+};
+
+__device__ __forceinline__ void merge_streams(Stream& a, const float (&b0)[16], const float (&b1)[16], float mb, float lb) {
+  const float m = fmaxf(a.m, mb);
+  const float c0 = expf(a.m - m), c1 = expf(mb - m);      // exp(-inf) = 0: a stream that saw no key contributes nothing
+  a.l = __fmaf_rn(lb, c1, __fmul_rn(a.l, c0));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    a.o0[r] = __fmaf_rn(b0[r], c1, __fmul_rn(a.o0[r], c0));
+    a.o1[r] = __fmaf_rn(b1[r], c1, __fmul_rn(a.o1[r], c0));
+  }
+}
+
 template <int WAVES, int SPLIT>
-__global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_kernel(const float* __restrict__ qkv,
                                                                float* __restrict__ out, int n, int heads,
                                                                float scale) {
   constexpr int NT = 64 * WAVES;           // threads
-  constexpr int NLD = 512 * SPLIT / NT;    // float4 of K (and of V) staged per thread and iteration
+  constexpr int NLD = 1024 / NT;           // float4 of K (and of V) staged per thread and iteration (64 keys)
   constexpr int KT = 32 * KP, VT = 32 * VP;
-  __shared__ __attribute__((aligned(16))) float Ks[SPLIT * KT];
-  __shared__ __attribute__((aligned(16))) float Vs[SPLIT * VT];
+  __shared__ __attribute__((aligned(16))) float Ks[2 * KT];
+  __shared__ __attribute__((aligned(16))) float Vs[2 * VT];
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int inner = heads * 64;
   const size_t ld = (size_t)3 * inner;
   const float* base = qkv + (size_t)b * n * ld + h * 64;
-  const int qt = wave / SPLIT, sp = wave % SPLIT;      // query tile of the block, key-split index
+  const int qt = wave / SPLIT, sp = wave % SPLIT;      // query tile of the block, stream of this wave (SPLIT = 2)
   const int q0 = blockIdx.x * (32 * WAVES / SPLIT) + qt * 32;
   const int qi = q0 + l31;
 
@@ -54,18 +75,71 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __re
     qf[qq] = v;
   }
 
-  f32x16 o0, o1;
+  constexpr int NS = 3 - SPLIT;            // streams this wave runs: 2 (SPLIT = 1) or 1 (SPLIT = 2)
+  Stream st[NS];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int i = 0; i < NS; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[i].o0[r] = 0.f; st[i].o1[r] = 0.f; }
+    st[i].m = -INFINITY;
+    st[i].l = 0.f;
+  }
 
-  // K / V tiles (512 float4 each) go global -> registers one tile ahead, registers -> LDS at the top of
-  // their own iteration: the loads of tile i + 1 are in flight while tile i is on the matrix cores
+  // one 32-key tile into one stream
+  auto tile = [&](Stream& S, int k0, const float* Kt, const float* Vt) {
+    // S^T tile
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + l31 * KP + 4 * (2 * qq + lh));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[qq][e], s, 0, 0, 0);
+    }
+    // online softmax for this lane's query; key of reg r = k0 + (r&3) + 8 (r>>2) + 4 lh
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = __fmul_rn(s[r], scale);
+      v = key < n ? v : -INFINITY;
+      s[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(S.m, mx);            // finite: every tile has >= 1 valid key
+    const float corr = expf(S.m - m_new);          // exp(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = expf(s[r] - m_new);
+      s[r] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    S.l = __fmaf_rn(S.l, corr, psum);
+    S.m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S.o0[r] *= corr; S.o1[r] *= corr; }
+    // O^T += V^T P^T
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float v0 = Vt[key * VP + l31];
+      const float v1 = Vt[key * VP + 32 + l31];
+      S.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], S.o0, 0, 0, 0);
+      S.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], S.o1, 0, 0, 0);
+    }
+  };
+
+  // K / V tiles (2 x 512 float4 each) go global -> registers one iteration ahead, registers -> LDS at the top
+  // of their own iteration: the loads of the next 64 keys are in flight while these are on the matrix cores
   f32x4 kreg[NLD], vreg[NLD];
   auto load_kv = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int f = tid + NT * i, key = f >> 4, c4 = f & 15;        // key < 32 SPLIT
+      const int f = tid + NT * i, key = f >> 4, c4 = f & 15;        // key < 64
       f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
       if (k0 + key < n) {
         const float* rowp = base + (size_t)(k0 + key) * ld + 4 * c4;
@@ -77,7 +151,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __re
     }
   };
   load_kv(0);
-  for (int kb = 0; kb < n; kb += 32 * SPLIT) {
+  for (int kb = 0; kb < n; kb += 64) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -86,90 +160,46 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const float* __re
       *reinterpret_cast<f32x4*>(Vs + key * VP + 4 * c4) = vreg[i];
     }
     __syncthreads();
-    if (kb + 32 * SPLIT < n) load_kv(kb + 32 * SPLIT);
-    const int k0 = kb + 32 * sp;                 // this wave's key tile of the iteration
-    const float* Kt = Ks + sp * KT;
-    const float* Vt = Vs + sp * VT;
-    if (k0 >= n) continue;                       // (wave-uniform; the barriers above are outside)
-
-    // S^T tile
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int qq = 0; qq < 8; ++qq) {
-      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + l31 * KP + 4 * (2 * qq + lh));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[qq][e], s, 0, 0, 0);
-    }
-
-    // online softmax for this lane's query; key of reg r = k0 + (r&3) + 8 (r>>2) + 4 lh
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float v = s[r] * scale;
-      v = key < n ? v : -INFINITY;
-      s[r] = v;
-      mx = fmaxf(mx, v);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
-    const float corr = expf(m_run - m_new);        // exp(-inf) = 0 on the first tile
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float p = expf(s[r] - m_new);
-      s[r] = p;
-      psum += p;
-    }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * corr + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
-
-    // O^T += V^T P^T
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float v0 = Vt[key * VP + l31];
-      const float v1 = Vt[key * VP + 32 + l31];
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
+    if (kb + 64 < n) load_kv(kb + 64);
+    if constexpr (SPLIT == 2) {
+      const int k0 = kb + 32 * sp;               // this wave's key tile of the iteration
+      if (k0 < n) tile(st[0], k0, Ks + sp * KT, Vs + sp * VT);     // (wave-uniform; the barriers are outside)
+    } else {
+      tile(st[0], kb, Ks, Vs);
+      if (kb + 32 < n) tile(st[1], kb + 32, Ks + KT, Vs + VT);
     }
   }
 
-  if constexpr (SPLIT > 1) {       // merge the key-split partial results into the sp == 0 wave (through the K / V tiles' LDS)
+  if constexpr (SPLIT == 2) {      // stream 1 -> the sp == 0 wave (through the K / V tiles' LDS)
     __syncthreads();
-    float* X = Ks + qt * (34 * 64);              // per query tile: 32 O values + m + l per lane (SPLIT == 2)
-    static_assert(SPLIT <= 2 && (WAVES / SPLIT) * 34 * 64 <= SPLIT * (KT + VT), "exchange area");
+    float* X = Ks + qt * (34 * 64);              // per query tile: 32 O values + m + l per lane
+    static_assert((WAVES / SPLIT) * 34 * 64 <= 2 * (KT + VT), "exchange area");
     if (sp == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { X[r * 64 + lane] = o0[r]; X[(16 + r) * 64 + lane] = o1[r]; }
-      X[32 * 64 + lane] = m_run;
-      X[33 * 64 + lane] = l_run;
+      for (int r = 0; r < 16; ++r) { X[r * 64 + lane] = st[0].o0[r]; X[(16 + r) * 64 + lane] = st[0].o1[r]; }
+      X[32 * 64 + lane] = st[0].m;
+      X[33 * 64 + lane] = st[0].l;
     }
     __syncthreads();
     if (sp != 0) return;
-    const float m1 = X[32 * 64 + lane], l1 = X[33 * 64 + lane];
-    const float m = fmaxf(m_run, m1);
-    const float c0 = expf(m_run - m), c1 = expf(m1 - m);      // exp(-inf) = 0: a wave that saw no key contributes nothing
-    l_run = l_run * c0 + l1 * c1;
+    float b0[16], b1[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] = o0[r] * c0 + X[r * 64 + lane] * c1;
-      o1[r] = o1[r] * c0 + X[(16 + r) * 64 + lane] * c1;
-    }
+    for (int r = 0; r < 16; ++r) { b0[r] = X[r * 64 + lane]; b1[r] = X[(16 + r) * 64 + lane]; }
+    merge_streams(st[0], b0, b1, X[32 * 64 + lane], X[33 * 64 + lane]);
+  } else {
+    float b0[16], b1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { b0[r] = st[NS - 1].o0[r]; b1[r] = st[NS - 1].o1[r]; }
+    merge_streams(st[0], b0, b1, st[NS - 1].m, st[NS - 1].l);
   }
   if (qi < n) {
-    const float inv = 1.f / l_run;
+    const float inv = 1.f / st[0].l;
     float* orow = out + ((size_t)b * n + qi) * inner + h * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       // regs 4g..4g+3 -> d = 8 g + 4 lh + (0..3)
-      f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-      f32x4 c = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+      f32x4 a = {st[0].o0[4 * g] * inv, st[0].o0[4 * g + 1] * inv, st[0].o0[4 * g + 2] * inv, st[0].o0[4 * g + 3] * inv};
+      f32x4 c = {st[0].o1[4 * g] * inv, st[0].o1[4 * g + 1] * inv, st[0].o1[4 * g + 2] * inv, st[0].o1[4 * g + 3] * inv};
       *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * lh) = a;
       *reinterpret_cast<f32x4*>(orow + 32 + 8 * g + 4 * lh) = c;
     }

@@ -43,6 +43,78 @@ def reference_prior_draw(n_frames, n_mels=256, generator=None):
     return t.normal_(generator=generator)
 
 
+def _load_checkpoint(path):
+    """torch.load of a reference checkpoint file.  Only plain state-dict entries are read ('generator', 'model'), so
+    the safe unpickler is enough (`weights_only=True`: a downloaded file cannot run code); a checkpoint that carries
+    arbitrary pickled objects needs the explicit opt-in FH_UNSAFE_LOAD=1."""
+    try:
+        return torch.load(str(path), map_location='cpu', weights_only=True)
+    except Exception as e:                         # noqa: BLE001  (torch raises pickle.UnpicklingError subclasses)
+        if os.environ.get("FH_UNSAFE_LOAD", "0") != "1":
+            raise RuntimeError(f"{path}: cannot be read with weights_only=True ({type(e).__name__}: {e}); "
+                               "set FH_UNSAFE_LOAD=1 to unpickle it anyway (executes code from the file)") from e
+        return torch.load(str(path), map_location='cpu', weights_only=False)
+
+
+def expected_state_keys(vocoder_cfg, depth=2):
+    """Key set of the reference module's state_dict (SURVEY.md 8a "State-dict contract"): what
+    `load_state_dict(strict=True)` (flowhighsr.py:135, cfm_superresolution.py:125-131) accepts, no more, no less."""
+    fh = "flowhigh."
+    keys = [fh + k for k in ("null_cond", "sinu_pos_emb.0.weights", "sinu_pos_emb.1.weight", "sinu_pos_emb.1.bias",
+                             "to_embed.weight", "to_embed.bias", "conv_embed.dw_conv1d.0.weight",
+                             "conv_embed.dw_conv1d.0.bias", "transformer.rotary_emb.inv_freq",
+                             "transformer.final_norm.gamma", "to_pred.weight")]
+    for layer in range(depth):
+        p = f"{fh}transformer.layers.{layer}."
+        for nidx in ("2", "4"):
+            keys += [p + f"{nidx}.{w}.{t}" for w in ("to_gamma", "to_beta") for t in ("weight", "bias")]
+        keys += [p + "3.q_norm.gamma", p + "3.k_norm.gamma", p + "3.to_qkv.weight", p + "3.to_out.weight",
+                 p + "5.0.weight", p + "5.0.bias", p + "5.3.weight", p + "5.3.bias"]
+    cfg = vocoder_cfg
+    beta = cfg["activation"] == "snakebeta"
+
+    def act(name):
+        return [name + "act.alpha"] + ([name + "act.beta"] if beta else []) + \
+               [name + "upsample.filter", name + "downsample.lowpass.filter"]
+
+    keys += [VOC + "conv_pre.weight", VOC + "conv_pre.bias", VOC + "conv_post.weight", VOC + "conv_post.bias"]
+    keys += [VOC + k for k in act("activation_post.")]
+    nk, nm = len(cfg["resblock_kernel_sizes"]), len(cfg["resblock_dilation_sizes"][0])
+    for i in range(len(cfg["upsample_rates"])):
+        keys += [VOC + f"ups.{i}.0.weight", VOC + f"ups.{i}.0.bias"]
+        for j in range(nk):
+            r = VOC + f"resblocks.{i * nk + j}."
+            if str(cfg["resblock"]) == "1":
+                keys += [r + f"{c}.{m}.{t}" for c in ("convs1", "convs2") for m in range(nm) for t in ("weight", "bias")]
+                nact = 2 * nm
+            else:
+                keys += [r + f"convs.{m}.{t}" for m in range(nm) for t in ("weight", "bias")]
+                nact = nm
+            for a in range(nact):
+                keys += [k for k in act(r + f"activations.{a}.")]
+    return keys
+
+
+def check_state_dict_keys(sd, vocoder_cfg, depth=2, only_prefix=None):
+    """load_state_dict(strict=True) semantics on the key set: missing AND unexpected keys raise RuntimeError."""
+    want = expected_state_keys(vocoder_cfg, depth)
+    if only_prefix is not None:
+        want = [k for k in want if k.startswith(only_prefix)]
+    have = set(sd)
+    missing = [k for k in want if k not in have]
+    wset = set(want)
+    unexpected = [k for k in sd if k not in wset]
+    if missing or unexpected:
+        def short(v):
+            return f"{v[:8]}{' ...' if len(v) > 8 else ''}"
+        msg = "Error(s) in loading state_dict:"
+        if missing:
+            msg += f" Missing key(s) in state_dict: {short(missing)}."
+        if unexpected:
+            msg += f" Unexpected key(s) in state_dict: {short(unexpected)}."
+        raise RuntimeError(msg)
+
+
 class GraphedGenerate:
     """One captured generate_from_device call (FlowHighSR.capture)."""
 
@@ -62,6 +134,19 @@ class GraphedGenerate:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = model.generate_from_device(self.x, sr, timestep, noise=self.noise)
+        # The graph holds raw pointers into the per-shape plans / workspaces of the model (vocoder pool and
+        # descriptor arrays, transformer / front-end / post-processing buffers).  Those live in byte-bounded LRU
+        # caches (hip.ShapeCache): keep a strong reference to every entry of this shape, so that an eviction only
+        # drops the cache's reference and replay() never touches memory that went back to the allocator.
+        fh = model.flowhigh
+        n = t48 // 480
+        self._keep = [c.get(k) for c, k in ((fh.net._ws, (batch, n)), (fh.vocoder._plans, (batch, n)),
+                                            (fh.logmel._ws, (batch, t48)),
+                                            (model.postproc._ws, (batch, 480 * n, t48, t48)))]
+        if any(v is None for v in self._keep):
+            raise hip.HipError("capture: a workspace of the captured shape is not in its cache (cache bound too small "
+                               "for this shape: raise FH_CACHE_GB)")
+        self._keep.append(model)
 
     def replay(self):
         self.graph.replay()
@@ -132,7 +217,9 @@ class FlowHighSR:
     def load(self, path, strict=True):
         path = Path(path)
         assert path.exists()
-        pkg = torch.load(str(path), map_location='cpu', weights_only=False)
+        pkg = _load_checkpoint(path)
+        if strict:
+            check_state_dict_keys(pkg['model'], self.flowhigh.vocoder_config)
         self.flowhigh = FLowHigh(pkg['model'], self.flowhigh.vocoder_config, self.device)
         return pkg
 
@@ -140,12 +227,11 @@ class FlowHighSR:
     def from_local(cls, ckpt_dir, device='cuda', **kwargs) -> 'FlowHighSR':
         ckpt_dir = Path(ckpt_dir)
         cfg = json.loads((ckpt_dir / "bigvgan_48khz_256band.json").read_text())
-        gen = torch.load(ckpt_dir / "bigvgan_48khz_256band.pt", map_location='cpu', weights_only=False)['generator']
+        gen = _load_checkpoint(ckpt_dir / "bigvgan_48khz_256band.pt")['generator']
         sd = {VOC + k: v for k, v in fold_weight_norm(gen).items()}            # init_vocoder.py:13-17
-        model = torch.load(ckpt_dir / "FLowHigh_basic_400k.pt", map_location='cpu', weights_only=False)['model']
-        missing = [k for k in sd if k not in model]
-        if missing:       # load_state_dict(strict=True), flowhighsr.py:135
-            raise RuntimeError(f"Missing key(s) in state_dict: {missing[:8]}{' ...' if len(missing) > 8 else ''}")
+        model = _load_checkpoint(ckpt_dir / "FLowHigh_basic_400k.pt")['model']
+        check_state_dict_keys(sd, cfg, only_prefix=VOC)                        # vocoder.load_state_dict (init_vocoder.py:16)
+        check_state_dict_keys(model, cfg)                                      # load_state_dict(strict=True), flowhighsr.py:135
         sd.update(model)                                                       # wrapper checkpoint wins
         dev = device if torch.device(device).type == 'cuda' else 'cuda'        # the reference always .cuda()s
         return cls(flowhigh=FLowHigh(sd, cfg, dev), **kwargs)
@@ -250,6 +336,16 @@ class FlowHighSR:
     @torch.no_grad()
     def sample(self, *, cond=None, cond_mask=None, time_steps=4, cond_scale=1., decode_to_audio=True,
                std_1=None, std_2=None, mel_pp=False, cfm_method=None, noise=None, generator=None):
+        """The reference's `sample` (cfm:162-284).  The returned tensor is the caller's own (the vocoder's output
+        buffer belongs to a per-shape launch plan and is overwritten by the next call of the same shape, so the
+        public entry hands out a copy; `generate*` read the plan's buffer in place)."""
+        out = self._sample(cond=cond, cond_mask=cond_mask, time_steps=time_steps, cond_scale=cond_scale,
+                           decode_to_audio=decode_to_audio, std_1=std_1, std_2=std_2, mel_pp=mel_pp,
+                           cfm_method=cfm_method, noise=noise, generator=generator)
+        return out.clone() if decode_to_audio else out
+
+    def _sample(self, *, cond=None, cond_mask=None, time_steps=4, cond_scale=1., decode_to_audio=True,
+                std_1=None, std_2=None, mel_pp=False, cfm_method=None, noise=None, generator=None):
         if cfm_method not in _CFM_METHODS:
             cfm_method = self.cfm_method
         if cfm_method in _CFM_METHODS[1:]:
@@ -295,12 +391,12 @@ class FlowHighSR:
                        generator=None, return_stages=False):
         cond = self._prepare_cond(list(clips), sr, target_sampling_rate)
         kw = dict(std_2=1.) if self.cfm_method == 'independent_cfm_adaptive' else {}
-        HR_audio = self.sample(cond=cond, time_steps=timestep, cfm_method=self.cfm_method, noise=noise,
-                               generator=generator, **kw)
+        HR_audio = self._sample(cond=cond, time_steps=timestep, cfm_method=self.cfm_method, noise=noise,
+                                generator=generator, **kw)
         HR_audio = HR_audio.squeeze(1)
         out = self.postproc(HR_audio, cond, cond.size(-1), return_cr=return_stages)
         if return_stages:
-            return out[0], dict(cond=cond, wav=HR_audio, cr=out[1])
+            return out[0], dict(cond=cond, wav=HR_audio.clone(), cr=out[1].clone())      # (plan-owned buffers)
         return out
 
     @torch.no_grad()
@@ -310,9 +406,11 @@ class FlowHighSR:
         int16 or float.  Clips of equal length run as one batch (at most max_batch rows), so every result is
         what generate() returns for that clip alone; the prior noise is drawn in the order of `clips`, as a loop
         over generate() would.  noise: optional list of [1, N_i, n_mels] tensors.  Returns a list of [1, T48_i].
-        streams: batches of different lengths can be enqueued round-robin on several HIP streams (FH_SERVE_STREAMS,
+        streams: batches of different FRAME COUNTS can be enqueued round-robin on several HIP streams (FH_SERVE_STREAMS,
         default 1), so that the launches of a short clip - a few dozen blocks each, a fraction of the 256 CUs - overlap
-        with those of the next one; results do not depend on it (no buffer is shared between shapes).  Measured on a
+        with those of the next one.  The per-shape workspaces are keyed by (batch, frames): two input lengths with the
+        same frame count (6000 and 6001 samples at 12 kHz: 50 frames both) share them, so every bucket of one frame
+        count runs on the same stream, in order; results do not depend on `streams`.  Measured on a
         mix of 0.5-4 s clips: between -15 % and +40 % of the single-stream time from run to run (the host enqueues
         ~120 launches per clip and is the bottleneck either way), hence off by default."""
         clips = list(clips)
@@ -332,14 +430,16 @@ class FlowHighSR:
         out = [None] * len(clips)
         if streams is None:
             streams = int(os.environ.get("FH_SERVE_STREAMS", "1"))
-        n_streams = max(1, min(int(streams), len(buckets)))
+        frame_counts = sorted({key[1][1] for key in buckets})
+        n_streams = max(1, min(int(streams), len(frame_counts)))
         main = torch.cuda.current_stream(self.device)
         side = self._serve_streams(n_streams) if n_streams > 1 else [main]
         for s_ in side:
             if s_ is not main:
                 s_.wait_stream(main)
-        for b, idx in enumerate(buckets.values()):
-            st = side[b % len(side)]
+        stream_of = {n: side[i % len(side)] for i, n in enumerate(frame_counts)}
+        for key, idx in buckets.items():
+            st = stream_of[key[1][1]]
             with torch.cuda.stream(st):
                 for k in range(0, len(idx), max_batch):
                     part = idx[k:k + max_batch]
@@ -368,7 +468,7 @@ class FlowHighSR:
         arithmetic as generate_batch with upsampling_method='hip'."""
         cond = self.resampler(x, sr, 48000)
         kw = dict(std_2=1.) if self.cfm_method == 'independent_cfm_adaptive' else {}
-        wav = self.sample(cond=cond, time_steps=timestep, cfm_method=self.cfm_method, noise=noise, **kw).squeeze(1)
+        wav = self._sample(cond=cond, time_steps=timestep, cfm_method=self.cfm_method, noise=noise, **kw).squeeze(1)
         return self.postproc(wav, cond, cond.size(-1))
 
     @torch.no_grad()

@@ -29,13 +29,16 @@ def _p2p(ops):
             w.wait()
 
 
-def scatter_rows(full, shape_tail, dtype, device, src=0, group=None):
+def scatter_rows(full, shape_tail, dtype, device, src=0, group=None, n_total=None):
     """Rank `src` holds `full` [B, *tail]; every rank returns its contiguous row shard.
-    B is broadcast first so that the other ranks can size their buffers."""
+    B is broadcast first so that the other ranks can size their buffers, unless every rank already knows it
+    (`n_total`: no collective and no host sync on the data path then)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    nb = torch.tensor([full.shape[0] if rank == src else 0], dtype=torch.int64, device=device)
-    dist.broadcast(nb, src, group=group)
-    bounds = shard_bounds(int(nb.item()), world)
+    if n_total is None:
+        nb = torch.tensor([full.shape[0] if rank == src else 0], dtype=torch.int64, device=device)
+        dist.broadcast(nb, src, group=group)
+        n_total = int(nb.item())
+    bounds = shard_bounds(int(n_total), world)
     s, e = bounds[rank]
     if rank == src:
         ops = [dist.P2POp(dist.isend, full[a:b].contiguous(), r, group) for r, (a, b) in enumerate(bounds)
@@ -64,20 +67,28 @@ def gather_rows(mine, bounds, dst=0, group=None):
     return out
 
 
-def generate_sharded(generate_fn, x, noise, n_in, n_frames, n_mels=256, src=0, group=None, device=None):
+def generate_sharded(generate_fn, x, noise, n_in, n_frames, n_mels=256, src=0, group=None, device=None,
+                     n_total=None, t48=None):
     """x [B, n_in] low-rate clips and noise [B, n_frames, n_mels] live on rank `src` (None elsewhere).
     `generate_fn(x_shard, noise_shard) -> [b, T48]` runs on every rank (e.g. FlowHighSR.generate_from_device).
-    Returns [B, T48] on rank `src`, None on the others."""
+    Returns [B, T48] on rank `src`, None on the others.
+    n_total (= B) and t48 (output samples per clip), when every rank knows them, remove the two size exchanges
+    and their host syncs: the step is then P2P scatter -> generate -> P2P gather, nothing else.
+    Without an initialised process group (one GPU) the scatter / gather are the identity."""
     device = device if device is not None else (x.device if x is not None else torch.device("cpu"))
+    if not (dist.is_available() and dist.is_initialized()):
+        return generate_fn(x, noise)
     rank = dist.get_rank(group)
-    xs, bounds = scatter_rows(x if rank == src else None, (n_in,), torch.float32, device, src, group)
-    ns, _ = scatter_rows(noise if rank == src else None, (n_frames, n_mels), torch.float32, device, src, group)
+    xs, bounds = scatter_rows(x if rank == src else None, (n_in,), torch.float32, device, src, group, n_total)
+    ns, _ = scatter_rows(noise if rank == src else None, (n_frames, n_mels), torch.float32, device, src, group, n_total)
     out = generate_fn(xs, ns) if xs.shape[0] else torch.empty(0, 0, device=device)
-    if not xs.shape[0]:                      # ranks without clips still take part in the gather
-        t48 = torch.tensor([0], dtype=torch.int64, device=device)
-    else:
-        t48 = torch.tensor([out.shape[1]], dtype=torch.int64, device=device)
-    dist.all_reduce(t48, op=dist.ReduceOp.MAX, group=group)
+    if t48 is None:
+        if not xs.shape[0]:                  # ranks without clips still take part in the gather
+            t = torch.tensor([0], dtype=torch.int64, device=device)
+        else:
+            t = torch.tensor([out.shape[1]], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        t48 = int(t.item())
     if not xs.shape[0]:
-        out = torch.empty(0, int(t48.item()), dtype=torch.float32, device=device)
+        out = torch.empty(0, int(t48), dtype=torch.float32, device=device)
     return gather_rows(out, bounds, src, group)

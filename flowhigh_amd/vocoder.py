@@ -484,6 +484,7 @@ class Vocoder:
         self.post_k = self.post_w.shape[-1]
         self._plans = hip.ShapeCache()
         self.conv_timing = None
+        self.act_timing = None
         self.chain_streams = os.environ.get("FH_VOCODER_STREAMS", "0") == "1"
         self._side = None
 
@@ -780,7 +781,10 @@ class Vocoder:
         act_step([make_act_group(cur, post_t, self.post_act)], c_last, L)
         wav = torch.empty(B, L, **f32)
         steps.append(("post", post_t, wav, c_last, L))
-        p = dict(steps=steps, keep=keep, mel_in=mel_in, wav=wav, B=B, N=N, L=L, conv_executed_flops=executed[0])
+        # algorithmic HBM bytes of the Activation1d launches: every site reads and writes its [B, C, L] tensor once
+        act_bytes = sum(8.0 * s_[2] * B * s_[3] * s_[4] for s_ in steps if s_[0] == "act")
+        p = dict(steps=steps, keep=keep, mel_in=mel_in, wav=wav, B=B, N=N, L=L, conv_executed_flops=executed[0],
+                 act_bytes=act_bytes, n_act=sum(s_[0] == "act" for s_ in steps))
         self._plans[key] = p
         return p
 
@@ -827,7 +831,14 @@ class Vocoder:
             hip.check(L.fh_sum_f32(arr, len(srcs), out.data_ptr(), n, scale, st), "fh_sum_f32")
         elif s[0] == "act":
             _, d, ng, c, length, din, dout = s
+            timing = self.act_timing           # optional list of (start, end) events around activation launches
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             hip.check(L.fh_act1d_grouped_pm_f32(d.data_ptr(), ng, B, c, length, din, dout, st), "fh_act1d_grouped_pm_f32")
+            if timing is not None:
+                e1.record()
+                timing.append((e0, e1))
         else:
             _, x, wav, c, length = s
             hip.check(L.fh_conv_post_tanh_f32(x.data_ptr(), self.post_w.data_ptr(), self.post_b.data_ptr(),

@@ -502,6 +502,24 @@ def test_attention_block(n):
     assert maxdiff(out.view(B, n, D), ref) <= 1e-4       # logits reach +-640: one fp32 ulp there is 6e-5 in the exponent
 
 
+@pytest.mark.parametrize("n,big", [(50, 32), (50, 33), (1000, 4), (1000, 5), (130, 40), (3000, 2)])
+def test_attention_bits_do_not_depend_on_batch(n, big):
+    """fh_attention_f32 picks its kernel shape (one or two waves per query tile) from the GRID size, which
+    depends on the batch: both shapes run the same two-stream arithmetic, so a clip must give the same bits
+    alone and inside a batch on the other side of the threshold (cdiv(n, 128) * heads * batch >= 512)."""
+    H, D = 16, 1024
+    assert -(-n // 128) * H * 1 < 512 <= -(-n // 128) * H * big
+    qkv = rnd(big * n, 3 * D, seed=155 + n, scale=2.0).to(DEV)
+    L = hip.lib()
+    att = torch.empty(big * n, D, device=DEV)
+    hip.check(L.fh_attention_f32(qkv.data_ptr(), att.data_ptr(), big, n, H, 10.0, hip.stream()), "attention")
+    for b in (0, big - 1):
+        one = torch.empty(n, D, device=DEV)
+        q1 = qkv[b * n:(b + 1) * n].contiguous()
+        hip.check(L.fh_attention_f32(q1.data_ptr(), one.data_ptr(), 1, n, H, 10.0, hip.stream()), "attention")
+        assert torch.equal(one, att[b * n:(b + 1) * n])
+
+
 @pytest.mark.parametrize("B,n,t", [(1, 25, 0.0), (2, 200, 0.3)])
 def test_flow_forward(B, n, t):
     from flowhigh_amd.flow import FlowNet

@@ -34,8 +34,11 @@ def _worker(rank, world, port, n_clips, q):
         x = torch.randn(n_clips, 50, generator=g) if rank == 0 else None
         noise = torch.randn(n_clips, 5, 8, generator=g) if rank == 0 else None
         out = parallel.generate_sharded(_fake_generate, x, noise, 50, 5, n_mels=8, device=torch.device("cpu"))
+        # ... and with the sizes known to every rank (bench.py --config 4: no size exchange, no host sync)
+        out2 = parallel.generate_sharded(_fake_generate, x, noise, 50, 5, n_mels=8, device=torch.device("cpu"),
+                                         n_total=n_clips, t48=200)
         if rank == 0:
-            q.put(torch.equal(out, _fake_generate(x, noise)) and out.shape == (n_clips, 200))
+            q.put(torch.equal(out, _fake_generate(x, noise)) and out.shape == (n_clips, 200) and torch.equal(out, out2))
     finally:
         dist.destroy_process_group()
 
@@ -52,6 +55,13 @@ def test_sharded_generate_equals_unsharded(world, n_clips):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_sharded_generate_without_process_group_is_the_identity():
+    g = torch.Generator().manual_seed(1)
+    x, noise = torch.randn(3, 50, generator=g), torch.randn(3, 5, 8, generator=g)
+    assert not dist.is_initialized()
+    assert torch.equal(parallel.generate_sharded(_fake_generate, x, noise, 50, 5, n_mels=8), _fake_generate(x, noise))
 
 
 def test_shard_bounds():

@@ -1,13 +1,16 @@
-"""profiles/conv_hbm_bytes_per_launch.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+"""profiles/{conv,act}_hbm_bytes_per_launch.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
 of `bench.py --steps 1 --warmup 1`.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM):
-counters are in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled."""
+counters are in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled.
+usage: make_traffic_json.py <fetch_dir> <write_dir> <out.json> [conv|act]"""
 import csv, glob, json, sys
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+which = sys.argv[4] if len(sys.argv) > 4 else "conv"
+names = {"conv": ("conv_mfma_kernel", "conv_wino_kernel"), "act": ("act1d_strip_kernel",)}[which]
 def total(d, name):
     f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == name and ('conv_mfma_kernel' in r['Kernel_Name'] or 'conv_wino_kernel' in r['Kernel_Name']):
+        if r['Counter_Name'] == name and any(k in r['Kernel_Name'] for k in names):
             tot += float(r['Counter_Value']); n += 1
     return tot, n
 fs, n1 = total(fetch_dir, 'FETCH_SIZE')
@@ -15,6 +18,8 @@ ws, n2 = total(write_dir, 'WRITE_SIZE')
 assert n1 == n2 and n1 > 0
 per = (2.0 * fs + ws) * 1024.0 / n1
 json.dump({"bytes_per_launch": round(per), "launches": n1, "fetch_kb_raw": fs, "write_kb": ws,
-           "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches, conv_wino_kernel + conv_mfma_kernel dispatches"},
+           "read_bytes_per_launch": round(2.0 * fs * 1024.0 / n1), "write_bytes_per_launch": round(ws * 1024.0 / n1),
+           "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches, " + " + ".join(names) + " dispatches of "
+                      "`bench.py --steps 1 --warmup 1` (B = 1, 10 s clip)"},
           open(out, 'w'), indent=1)
 print(open(out).read())

@@ -1,16 +1,17 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): rocprofv3 kernel stats + the two HBM-traffic PMC passes + the bench line.
 # Outputs under gpurun_out/prof_<tag>/ ; copy the summaries into profiles/ with tools/make_profile_summary.py.
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline > $out/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
-python tools/make_traffic_json.py $out/pmc_fetch $out/pmc_write $out/conv_hbm_bytes_per_launch.json > /dev/null
-cp $out/conv_hbm_bytes_per_launch.json profiles/conv_hbm_bytes_per_launch.json
-python bench.py ${BENCH_ARGS:---steps 20 --warmup 3} 2> $out/bench.err | tail -1 > $out/bench_line.json
+python tools/make_traffic_json.py $out/pmc_fetch $out/pmc_write $out/conv_hbm_bytes_per_launch.json conv > /dev/null
+python tools/make_traffic_json.py $out/pmc_fetch $out/pmc_write $out/act_hbm_bytes_per_launch.json act > /dev/null
+cp $out/conv_hbm_bytes_per_launch.json $out/act_hbm_bytes_per_launch.json profiles/
+python bench.py ${BENCH_ARGS:-} 2> $out/bench.err | tail -1 > $out/bench_line.json
 cp $(ls $out/stats/*/*_kernel_stats.csv | head -1) $out/kernel_stats.csv
 rm -rf $out/stats/*/*_kernel_trace.csv $out/pmc_fetch/*/*agent* $out/pmc_write/*/*agent*
-tail -1 $out/stats.log | cut -c1-200; cat $out/bench_line.json | cut -c1-600
+tail -1 $out/stats.log | cut -c1-200; cat $out/bench_line.json | cut -c1-900
