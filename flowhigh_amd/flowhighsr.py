@@ -140,9 +140,11 @@ class GraphedGenerate:
         # drops the cache's reference and replay() never touches memory that went back to the allocator.
         fh = model.flowhigh
         n = t48 // 480
-        self._keep = [c.get(k) for c, k in ((fh.net._ws, (batch, n)), (fh.vocoder._plans, (batch, n)),
-                                            (fh.logmel._ws, (batch, t48)),
+        self._keep = [c.get(k) for c, k in ((fh.net._ws, (batch, n)), (fh.logmel._ws, (batch, t48)),
                                             (model.postproc._ws, (batch, 480 * n, t48, t48)))]
+        # vocoder: the plan of the clip, or the plans of its time chunks (key (batch, chunk frames, clip frames))
+        voc_plans = [v for k, v in dict.items(fh.vocoder._plans) if k[0] == batch and k[-1] == n]
+        self._keep += voc_plans if voc_plans else [None]
         if any(v is None for v in self._keep):
             raise hip.HipError("capture: a workspace of the captured shape is not in its cache (cache bound too small "
                                "for this shape: raise FH_CACHE_GB)")

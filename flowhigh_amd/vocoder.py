@@ -499,8 +499,13 @@ class Vocoder:
             f += length * st["c"] ** 2 * 2.0 * 2 * self.nm * sum(self.ks)
         return f
 
-    def plan(self, batch, n_frames):
-        key = (batch, n_frames)
+    def plan(self, batch, n_frames, ref_frames=None):
+        """Launch plan for [batch, num_mels, n_frames].  ref_frames: the frame count of the WHOLE clip when this
+        plan runs a time chunk of it (forward_chunked): every choice that changes the order of additions (input-
+        channel slices of short clips, fused / unfused stage-closing conv) is then taken as for the whole clip, so
+        a chunk gives the bits of the unchunked run; tile shapes (no effect on the arithmetic) follow the chunk."""
+        ref_frames = n_frames if ref_frames is None else ref_frames
+        key = (batch, n_frames) if ref_frames == n_frames else (batch, n_frames, ref_frames)
         if key in self._plans:
             return self._plans[key]
         dev = self.device
@@ -552,12 +557,14 @@ class Vocoder:
 
         parts = []                  # split-K partial outputs, allocated by the first launch that needs them
 
+        ref = dict(L=ref_frames)      # stage length of the whole clip (== L unless this plan is a chunk of a longer clip)
+
         def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None, wcfg=0, pm=False,
                      split=True, defer_sum=False):
             """One launch of the same conv position in the nk AMP blocks (one group per block).  Returns, per
             block, the tensors whose sum is the conv's output (more than one: split-K partial outputs that the
             caller adds, defer_sum)."""
-            nsplit = wino_split_k(ks, c, wpad, L, dil, wcfg) if split and sink is None and all("u" in e for e in ents) else 1
+            nsplit = wino_split_k(ks, c, wpad, ref["L"], dil, wcfg) if split and sink is None and all("u" in e for e in ents) else 1
             if nsplit > 1:
                 # Short clips: a launch of a few dozen blocks is bound by the K loop of ONE block.  The input channels
                 # are cut into nsplit slices, one group each (first slice: bias and residual), and the partial
@@ -624,13 +631,14 @@ class Vocoder:
         for i, st in enumerate(self.stages):
             c, u, cpad, tcfg = st["c"], st["u"], st["cpad"], st["tile_cfg"]
             lin, L = L, L * u
+            lin_ref, ref["L"] = ref["L"], ref["L"] * u
             view = lambda idx: pool[idx, :B * c * L].view(B, c, L)
             X = view(0)
             S = view(1)
             if st["up_wino"] is not None:
                 up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
                 nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"],
-                                          st["wpad"], lin, 1, st["wcfg"])
+                                          st["wpad"], lin_ref, 1, st["wcfg"])
                 if nsplit > 1:              # short clips: input channels in slices, as in res_conv
                     if not parts:
                         parts.append(torch.empty(2 * self.nk, B * max_elems, **f32))
@@ -738,7 +746,7 @@ class Vocoder:
                 if last:
                     ents = [st["blocks"][j]["c2"][m] for j in order]
                     wbm, wbn = (96, 256) if st["wcfg"] & 1 else (64, 512)
-                    fused_blocks = B * (st["wpad"] // wbm) * -(-L // wbn)
+                    fused_blocks = B * (st["wpad"] // wbm) * -(-ref["L"] // wbn)
                     unfuse = fused_blocks < _WINO_FUSE_MIN_BLOCKS
                     if _WINO_AUTO and all("u" in e for e in ents):
                         # one launch of nk groups + the averaging pass (4 streams of B c L floats) against one
@@ -746,8 +754,9 @@ class Vocoder:
                         ks = [c // 16 * -(-st["blocks"][j]["k"] // 3) for j in order]
                         # (for ONE clip, whatever the batch: the two forms round differently, and a clip must give
                         # the same bits alone and inside a batch)
-                        unfuse = (choose_wino_cfg(ks, 1, st["wpad"], L, 1, st["wcfg"])[1] + 4.0 + c * L * 16 / 4.0e6
-                                  < choose_wino_cfg([sum(ks)], 1, st["wpad"], L, 1, st["wcfg"])[1])
+                        Lr = ref["L"]
+                        unfuse = (choose_wino_cfg(ks, 1, st["wpad"], Lr, 1, st["wcfg"])[1] + 4.0 + c * Lr * 16 / 4.0e6
+                                  < choose_wino_cfg([sum(ks)], 1, st["wpad"], Lr, 1, st["wcfg"])[1])
                     if all("u" in e for e in ents) and unfuse and self.nk in (2, 3):
                         # one group = too few blocks for 256 CUs: run the nk convs as groups and average after
                         pieces = res_conv(ents, [T1[j] for j in order], [st["blocks"][j]["k"] for j in order], 1,
@@ -788,9 +797,72 @@ class Vocoder:
         self._plans[key] = p
         return p
 
-    def forward(self, mel_bnd):
-        """mel [B, N, num_mels] (token-major, as the sampler produces it) -> wav [B, hop * N]."""
+    # ---- time-chunked execution (streaming / chunked vocoder) ----------------------------------
+    def chunk_geometry(self):
+        """(halo, align) in mel frames for time-chunked execution.
+        halo: how far (in frames, rounded up) a waveform sample looks into the mel: BigVGAN is purely local
+        (bigvgan/models.py:172-194) -- conv_pre 3 taps a side, per stage the transposed conv and three AMP blocks of
+        (anti-aliased activation 6 | conv (k-1)/2 d | activation 6 | conv (k-1)/2) per dilation, then activation +
+        conv_post.  A chunk run with `halo` extra frames on each inner side reproduces the whole-clip values in
+        its middle: the zero / replicate padding of a chunk edge only reaches samples that are thrown away.
+        align: chunk starts are multiples of it, so that every sample keeps its position inside its Winograd
+        F(4,3) tile and its dilation phase at every stage -- the per-sample arithmetic is then the same instruction
+        sequence as in the whole-clip run and the result is bit-identical, not just close."""
+        kmax = max(self.ks)
+        per_stage = sum(12 + (kmax - 1) // 2 * (d + 1) for d in (max(dl[m] for dl in self.dil) for m in range(self.nm)))
+        if self.resblock == "2":
+            per_stage = sum(6 + (kmax - 1) // 2 * d for d in (max(dl[m] for dl in self.dil) for m in range(self.nm)))
+        h = 3.0 + 6.0                                   # conv_post (7 taps) + activation_post, in output samples
+        for i in reversed(range(len(self.rates))):
+            h += per_stage                               # residual stack at this stage's rate
+            h = h / self.rates[i] + self.up_k[i] / self.rates[i] + 1.0     # ... seen from the transposed conv's input
+        h += 3.0                                        # conv_pre
+        align, rate = 4, 1
+        lcm = lambda a, b: a * b // math.gcd(a, b)
+        dl = 1
+        for dils in self.dil:
+            for d in dils:
+                dl = lcm(dl, d)
+        for u in self.rates:
+            align = lcm(align, 4 // math.gcd(4, rate))                      # Winograd transposed conv reads at `rate`
+            rate *= u
+            align = lcm(align, 4 * dl // math.gcd(4 * dl, rate))            # residual stack at `rate` samples per frame
+        halo = -(-int(math.ceil(h)) // align) * align
+        return halo, align
+
+    def forward_chunks(self, mel_bnd, chunk_frames):
+        """Generator over time chunks of forward(mel): yields (first_sample, wav_chunk [B, n_samples]) in order, each
+        chunk bit-identical to the same samples of the whole-clip run; workspace is O(chunk_frames + 2 halo).
+        The yielded tensor is the plan's buffer view: consume (copy) it before the next iteration."""
         B, N, D = mel_bnd.shape
+        halo, align = self.chunk_geometry()
+        step = max(align, chunk_frames // align * align)
+        s = 0
+        while s < N:
+            e = min(N, s + step)
+            a, b = max(0, s - halo), min(N, e + halo)
+            p = self.plan(B, b - a, ref_frames=N)
+            p["mel_in"].copy_(mel_bnd[:, a:b].transpose(1, 2))
+            self.run(p)
+            yield s * self.hop, p["wav"][:, (s - a) * self.hop:(e - a) * self.hop]
+            s = e
+
+    def forward_chunked(self, mel_bnd, chunk_frames, out=None):
+        """forward() in time chunks of `chunk_frames` mel frames: same bits, bounded workspace."""
+        B, N, D = mel_bnd.shape
+        wav = out if out is not None else torch.empty(B, N * self.hop, dtype=torch.float32, device=self.device)
+        for first, w in self.forward_chunks(mel_bnd, chunk_frames):
+            wav[:, first:first + w.shape[1]].copy_(w)
+        return wav
+
+    def forward(self, mel_bnd):
+        """mel [B, N, num_mels] (token-major, as the sampler produces it) -> wav [B, hop * N].  Clips longer than
+        FH_VOCODER_CHUNK_FRAMES (default 6000 = 60 s) run in time chunks of that many frames: same result, the
+        workspace (645 MB per 10 s of audio and clip) stops growing with the clip length."""
+        B, N, D = mel_bnd.shape
+        limit = int(os.environ.get("FH_VOCODER_CHUNK_FRAMES", "6000"))
+        if limit > 0 and N > limit + 2 * self.chunk_geometry()[0]:
+            return self.forward_chunked(mel_bnd, limit)
         p = self.plan(B, N)
         p["mel_in"].copy_(mel_bnd.transpose(1, 2))       # 'b n d -> b d n' (melvoco.py:115); layout only
         self.run(p)

@@ -351,3 +351,20 @@ def test_baseline_config5_batch8_30s_midpoint4():
     """configs[4]: B = 8, 30 s clips, 24 -> 48 kHz, time_step = 4 midpoint (8 transformer evaluations at
     N = 3000)."""
     _batch_case(30.0, 24000, "midpoint", 4, 8, 500)
+
+
+def test_two_minute_clip_runs_through_the_chunked_vocoder(monkeypatch):
+    """A 120 s clip (N = 12 000 frames, app.py:8-26 takes arbitrary uploads): the vocoder runs in 60 s chunks with
+    bounded workspace; forcing smaller chunks gives the same waveform bit for bit."""
+    cfg = synth.SYNTH_CFG
+    m, _ = model_for(cfg, 0, "euler", upsampling="hip")
+    audio = synth.lowres_clip(90, 120.0, 12000)
+    noise = synth.prior_noise(90, 12000)
+    voc = m.flowhigh.vocoder
+    out = m.generate(audio, 12000, 48000, 1, noise=noise).clone()
+    assert tuple(out.shape) == (1, 5760000) and torch.isfinite(out).all()
+    assert abs(out.abs().max().item() - 0.99) <= 1e-6
+    assert any(len(k) == 3 and k[2] == 12000 for k in dict.keys(voc._plans))        # it did run in chunks
+    monkeypatch.setenv("FH_VOCODER_CHUNK_FRAMES", "2400")
+    out2 = m.generate(audio, 12000, 48000, 1, noise=noise)
+    assert torch.equal(out, out2)

@@ -553,6 +553,33 @@ def test_vocoder_forward(cfgname, B, N):
     assert maxdiff(wav, ref) <= 2e-5          # ~110 stacked convs, oracle fp32-vs-fp64 noise is ~1e-6
 
 
+@pytest.mark.parametrize("cfgname,B,N,chunk", [("SYNTH_CFG", 1, 150, 48), ("SYNTH_CFG", 2, 100, 24), ("TINY_CFG", 1, 333, 100),
+                                                 ("TINY_CFG", 3, 77, 12), ("ALT_CFG", 1, 260, 60), ("ALT3_CFG", 1, 130, 36)])
+def test_vocoder_chunked_equals_unchunked_bitwise(cfgname, B, N, chunk):
+    """Time-chunked vocoder (BigVGAN is purely local, bigvgan/models.py:172-194): chunks with fixed
+    halos, aligned so that every sample keeps its Winograd tile position and dilation phase, reproduce the whole-clip
+    run bit for bit -- including the short-clip input-channel slices and fused / unfused closing convs, which are
+    decided for the whole clip's length, not the chunk's."""
+    cfg = getattr(synth, cfgname)
+    sd = synth.make_vocoder_state_dict(cfg, seed=1)
+    voc = V.Vocoder(cfg, sd, DEV)
+    mel = (rnd(B, N, 256, seed=175, scale=2.0) - 3.0).to(DEV)
+    whole = voc.forward(mel).clone()
+    halo, align = voc.chunk_geometry()
+    assert chunk % align == 0 and N > chunk + halo          # really several chunks, inner edges on both sides
+    got = voc.forward_chunked(mel, chunk)
+    assert torch.equal(got, whole)
+    # generator form: chunks arrive in order and tile the waveform
+    pos = 0
+    for first, w in voc.forward_chunks(mel, chunk):
+        assert first == pos and torch.equal(w, whole[:, first:first + w.shape[1]])
+        pos += w.shape[1]
+    assert pos == N * voc.hop
+    # every chunk plan is smaller than the whole-clip plan
+    chunk_plans = [k for k in dict.keys(voc._plans) if len(k) == 3]
+    assert chunk_plans and all(k[1] <= chunk + 2 * halo for k in chunk_plans)
+
+
 @pytest.mark.parametrize("T", [4999, 9600, 12345])
 def test_postprocessing(T):
     from flowhigh_amd.frontend import PostProcessor
