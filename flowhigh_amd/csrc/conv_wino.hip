@@ -344,23 +344,6 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #if defined(WINO_ABL) && (WINO_ABL & 1)           // timing experiment: reads stay, no transform
           bf[nt] = xr[p & 1][0][nt];
           asm volatile("" : "+v"(bf[nt]) : "v"(xr[p & 1][1][nt]), "v"(xr[p & 1][2][nt]), "v"(xr[p & 1][3][nt]));
-#elif defined(WINO_PLAIN_FMA)          // experiment: 8 plain v_fma_f32 instead of 4 packed ones (packed fp32 beside MFMAs)
-          {
-            float b0, b1;
-            const f32x2 x0 = xr[p & 1][0][nt], x1 = xr[p & 1][1][nt], x2 = xr[p & 1][2][nt], x3 = xr[p & 1][3][nt];
-            asm("v_mul_f32 %0, %1, %2" : "=v"(b0) : "s"(bc0), "v"(x0[0]));
-            asm("v_mul_f32 %0, %1, %2" : "=v"(b1) : "s"(bc0), "v"(x0[1]));
-            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(b0) : "s"(bc1), "v"(x1[0]));
-            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(b1) : "s"(bc1), "v"(x1[1]));
-            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(b0) : "s"(bc2), "v"(x2[0]));
-            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(b1) : "s"(bc2), "v"(x2[1]));
-            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(b0) : "s"(bc3), "v"(x3[0]));
-            if (nt + 1 < NT)
-              asm("v_fma_f32 %0, %1, %2, %0" : "+v"(b1) : "s"(bc3), "v"(x3[1]));
-            else
-              asm("v_fma_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(b1) : "s"(bc3), "v"(x3[1]));
-            bf[nt] = (f32x2){b0, b1};
-          }
 #else
           asm("v_pk_mul_f32 %0, %1, %2" : "=v"(bf[nt]) : "s"(c0), "v"(xr[p & 1][0][nt]));
           asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(c1), "v"(xr[p & 1][1][nt]));
