@@ -73,18 +73,34 @@ constexpr int ACT_XF4 = ACT_XS / 4;          // ... as float4s
 // flowhigh_hip.h): element t of a row lives at (t % d) * lp + t / d.  A dilated Winograd conv between two
 // such launches then works on contiguous runs.  Consecutive lanes still touch consecutive t, i.e. d runs of
 // 64 / d contiguous floats per wave instruction.
+// RAGGED (fh_act1d_ragged_f32): every group is one clip's [C, len_g] tensor with its own length (fh_act_group.len);
+// block -> (group, channel, tile) through the groups' tile_base prefix (ascending; one ballot per 64 groups).
+template <bool RAGGED>
 __global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const fh_act_group* __restrict__ groups,
                                                     int batch, int channels, int len,
-                                                    int tiles_per_row, int din, int dout) {
+                                                    int tiles_per_row, int din, int dout, int n_groups) {
   __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
 
-  const int tile = blockIdx.x % tiles_per_row;
-  const int row = blockIdx.x / tiles_per_row;          // (g * batch + b) * channels + c
+  int gsel = 0, local = blockIdx.x;
+  if (RAGGED) {
+    int cnt = 0;
+    for (int base = 0; base < n_groups; base += 64) {
+      const int idx = base + (int)(threadIdx.x & 63);
+      const bool le = idx < n_groups && groups[idx].tile_base <= (int)blockIdx.x;
+      cnt += __popcll(__ballot(le));
+    }
+    gsel = __builtin_amdgcn_readfirstlane(cnt - 1);
+    len = __builtin_amdgcn_readfirstlane(groups[gsel].len);
+    tiles_per_row = (len + ACT_TT - 1) / ACT_TT;
+    local = (int)blockIdx.x - __builtin_amdgcn_readfirstlane(groups[gsel].tile_base);
+  }
+  const int tile = local % tiles_per_row;
+  const int row = local / tiles_per_row;          // (g * batch + b) * channels + c
   const int c = row % channels;
-  const int gb = row / channels;
-  const fh_act_group& G = groups[gb / batch];
-  const int b = gb % batch;
+  const int gb = RAGGED ? gsel : row / channels;
+  const fh_act_group& G = groups[RAGGED ? gsel : gb / batch];
+  const int b = RAGGED ? 0 : gb % batch;
   const int lp_in = ((len + din - 1) / din + 3) & ~3, lp_out = ((len + dout - 1) / dout + 3) & ~3;
   const size_t rowi = (size_t)b * channels + c;
   const float* __restrict__ x = G.x + rowi * (din > 1 ? (size_t)din * lp_in : (size_t)len);
@@ -624,9 +640,22 @@ extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups,
     FH_CHECK_LAUNCH("fh_act1d_grouped_f32");
     return FH_OK;
   }
-  hipLaunchKernelGGL(act1d_kernel, dim3((unsigned)blocks), dim3(ACT_THREADS), 0, (hipStream_t)stream, groups,
-                     batch, channels, len, tiles, din, dout);
+  hipLaunchKernelGGL(act1d_kernel<false>, dim3((unsigned)blocks), dim3(ACT_THREADS), 0, (hipStream_t)stream, groups,
+                     batch, channels, len, tiles, din, dout, n_groups);
   FH_CHECK_LAUNCH("fh_act1d_grouped_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_act_tile_len(void) { return ACT_TT; }
+
+extern "C" int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, int din, int dout,
+                                   long long total_tiles, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && channels > 0 && total_tiles > 0 && total_tiles < (1ll << 31),
+               "fh_act1d_ragged_f32: bad sizes");
+  FH_CHECK_ARG(din >= 1 && dout >= 1 && din <= 64 && dout <= 64, "fh_act1d_ragged_f32: bad dilations %d / %d", din, dout);
+  hipLaunchKernelGGL(act1d_kernel<true>, dim3((unsigned)total_tiles), dim3(ACT_THREADS), 0, (hipStream_t)stream, groups,
+                     1, channels, 0, 1, din, dout, n_groups);
+  FH_CHECK_LAUNCH("fh_act1d_ragged_f32");
   return FH_OK;
 }
 

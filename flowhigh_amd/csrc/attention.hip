@@ -50,7 +50,7 @@ __device__ __forceinline__ void merge_streams(Stream& a, const float (&b0)[16], 
 template <int WAVES, int SPLIT>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_kernel(const float* __restrict__ qkv,
                                                                float* __restrict__ out, int n, int heads,
-                                                               float scale) {
+                                                               float scale, const int* __restrict__ seg) {
   constexpr int NT = 64 * WAVES;           // threads
   constexpr int NLD = 1024 / NT;           // float4 of K (and of V) staged per thread and iteration (64 keys)
   constexpr int KT = 32 * KP, VT = 32 * VP;
@@ -61,7 +61,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
   const int l31 = lane & 31, lh = lane >> 5;
   const int inner = heads * 64;
   const size_t ld = (size_t)3 * inner;
-  const float* base = qkv + (size_t)b * n * ld + h * 64;
+  // ragged batch (fh_attention_seg_f32): clip b is rows [seg[2b], seg[2b] + seg[2b+1]) of the token-major tensors;
+  // its keys are its own rows only (the reference's key mask, attend.py:127-128, for clips packed without padding)
+  size_t row0 = (size_t)b * n;
+  if (seg) {
+    row0 = (size_t)__builtin_amdgcn_readfirstlane(seg[2 * b]);
+    n = __builtin_amdgcn_readfirstlane(seg[2 * b + 1]);
+    if ((int)blockIdx.x * (32 * WAVES / SPLIT) >= n) return;        // (block-uniform: before any barrier)
+  }
+  const float* base = qkv + row0 * ld + h * 64;
   const int qt = wave / SPLIT, sp = wave % SPLIT;      // query tile of the block, stream of this wave (SPLIT = 2)
   const int q0 = blockIdx.x * (32 * WAVES / SPLIT) + qt * 32;
   const int qi = q0 + l31;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
   }
   if (qi < n) {
     const float inv = 1.f / st[0].l;
-    float* orow = out + ((size_t)b * n + qi) * inner + h * 64;
+    float* orow = out + (row0 + qi) * inner + h * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       // regs 4g..4g+3 -> d = 8 g + 4 lh + (0..3)
@@ -208,16 +216,31 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 
 }  // namespace
 
+namespace {
+int launch_attention(const float* qkv, float* out, const int* seg, int batch, int n, int heads, float scale, void* stream) {
+  if ((long long)fh_cdiv(n, 128) * heads * batch >= 512) {
+    dim3 grid(fh_cdiv(n, 128), heads, batch);
+    hipLaunchKernelGGL((attention_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale, seg);
+  } else {
+    dim3 grid(fh_cdiv(n, 64), heads, batch);
+    hipLaunchKernelGGL((attention_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale, seg);
+  }
+  return 0;
+}
+}  // namespace
+
 extern "C" int fh_attention_f32(const float* qkv, float* out, int batch, int n, int heads,
                                 float scale, void* stream) {
   FH_CHECK_ARG(qkv && out && batch > 0 && n > 0 && heads > 0, "fh_attention_f32: bad args");
-  if ((long long)fh_cdiv(n, 128) * heads * batch >= 512) {
-    dim3 grid(fh_cdiv(n, 128), heads, batch);
-    hipLaunchKernelGGL((attention_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
-  } else {
-    dim3 grid(fh_cdiv(n, 64), heads, batch);
-    hipLaunchKernelGGL((attention_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale);
-  }
+  launch_attention(qkv, out, nullptr, batch, n, heads, scale, stream);
   FH_CHECK_LAUNCH("fh_attention_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_attention_seg_f32(const float* qkv, float* out, const int* seg, int n_seg, int max_n, int heads,
+                                    float scale, void* stream) {
+  FH_CHECK_ARG(qkv && out && seg && n_seg > 0 && max_n > 0 && heads > 0, "fh_attention_seg_f32: bad args");
+  launch_attention(qkv, out, seg, n_seg, max_n, heads, scale, stream);
+  FH_CHECK_LAUNCH("fh_attention_seg_f32");
   return FH_OK;
 }

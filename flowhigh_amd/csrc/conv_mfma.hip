@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   const int co0 = cot * BM;
   const int n0 = ntile * BN;
   const int lin = uni(G->lin), cout_pad = uni(G->cout_pad), nseg = uni(G->nseg);
+  // groups of one launch may have different lengths (ragged batches: one group per clip, the grid is sized for the
+  // longest): a block past its group's last column has nothing to do
+  if (n0 >= uni(G->n_len)) return;
 
   f32x16 acc[MT][NT];
 #pragma unroll

@@ -139,6 +139,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const int l31 = lane & 31, lh = lane >> 5;
   const int co0 = cot * W_BM;
   const int len = uni(G->len), cout_pad = uni(G->cout_pad), nseg = uni(G->nseg);
+  // Groups of one launch may have different lengths (ragged batches: one group per clip, the grid is sized for
+  // the longest): a block whose first output lies past its group's row has nothing to do.
+  if (tb * (4 * W_BT) * dil + ph >= len) return;
 
   // phase-major tensors (pm): row = dil phases of lp samples, x[p + dil u] at p * lp + u
   const int lp = ((len + dil - 1) / dil + 3) & ~3;
@@ -588,6 +591,26 @@ extern "C" int fh_sum_f32(const float* const* srcs, int n_srcs, float* out, long
   return FH_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void sum_multi_kernel(const fh_sum_job* __restrict__ jobs) {
+  const fh_sum_job& J = jobs[blockIdx.y];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= J.n / 4) return;
+  f32x4 v = reinterpret_cast<const f32x4*>(J.src[0])[i];
+  for (int k = 1; k < J.n_src; ++k) v += reinterpret_cast<const f32x4*>(J.src[k])[i];
+  reinterpret_cast<f32x4*>(J.out)[i] = v * J.scale;
+}
+}  // namespace
+
+extern "C" int fh_sizeof_sum_job(void) { return (int)sizeof(fh_sum_job); }
+
+extern "C" int fh_sum_multi_f32(const fh_sum_job* jobs, int n_jobs, long long max_n, void* stream) {
+  FH_CHECK_ARG(jobs && n_jobs > 0 && n_jobs < 65536 && max_n > 0 && max_n % 4 == 0, "fh_sum_multi_f32: bad args");
+  hipLaunchKernelGGL(sum_multi_kernel, dim3(fh_cdiv(max_n / 4, 256), n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+  FH_CHECK_LAUNCH("fh_sum_multi_f32");
+  return FH_OK;
+}
+
 extern "C" int fh_debug_set_wino_trace(void* buf) {
   unsigned long long* p = (unsigned long long*)buf;
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &p, sizeof(p));
@@ -634,9 +657,12 @@ template <int MT, int NT, int SUBS>
 int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
                 int phase_major, hipStream_t stream) {
   // 16-byte slab loads need contiguous aligned rows (tensors themselves 16-byte aligned: host plan)
-  const bool vl = (phase_major || (dilation == 1 && len % 4 == 0)) && !getenv("FH_WINO_NO_VL");
-  return vl ? launch_wino_vl<MT, NT, SUBS, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, stream)
-            : launch_wino_vl<MT, NT, SUBS, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, stream);
+  // (phase_major bit 1: the caller rules the vector loader out -- ragged launches in which some group's rows are
+  // not 16-byte aligned; `len` is then only the longest group's length)
+  const bool pm = (phase_major & 1) != 0;
+  const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2) && !getenv("FH_WINO_NO_VL");
+  return vl ? launch_wino_vl<MT, NT, SUBS, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream)
+            : launch_wino_vl<MT, NT, SUBS, false>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream);
 }
 
 }  // namespace
@@ -654,11 +680,11 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
   // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cin * len * 4 < 2^31
   // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
   switch (tile_cfg) {
-    case 0: return launch_wino<2, 2, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
-    case 1: return launch_wino<3, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
-    case 4: return launch_wino<2, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
-    case 5: return launch_wino<1, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
-    case 6: return launch_wino<4, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0, (hipStream_t)stream);
+    case 0: return launch_wino<2, 2, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
+    case 1: return launch_wino<3, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
+    case 4: return launch_wino<2, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
+    case 5: return launch_wino<1, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
+    case 6: return launch_wino<4, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
   }
   fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
   return FH_E_ARG;

@@ -20,15 +20,21 @@ __global__ __launch_bounds__(256) void dwconv_gelu_res_kernel(const float* __res
                                                               const float* __restrict__ wt,
                                                               const float* __restrict__ bias,
                                                               float* __restrict__ y, int n, int dim,
-                                                              int ksz) {
+                                                              int ksz, const int* __restrict__ seg) {
   extern __shared__ __attribute__((aligned(16))) float xs[];     // [DW_TOK + ksz - 1][DW_CH]
   const int c0 = blockIdx.x * DW_CH;
   const int tok0 = blockIdx.y * DW_TOK;
   const int b = blockIdx.z;
   const int half = ksz / 2;
   const int rows = DW_TOK + ksz - 1;
-  const float* xb = x + (size_t)b * n * dim;
-  float* yb = y + (size_t)b * n * dim;
+  size_t row0 = (size_t)b * n;
+  if (seg) {             // ragged batch: clip b = rows [seg[2b], + seg[2b+1]); zero padding at ITS ends (transformer.py:35-44)
+    row0 = (size_t)seg[2 * b];
+    n = seg[2 * b + 1];
+    if (tok0 >= n) return;
+  }
+  const float* xb = x + row0 * dim;
+  float* yb = y + row0 * dim;
   const int tid = threadIdx.x;
   // stage: 32 threads per row (128 channels = 32 float4), 8 rows per pass; zero outside [0, n)
   for (int r = tid >> 5; r < rows; r += 8) {
@@ -113,14 +119,19 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(float* __restrict__ qk
                                                           const float* __restrict__ gk,
                                                           const float* __restrict__ cos_t,
                                                           const float* __restrict__ sin_t, int n,
-                                                          int heads, long long total) {
+                                                          int heads, long long total, const int* __restrict__ seg) {
   const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (item >= total) return;
   const int which = (int)(item % 2);                 // 0 = q, 1 = k
   const int h = (int)((item / 2) % heads);
-  const long long row = item / (2 * heads);          // b * n + pos
+  long long row = item / (2 * heads);                // b * n + pos
   const int pos = (int)(row % n);
+  if (seg) {             // ragged batch: position `pos` of clip b, if it has one (n = longest clip)
+    const int b = (int)(row / n);
+    if (pos >= seg[2 * b + 1]) return;
+    row = (long long)seg[2 * b] + pos;
+  }
   const int inner = heads * 64;
   float* p = qkv + (size_t)row * (3 * inner) + which * inner + h * 64;
   const float v = p[lane];
@@ -144,8 +155,20 @@ extern "C" int fh_dwconv_gelu_res_f32(const float* x, const float* w, const floa
   dim3 grid(dim / DW_CH, fh_cdiv(n, DW_TOK), batch);
   const size_t lds = (size_t)(DW_TOK + ksz - 1) * DW_CH * sizeof(float);
   hipLaunchKernelGGL(dwconv_gelu_res_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, n,
-                     dim, ksz);
+                     dim, ksz, (const int*)nullptr);
   FH_CHECK_LAUNCH("fh_dwconv_gelu_res_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_dwconv_gelu_res_seg_f32(const float* x, const float* w, const float* bias, float* y,
+                                          const int* seg, int n_seg, int max_n, int dim, int ksz, void* stream) {
+  FH_CHECK_ARG(x && w && bias && y && seg && n_seg > 0 && max_n > 0, "fh_dwconv_gelu_res_seg_f32: bad args");
+  FH_CHECK_ARG(dim % DW_CH == 0 && (ksz & 1) && ksz <= DW_KMAX, "fh_dwconv_gelu_res_seg_f32: dim %d / ksz %d unsupported", dim, ksz);
+  dim3 grid(dim / DW_CH, fh_cdiv(max_n, DW_TOK), n_seg);
+  const size_t lds = (size_t)(DW_TOK + ksz - 1) * DW_CH * sizeof(float);
+  hipLaunchKernelGGL(dwconv_gelu_res_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, max_n,
+                     dim, ksz, seg);
+  FH_CHECK_LAUNCH("fh_dwconv_gelu_res_seg_f32");
   return FH_OK;
 }
 
@@ -164,7 +187,19 @@ extern "C" int fh_qknorm_rope_f32(float* qkv, const float* gq, const float* gk, 
   FH_CHECK_ARG(qkv && gq && gk && cos_t && sin_t && batch > 0 && n > 0 && heads > 0, "fh_qknorm_rope_f32: bad args");
   const long long total = (long long)batch * n * heads * 2;
   hipLaunchKernelGGL(qknorm_rope_kernel, dim3(fh_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, qkv,
-                     gq, gk, cos_t, sin_t, n, heads, total);
+                     gq, gk, cos_t, sin_t, n, heads, total, (const int*)nullptr);
   FH_CHECK_LAUNCH("fh_qknorm_rope_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_qknorm_rope_seg_f32(float* qkv, const float* gq, const float* gk, const float* cos_t,
+                                      const float* sin_t, const int* seg, int n_seg, int max_n, int heads,
+                                      void* stream) {
+  FH_CHECK_ARG(qkv && gq && gk && cos_t && sin_t && seg && n_seg > 0 && max_n > 0 && heads > 0,
+               "fh_qknorm_rope_seg_f32: bad args");
+  const long long total = (long long)n_seg * max_n * heads * 2;
+  hipLaunchKernelGGL(qknorm_rope_kernel, dim3(fh_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, qkv,
+                     gq, gk, cos_t, sin_t, max_n, heads, total, seg);
+  FH_CHECK_LAUNCH("fh_qknorm_rope_seg_f32");
   return FH_OK;
 }

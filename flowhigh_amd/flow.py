@@ -118,18 +118,44 @@ class FlowNet:
         self._ws[key] = ws
         return ws
 
-    def set_cond(self, cond, batch, n):
-        """cond [B*n, dim_in] (log-mel of the low-res clip): e_cond = cond @ W_c^T + b."""
-        ws = self.workspace(batch, n)
-        hip.gemm(cond, self.w_c, ws["e_cond"], batch * n, self.dim, self.dim_in, bias=self.b_embed)
+    def ragged_workspace(self, frames):
+        """Workspace for a ragged batch: clips of `frames` frames each packed back to back (M = sum rows, no padding).
+        Carries the device segment table [n_seg][2] = (first row, rows) the seg kernels take."""
+        frames = tuple(int(n) for n in frames)
+        key = ("ragged",) + frames
+        if key in self._ws:
+            return self._ws[key]
+        M, max_n = sum(frames), max(frames)
+        ws = dict(self.workspace(1, M))                         # same buffers as one clip of M frames ...
+        cos_t, sin_t = rotary_tables(self.inv_freq, max_n)      # ... but positions restart in every clip
+        ws["cos"], ws["sin"] = cos_t.to(self.device), sin_t.to(self.device)
+        starts = [0]
+        for n in frames[:-1]:
+            starts.append(starts[-1] + n)
+        ws["seg"] = torch.tensor([[s_, n] for s_, n in zip(starts, frames)], dtype=torch.int32).to(self.device)
+        ws["frames"], ws["rows"], ws["max_n"] = frames, M, max_n
+        self._ws.put(key, ws, ws["cos"].numel() * 8 + ws["seg"].numel() * 4)
+        return ws
 
-    def forward(self, x, t, out, batch, n, alpha=1.0, res=None, null_cond=False):
+    def set_cond(self, cond, batch, n, ragged=None):
+        """cond [B*n, dim_in] (log-mel of the low-res clip): e_cond = cond @ W_c^T + b."""
+        ws = ragged if ragged is not None else self.workspace(batch, n)
+        M = ragged["rows"] if ragged is not None else batch * n
+        hip.gemm(cond, self.w_c, ws["e_cond"], M, self.dim, self.dim_in, bias=self.b_embed)
+
+    def forward(self, x, t, out, batch, n, alpha=1.0, res=None, null_cond=False, ragged=None):
         """out = alpha * v(x, t) + res  with v the vector field; x/out/res [B*n, dim_in].
         null_cond=True evaluates v with every frame's condition replaced by `null_cond`
-        (the cond_drop_prob = 1 pass of forward_with_cond_scale, flow.py:174-178,222-230)."""
+        (the cond_drop_prob = 1 pass of forward_with_cond_scale, flow.py:174-178,222-230).
+        ragged: a ragged_workspace -- the rows are clips of different lengths packed back to back; everything
+        row-wise runs as for one long clip, the three operators that look across rows (ConvPositionEmbed, rotary
+        positions, attention) take the segment table: the reference's mask paths (transformer.py:35-44,
+        attend.py:127-128) without the padding rows."""
         L, st = hip.lib(), hip.stream()
-        ws = self.workspace(batch, n)
-        M, D = batch * n, self.dim
+        ws = ragged if ragged is not None else self.workspace(batch, n)
+        M, D = (ragged["rows"] if ragged is not None else batch * n), self.dim
+        seg = ragged["seg"].data_ptr() if ragged is not None else None
+        n_seg, max_n = (len(ragged["frames"]), ragged["max_n"]) if ragged is not None else (0, 0)
         h, h2, a, att, qkv = ws["h"], ws["h2"], ws["a"], ws["att"], ws["qkv"]
         if null_cond:
             if self._e_null is None:            # null_cond @ W_c^T + b: one row, broadcast with ldr = 0
@@ -138,8 +164,12 @@ class FlowNet:
             hip.gemm(x, self.w_x, h, M, D, self.dim_in, R=self._e_null, ldr=0)
         else:
             hip.gemm(x, self.w_x, h, M, D, self.dim_in, R=ws["e_cond"])
-        hip.check(L.fh_dwconv_gelu_res_f32(h.data_ptr(), self.dw_w.data_ptr(), self.dw_b.data_ptr(),
-                                           h2.data_ptr(), batch, n, D, self.dw_k, st), "fh_dwconv_gelu_res_f32")
+        if seg is None:
+            hip.check(L.fh_dwconv_gelu_res_f32(h.data_ptr(), self.dw_w.data_ptr(), self.dw_b.data_ptr(),
+                                               h2.data_ptr(), batch, n, D, self.dw_k, st), "fh_dwconv_gelu_res_f32")
+        else:
+            hip.check(L.fh_dwconv_gelu_res_seg_f32(h.data_ptr(), self.dw_w.data_ptr(), self.dw_b.data_ptr(), h2.data_ptr(),
+                                                   seg, n_seg, max_n, D, self.dw_k, st), "fh_dwconv_gelu_res_seg_f32")
         hip.check(L.fh_time_fourier_f32(self.sinu_w.data_ptr(), float(t), ws["four"].data_ptr(), D // 2, st),
                   "fh_time_fourier_f32")
         hip.check(L.fh_gemv_f32(self.t_w.data_ptr(), ws["four"].data_ptr(), self.t_b.data_ptr(),
@@ -154,11 +184,18 @@ class FlowNet:
             hip.check(L.fh_rmsnorm_f32(cur.data_ptr(), g1.data_ptr(), b1.data_ptr(), a.data_ptr(), M, D, st),
                       "fh_rmsnorm_f32")
             hip.gemm(a, lay["w_qkv"], qkv, M, 3 * D, D)
-            hip.check(L.fh_qknorm_rope_f32(qkv.data_ptr(), lay["gq"].data_ptr(), lay["gk"].data_ptr(),
-                                           ws["cos"].data_ptr(), ws["sin"].data_ptr(), batch, n, self.heads, st),
-                      "fh_qknorm_rope_f32")
-            hip.check(L.fh_attention_f32(qkv.data_ptr(), att.data_ptr(), batch, n, self.heads, 10.0, st),
-                      "fh_attention_f32")
+            if seg is None:
+                hip.check(L.fh_qknorm_rope_f32(qkv.data_ptr(), lay["gq"].data_ptr(), lay["gk"].data_ptr(),
+                                               ws["cos"].data_ptr(), ws["sin"].data_ptr(), batch, n, self.heads, st),
+                          "fh_qknorm_rope_f32")
+                hip.check(L.fh_attention_f32(qkv.data_ptr(), att.data_ptr(), batch, n, self.heads, 10.0, st),
+                          "fh_attention_f32")
+            else:
+                hip.check(L.fh_qknorm_rope_seg_f32(qkv.data_ptr(), lay["gq"].data_ptr(), lay["gk"].data_ptr(),
+                                                   ws["cos"].data_ptr(), ws["sin"].data_ptr(), seg, n_seg, max_n,
+                                                   self.heads, st), "fh_qknorm_rope_seg_f32")
+                hip.check(L.fh_attention_seg_f32(qkv.data_ptr(), att.data_ptr(), seg, n_seg, max_n, self.heads, 10.0, st),
+                          "fh_attention_seg_f32")
             hip.gemm(att, lay["w_out"], other, M, D, D, R=cur)
             cur, other = other, cur
             hip.check(L.fh_rmsnorm_f32(cur.data_ptr(), g2.data_ptr(), b2.data_ptr(), a.data_ptr(), M, D, st),

@@ -287,7 +287,7 @@ class FlowHighSR:
         n_mels = self.flowhigh.n_mels
         return torch.cat([reference_prior_draw(n_frames, n_mels, generator) for _ in range(batch)], 0)
 
-    def _integrate(self, y0, cond_mel, batch, n, time_steps, cond_scale=1.):
+    def _integrate(self, y0, cond_mel, batch, n, time_steps, cond_scale=1., ragged=None):
         """Fixed-grid euler / midpoint (torchdiffeq semantics); y0, cond_mel [B*n, n_mels] on device.
         Every update `out = base + h * v(x, t)` is the epilogue of the last GEMM of the vector field;
         with classifier-free guidance v = null + s (cond - null) it is two chained epilogues."""
@@ -295,17 +295,17 @@ class FlowHighSR:
         method = self.odeint_kwargs['method']
         if method not in ('euler', 'midpoint'):
             raise NotImplementedError(f"ode method '{method}'")
-        net.set_cond(cond_mel, batch, n)
+        net.set_cond(cond_mel, batch, n, ragged=ragged)
         t = torch.linspace(0, 1, time_steps + 1)
         y = y0
         bufs = [torch.empty_like(y0) for _ in range(4)]
 
         def axpy_field(x, tt, out, h, base):           # out = base + h * v(x, tt)
             if cond_scale == 1.:
-                net.forward(x, tt, out, batch, n, alpha=h, res=base)
+                net.forward(x, tt, out, batch, n, alpha=h, res=base, ragged=ragged)
             else:
-                net.forward(x, tt, bufs[3], batch, n, alpha=h * (1. - cond_scale), res=base, null_cond=True)
-                net.forward(x, tt, out, batch, n, alpha=h * cond_scale, res=bufs[3])
+                net.forward(x, tt, bufs[3], batch, n, alpha=h * (1. - cond_scale), res=base, null_cond=True, ragged=ragged)
+                net.forward(x, tt, out, batch, n, alpha=h * cond_scale, res=bufs[3], ragged=ragged)
 
         for i in range(time_steps):
             t0, dt = t[i], t[i + 1] - t[i]
@@ -388,6 +388,43 @@ class FlowHighSR:
             return mel
         return fh.vocoder.forward(mel).unsqueeze(1)           # [B, 1, hop * n]
 
+    def _sample_ragged(self, conds, noises, time_steps, cfm_method, std_2=None):
+        """`sample()` (cfm:162-284, cond_scale 1, no mel_pp) for clips of DIFFERENT lengths as one launch sequence.
+        conds: list of [T48_i] device tensors (peak-normalised), noises: list of [1, N_i, n_mels] host tensors.
+        Returns the vocoder's waveforms, a list of [1, 480 N_i] (plan-owned buffers), each what _sample gives for
+        that clip alone: the log-mels are made per clip, every row-wise operator runs on the packed rows, the
+        operators that look across rows take the clip boundaries, the vocoder runs its merged plan."""
+        fh = self.flowhigh
+        std_1 = None
+        if cfm_method in _CFM_METHODS[1:]:
+            std_1, std_2 = 1.0, self.sigma                   # cfm:180-183: generate() never passes std_1, so BOTH reset
+        mels = [fh.logmel(c[None]) for c in conds]           # [N_i, n_mels] each
+        frames = [m.shape[0] for m in mels]
+        cond_mel = torch.cat(mels, 0)
+        noise = self._upload(torch.cat([z.reshape(-1, z.shape[-1]).to(torch.float32) for z in noises], 0)).contiguous()
+        if noise.shape != cond_mel.shape:
+            raise ValueError(f"noise rows {tuple(noise.shape)} do not match the clips' frames {tuple(cond_mel.shape)}")
+        rws = fh.net.ragged_workspace(frames)
+        if cfm_method == 'basic_cfm':
+            y0 = noise
+        else:
+            y0 = torch.empty_like(noise)
+            hip.check(hip.lib().fh_axpby_f32(cond_mel.data_ptr(), float(std_1), noise.data_ptr(), float(std_2),
+                                             y0.data_ptr(), y0.numel(), hip.stream()), "fh_axpby_f32")
+            if cfm_method == 'independent_cfm_mix':          # per-clip cutoff bins (cfm:231-237): per-clip launches
+                parts, r = [], 0
+                for n in frames:
+                    cm, nz, yy = cond_mel[r:r + n], noise[r:r + n], y0[r:r + n]
+                    parts.append(self._mel_replace(nz, yy, self.mel_cutoff_bins(cm, 1, n), 1, n))
+                    r += n
+                y0 = torch.cat(parts, 0)
+        mel = self._integrate(y0, cond_mel, len(frames), max(frames), time_steps, 1., ragged=rws)
+        rows, out = 0, []
+        for n in frames:
+            out.append(mel[rows:rows + n])
+            rows += n
+        return fh.vocoder.forward_ragged(out)
+
     @torch.no_grad()
     def generate_batch(self, clips, sr, target_sampling_rate=48000, timestep=1, *, noise=None,
                        generator=None, return_stages=False):
@@ -403,12 +440,17 @@ class FlowHighSR:
 
     @torch.no_grad()
     def generate_many(self, clips, sr, target_sampling_rate=48000, timestep=1, *, noise=None, generator=None,
-                      max_batch=64, streams=None):
+                      max_batch=64, streams=None, ragged=None, max_frames=None):
         """Serving-side entry (the gradio caller of app.py:8-26, many requests at once): clips of ANY lengths,
         int16 or float.  Clips of equal length run as one batch (at most max_batch rows), so every result is
         what generate() returns for that clip alone; the prior noise is drawn in the order of `clips`, as a loop
         over generate() would.  noise: optional list of [1, N_i, n_mels] tensors.  Returns a list of [1, T48_i].
-        streams: batches of different FRAME COUNTS can be enqueued round-robin on several HIP streams (FH_SERVE_STREAMS,
+        ragged (default on, FH_RAGGED=0 switches it off): clips of different lengths run as ONE launch sequence
+        (masked / ragged batch, the reference's mask paths transformer.py:35-44, attend.py:127-128): ~120 launches for
+        the whole list instead of ~120 per distinct length; at most max_frames (FH_RAGGED_MAX_FRAMES, default 12 000 =
+        120 s of audio) frames per sequence; clips too long for that (or for the unchunked vocoder) run alone.
+        Results are bit-identical to generate() per clip either way.
+        streams (ragged off): batches of different FRAME COUNTS can be enqueued round-robin on several HIP streams (FH_SERVE_STREAMS,
         default 1), so that the launches of a short clip - a few dozen blocks each, a fraction of the 256 CUs - overlap
         with those of the next one.  The per-shape workspaces are keyed by (batch, frames): two input lengths with the
         same frame count (6000 and 6001 samples at 12 kHz: 50 frames both) share them, so every bucket of one frame
@@ -425,6 +467,11 @@ class FlowHighSR:
                 noise.append(self._draw_noise(1, t48 // 480, generator))
         if len(noise) != len(clips):
             raise ValueError("one noise tensor per clip")
+        if ragged is None:
+            ragged = os.environ.get("FH_RAGGED", "1") != "0"
+        lengths = [int(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a).shape[-1]) for a in clips]
+        if ragged and len(set(lengths)) > 1 and target_sampling_rate == 48000:
+            return self._generate_many_ragged(clips, lengths, sr, timestep, noise, max_frames)
         buckets = {}
         for i, a in enumerate(clips):
             key = (int(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a).shape[-1]), tuple(noise[i].shape))
@@ -455,6 +502,36 @@ class FlowHighSR:
         for s_ in side:
             if s_ is not main:
                 main.wait_stream(s_)
+        return out
+
+    def _generate_many_ragged(self, clips, lengths, sr, timestep, noise, max_frames):
+        if max_frames is None:
+            max_frames = int(os.environ.get("FH_RAGGED_MAX_FRAMES", "12000"))
+        chunk_limit = int(os.environ.get("FH_VOCODER_CHUNK_FRAMES", "6000"))
+        frames = [n.shape[1] for n in noise]
+        out = [None] * len(clips)
+        kw = dict(std_2=1.) if self.cfm_method == 'independent_cfm_adaptive' else {}
+        # greedy packing in list order; a clip that does not fit a sequence of its own runs through generate()
+        groups, cur, tot = [], [], 0
+        for i, n in enumerate(frames):
+            if n > max_frames or (chunk_limit > 0 and n > chunk_limit):
+                out[i] = self.generate_batch([clips[i]], sr, 48000, timestep, noise=noise[i]).clone()
+                continue
+            if cur and tot + n > max_frames:
+                groups.append(cur)
+                cur, tot = [], 0
+            cur.append(i)
+            tot += n
+        if cur:
+            groups.append(cur)
+        for idx in groups:
+            if len(idx) == 1:
+                out[idx[0]] = self.generate_batch([clips[idx[0]]], sr, 48000, timestep, noise=noise[idx[0]]).clone()
+                continue
+            conds = [self._prepare_cond([clips[i]], sr, 48000)[0] for i in idx]
+            wavs = self._sample_ragged(conds, [noise[i] for i in idx], timestep, self.cfm_method, **kw)
+            for i, cond, wav in zip(idx, conds, wavs):
+                out[i] = self.postproc(wav, cond[None], cond.shape[0]).clone()
         return out
 
     def _serve_streams(self, n):

@@ -46,7 +46,11 @@ class WinoGroup(C.Structure):
 
 class ActGroup(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("alpha", C.c_void_p), ("inv_beta", C.c_void_p),
-                ("up_taps", C.c_float * 12), ("down_taps", C.c_float * 12)]
+                ("up_taps", C.c_float * 12), ("down_taps", C.c_float * 12), ("len", C.c_int32), ("tile_base", C.c_int32)]
+
+
+class SumJob(C.Structure):
+    _fields_ = [("src", C.c_void_p * 12), ("out", C.c_void_p), ("n", C.c_int64), ("n_src", C.c_int32), ("scale", C.c_float)]
 
 
 class HipError(RuntimeError):
@@ -72,6 +76,13 @@ _SIGS = {
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_pm_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
+    "fh_act_tile_len": [],
+    "fh_act1d_ragged_f32": [_P, _I, _I, _I, _I, C.c_longlong, _P],
+    "fh_sizeof_sum_job": [],
+    "fh_sum_multi_f32": [_P, _I, C.c_longlong, _P],
+    "fh_attention_seg_f32": [_P, _P, _P, _I, _I, _I, _F, _P],
+    "fh_dwconv_gelu_res_seg_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "fh_qknorm_rope_seg_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "fh_gemm_f32": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P],
     "fh_gemv_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
     "fh_time_fourier_f32": [_P, _F, _P, _I, _P],
@@ -116,7 +127,7 @@ def lib():
     if L.fh_abi_version() != 1:
         raise HipError("libflowhigh_hip.so ABI version mismatch")
     if L.fh_sizeof_conv_group() != C.sizeof(ConvGroup) or L.fh_sizeof_act_group() != C.sizeof(ActGroup) \
-            or L.fh_sizeof_wino_group() != C.sizeof(WinoGroup):
+            or L.fh_sizeof_wino_group() != C.sizeof(WinoGroup) or L.fh_sizeof_sum_job() != C.sizeof(SumJob):
         raise HipError("descriptor struct layout mismatch between hip.py and flowhigh_hip.h")
     _lib = L
     return L
@@ -160,10 +171,17 @@ class ShapeCache(dict):
         super().__setitem__(key, v)            # most recently used last
         return v
 
+    def put(self, key, value, nbytes):
+        """Insert with a known size (entries that only reference buffers owned by other entries)."""
+        self._insert(key, value, int(nbytes))
+
     def __setitem__(self, key, value):
+        self._insert(key, value, _tensor_bytes(value, set()))
+
+    def _insert(self, key, value, nbytes):
         if key in self:
             super().pop(key)
-        self._bytes[key] = _tensor_bytes(value, set())
+        self._bytes[key] = nbytes
         total = sum(self._bytes[k] for k in self) + self._bytes[key]
         synced = False
         while len(self) and (len(self) >= self.max_entries or total > self.max_bytes):

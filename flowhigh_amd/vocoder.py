@@ -483,6 +483,7 @@ class Vocoder:
         self.post_b = g("conv_post.bias").to(dev)
         self.post_k = self.post_w.shape[-1]
         self._plans = hip.ShapeCache()
+        self._ragged = hip.ShapeCache()
         self.conv_timing = None
         self.act_timing = None
         self.chain_streams = os.environ.get("FH_VOCODER_STREAMS", "0") == "1"
@@ -499,20 +500,34 @@ class Vocoder:
             f += length * st["c"] ** 2 * 2.0 * 2 * self.nm * sum(self.ks)
         return f
 
-    def plan(self, batch, n_frames, ref_frames=None):
+    def plan(self, batch, n_frames, ref_frames=None, inst=0):
         """Launch plan for [batch, num_mels, n_frames].  ref_frames: the frame count of the WHOLE clip when this
         plan runs a time chunk of it (forward_chunked): every choice that changes the order of additions (input-
         channel slices of short clips, fused / unfused stage-closing conv) is then taken as for the whole clip, so
         a chunk gives the bits of the unchunked run; tile shapes (no effect on the arithmetic) follow the chunk."""
         ref_frames = n_frames if ref_frames is None else ref_frames
         key = (batch, n_frames) if ref_frames == n_frames else (batch, n_frames, ref_frames)
+        if inst:                    # (plan_ragged: clips of equal length in one ragged batch need buffers of their own)
+            key = (batch, n_frames, "inst", inst, ref_frames)
         if key in self._plans:
             return self._plans[key]
         dev = self.device
         B, N = batch, n_frames
         B_ = B
         f32 = dict(dtype=torch.float32, device=dev)
-        steps = []          # (kind, device descriptor tensor, n_groups, args...)
+        # (kind, device descriptor tensor, n_groups, args...); meta[i] = (position key, host descriptor structs) of
+        # steps[i]: the position key names the step's place in the model -- (stage, sub-block, slot, index) -- so that
+        # the plans of different clips can be merged launch by launch (plan_ragged) although their optional steps differ
+        steps, meta, kk = [], [], [None]
+
+        def at(*key):
+            kk[0] = key
+
+        class _Steps(list):
+            def append(self_, step, structs=None, key=None):
+                meta.append((key if key is not None else kk[0], structs))
+                list.append(self_, step)
+        steps = _Steps()
         executed = [0.0]    # FLOPs issued to the matrix cores by all conv launches (Winograd: 1.5 G / k of the algorithmic)
         keep = []           # tensors that must stay alive
         L = N
@@ -528,7 +543,10 @@ class Vocoder:
             flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * B
                         for g in groups for i in range(g.nseg))
             executed[0] += flops
-            (sink if sink is not None else steps).append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
+            if sink is not None:
+                sink.append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
+            else:
+                steps.append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops), groups)
 
         def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False, flops=None, batch=None):
             B = B_ if batch is None else batch          # (split-K launches carry one group per batch item)
@@ -553,7 +571,10 @@ class Vocoder:
             # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
             executed[0] += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
                                for g in groups for i in range(g.nseg))
-            (sink if sink is not None else steps).append(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B))
+            if sink is not None:
+                sink.append(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B))
+            else:
+                steps.append(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B), groups)
 
         parts = []                  # split-K partial outputs, allocated by the first launch that needs them
 
@@ -590,7 +611,8 @@ class Vocoder:
                 pieces = [[outs[i]] + [parts[0][2 * i + sl] for sl in range(nsplit - 1)] for i in range(len(ents))]
                 if not defer_sum:
                     for i in range(len(ents)):
-                        steps.append(("sum", pieces[i], outs[i], B_ * c * pitch, 1.0))
+                        steps.append(("sum", pieces[i], outs[i], B_ * c * pitch, 1.0),
+                                     key=kk[0][:2] + (kk[0][2] + 1, i))
                 return pieces
             elif all("u" in e for e in ents):
                 wino_step([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i])], biases[i],
@@ -608,12 +630,16 @@ class Vocoder:
         def act_step(groups, c, length, sink=None, din=1, dout=1):
             d = hip.to_device_struct_array(groups, dev)
             keep.append(d)
-            (sink if sink is not None else steps).append(("act", d, len(groups), c, length, din, dout))
+            if sink is not None:
+                sink.append(("act", d, len(groups), c, length, din, dout))
+            else:
+                steps.append(("act", d, len(groups), c, length, din, dout), groups)
 
         mel_in = torch.empty(B, self.num_mels, N, **f32)
         pre = torch.empty(B, self.c0, N, **f32)
         keep.append(pre)            # descriptors hold raw pointers: every buffer they name must outlive the plan
         k7 = [j - 3 for j in range(7)]
+        at(-1, 0, 0, 0)
         if self.pre_u is not None:
             wino_step([make_wino_group([make_wino_seg(mel_in, self.pre_u, self.num_mels, 7)], self.pre_b, [], pre,
                                        self.c0, self.pre_wpad, N)], self.pre_wpad, N, 1, self.pre_wcfg)
@@ -635,6 +661,7 @@ class Vocoder:
             view = lambda idx: pool[idx, :B * c * L].view(B, c, L)
             X = view(0)
             S = view(1)
+            at(i, -1, 0, 0)
             if st["up_wino"] is not None:
                 up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
                 nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"],
@@ -651,7 +678,7 @@ class Vocoder:
                                               c, st["wpad"], lin, stride=u, phase=r)
                               for r, ph in enumerate(st["up_wino"]) for sl in range(nsplit) for b in range(B)]
                     wino_step(groups, st["wpad"], lin, 1, st["wcfg"], flops=up_flops, batch=1)
-                    steps.append(("sum", dsts, X, B * c * L, 1.0))
+                    steps.append(("sum", dsts, X, B * c * L, 1.0), key=(i, -1, 1, 0))
                 else:
                     groups = [make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"])], st["up_b"],
                                               [], X, c, st["wpad"], lin, stride=u, phase=r)
@@ -675,7 +702,9 @@ class Vocoder:
                 ents = [b_["c1"][m] for b_ in blks]
                 ks = [b_["k"] for b_ in blks]
                 ds = [b_["dil"][m] for b_ in blks]
+                at(i, m, 0, 0)
                 act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][m]) for j in order], c, L)
+                at(i, m, 1, 0)
                 if m < self.nm - 1 or not all("w" in e for e in ents):
                     outs = [Y[j][m % 2] for j in order]
                     if all(d == ds[0] for d in ds):
@@ -688,7 +717,7 @@ class Vocoder:
                     xin = [Y[j][m % 2] for j in range(self.nk)]
                     if m == self.nm - 1:            # xs / num_kernels, block order = the reference's xs += order
                         steps.append(("mean", xin[0], xin[1], xin[2] if self.nk == 3 else None, S, B * c * L,
-                                      1.0 / self.nk))
+                                      1.0 / self.nk), key=(i, m, 6, 0))
                 else:                   # direct kernel: the nk closing convs as K segments of one group, / nk in the epilogue
                     segs = [make_conv_seg(T1[j], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])
                             for j, e, k, d in zip(order, ents, ks, ds)]
@@ -721,8 +750,10 @@ class Vocoder:
                     # dilated Winograd conv: the activations on both sides write / read phase-major tensors
                     pm = _WINO_PM and same_d and d1 > 1 and all("u" in b_["c1"][m] for b_ in blks)
                     dpm = d1 if pm else 1
+                    at(i, m, 0, 0)
                     act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L,
                              dout=dpm)
+                    at(i, m, 1, 0)
                     if same_d:
                         res_conv([b_["c1"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], d1,
                                  [T2[j] for j in order], [b_["c1"][m]["b"] for b_ in blks], [[] for _ in blks],
@@ -736,14 +767,17 @@ class Vocoder:
                             groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
                                                            blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
                         conv_step(groups, cpad, L, tcfg, st["ck"])
+                    at(i, m, 3, 0)
                     act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L,
                              din=dpm)
+                    at(i, m, 4, 0)
                     if not last:
                         res_conv([b_["c2"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], 1,
                                  [Y[j][m % 2] for j in order], [b_["c2"][m]["b"] for b_ in blks],
                                  [[xin[j]] for j in order], c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
                         xin = [Y[j][m % 2] for j in range(self.nk)]
                 if last:
+                    at(i, m, 4, 0)
                     ents = [st["blocks"][j]["c2"][m] for j in order]
                     wbm, wbn = (96, 256) if st["wcfg"] & 1 else (64, 512)
                     fused_blocks = B * (st["wpad"] // wbm) * -(-ref["L"] // wbn)
@@ -765,11 +799,11 @@ class Vocoder:
                         if len(pieces[0]) > 1:                              # split-K: all partial outputs in one pass
                             by_block = {j: pieces[n_] for n_, j in enumerate(order)}
                             steps.append(("sum", [t for j in range(self.nk) for t in by_block[j]], S, B * c * L,
-                                          1.0 / self.nk))
+                                          1.0 / self.nk), key=(i, m, 6, 0))
                         else:
                             ys = [Y[j][m % 2] for j in range(self.nk)]      # block order = the reference's xs += order
                             steps.append(("mean", ys[0], ys[1], ys[2] if self.nk == 3 else None, S, B * c * L,
-                                          1.0 / self.nk))
+                                          1.0 / self.nk), key=(i, m, 6, 0))
                     elif all("u" in e for e in ents):
                         segs = [make_wino_seg(T1[j], st["blocks"][j]["c2"][m]["u"], c, st["blocks"][j]["k"]) for j in order]
                         wino_step([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, st["wpad"], L,
@@ -787,15 +821,156 @@ class Vocoder:
             cur = S
         c_last = self.stages[-1]["c"]
         post_t = pool[2, :B * c_last * L].view(B, c_last, L)
+        at(99, 0, 0, 0)
         act_step([make_act_group(cur, post_t, self.post_act)], c_last, L)
         wav = torch.empty(B, L, **f32)
-        steps.append(("post", post_t, wav, c_last, L))
+        steps.append(("post", post_t, wav, c_last, L), key=(99, 0, 1, 0))
         # algorithmic HBM bytes of the Activation1d launches: every site reads and writes its [B, C, L] tensor once
         act_bytes = sum(8.0 * s_[2] * B * s_[3] * s_[4] for s_ in steps if s_[0] == "act")
-        p = dict(steps=steps, keep=keep, mel_in=mel_in, wav=wav, B=B, N=N, L=L, conv_executed_flops=executed[0],
+        p = dict(steps=list(steps), meta=meta, keep=keep, mel_in=mel_in, wav=wav, B=B, N=N, L=L, conv_executed_flops=executed[0],
                  act_bytes=act_bytes, n_act=sum(s_[0] == "act" for s_ in steps))
         self._plans[key] = p
         return p
+
+    # ---- ragged batches (clips of different lengths in ONE launch sequence) ------------------------
+    def plan_ragged(self, frames):
+        """Merged launch plan for clips of frame counts `frames` (any mix of lengths, batch 1 each).
+        Every clip keeps the plan it has alone (`plan(1, N)`: its own buffers, the same groups, K segments,
+        input-channel slices and partial-sum steps -- so the same bits); steps that sit at the same position of the
+        model are then launched together: one conv / activation launch carries the groups of all clips (the kernels
+        take a length per group; the grid is sized for the longest and blocks past a group's end exit), the partial-sum
+        / averaging passes become one multi-job launch.  A mix of 24 clips runs ~120 launches instead of ~2 900."""
+        frames = tuple(int(n) for n in frames)
+        key = ("ragged",) + frames
+        if key in self._ragged:
+            return self._ragged[key]
+        if self.chain_streams:
+            raise NotImplementedError("ragged batches with FH_VOCODER_STREAMS=1")
+        seen, subs = {}, []
+        for n in frames:
+            k = seen.get(n, 0)
+            seen[n] = k + 1
+            subs.append(self.plan(1, n, inst=k))
+        by_key = {}
+        for ci, sp in enumerate(subs):
+            ks = [m[0] for m in sp["meta"]]
+            if len(set(ks)) != len(ks):
+                raise NotImplementedError("this vocoder configuration has launch positions that cannot be merged")
+            for step, (k, structs) in zip(sp["steps"], sp["meta"]):
+                by_key.setdefault(k, []).append((ci, step, structs))
+        blobs, merged = [], []          # host bytes of every descriptor array (one upload), merged steps
+
+        def blob(structs):
+            arr = (type(structs[0]) * len(structs))(*structs)
+            off = sum(len(b) for b in blobs)
+            raw = bytes(arr)
+            blobs.append(raw + bytes(-len(raw) % 16))
+            return off
+
+        tt = hip.lib().fh_act_tile_len()
+        for k in sorted(by_key):
+            items = by_key[k]
+            kinds = {"sum" if it[1][0] == "mean" else it[1][0] for it in items}     # (a mean is a 2-3 term sum job)
+            if len(kinds) != 1:
+                raise NotImplementedError(f"launch position {k}: kinds {kinds} cannot be merged")
+            kind = kinds.pop()
+            if kind == "wino":
+                classes = {}
+                for ci, st_, groups in items:
+                    _, _d, ng, wpad, length, dil, _fl, wcfg, pm, bb = st_
+                    assert bb == 1 and ng == len(groups)
+                    classes.setdefault((wpad, dil, pm), []).append((length, wcfg, groups))
+                for (wpad, dil, pm), lst in classes.items():
+                    allg = [(sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg)), length, g)
+                            for length, _, groups in lst for g in groups]
+                    allg.sort(key=lambda t: (-t[0], -t[1]))                 # heavy groups first (dispatch order)
+                    maxlen = max(t[1] for t in allg)
+                    default = max(lst, key=lambda t: t[0])[1]               # the longest clip's tile shape
+                    wcfg = default
+                    if _WINO_AUTO and default in (0, 1, 4, 5):
+                        # the launch model takes one length: the mean one keeps the block count honest
+                        mean_len = max(1, sum(t[1] for t in allg) // len(allg))
+                        wcfg, _ = choose_wino_cfg([t[0] for t in allg], 1, wpad, mean_len, dil, default=default)
+                    novl = 0 if (pm or all(t[1] % 4 == 0 for t in allg)) else 2
+                    merged.append(("rwino", blob([t[2] for t in allg]), len(allg), wpad, maxlen, dil, wcfg, int(pm) | novl))
+            elif kind == "conv":
+                classes = {}
+                for ci, st_, groups in items:
+                    _, _d, ng, cpad, n_len, tcfg, ck, _fl = st_
+                    classes.setdefault((cpad, ck), []).append((n_len, tcfg, groups))
+                for (cpad, ck), lst in classes.items():
+                    allg = [(sum(g.seg[i].cin * g.seg[i].ntaps for i in range(g.nseg)), n_len, g)
+                            for n_len, _, groups in lst for g in groups]
+                    allg.sort(key=lambda t: (-t[0], -t[1]))
+                    tcfg = max(lst, key=lambda t: t[0])[1]
+                    merged.append(("rconv", blob([t[2] for t in allg]), len(allg), cpad, max(t[1] for t in allg), tcfg, ck))
+            elif kind == "act":
+                classes = {}
+                for ci, st_, groups in items:
+                    _, _d, ng, c, length, din, dout = st_
+                    classes.setdefault((c, din, dout), []).append((length, groups))
+                for (c, din, dout), lst in classes.items():
+                    out, base = [], 0
+                    for length, groups in sorted(lst, key=lambda t: -t[0]):
+                        for g in groups:
+                            g2 = hip.ActGroup.from_buffer_copy(g)
+                            g2.len, g2.tile_base = length, base
+                            base += c * -(-length // tt)
+                            out.append(g2)
+                    merged.append(("ract", blob(out), len(out), c, din, dout, base))
+            elif kind == "sum":
+                jobs = []
+                for ci, st_, _ in items:
+                    if st_[0] == "sum":
+                        _, srcs, out, n, scale = st_
+                    else:
+                        _, a, b_, c_, out, n, scale = st_
+                        srcs = [a, b_] + ([c_] if c_ is not None else [])
+                    j = hip.SumJob()
+                    for i, t in enumerate(srcs):
+                        j.src[i] = t.data_ptr()
+                    j.out, j.n, j.n_src, j.scale = out.data_ptr(), n, len(srcs), scale
+                    if n % 4 or len(srcs) > 12:
+                        raise NotImplementedError("partial-sum job shape")
+                    jobs.append(j)
+                merged.append(("rsum", blob(jobs), len(jobs), max(j.n for j in jobs)))
+            elif kind == "post":
+                for ci, st_, _ in items:
+                    merged.append(st_)
+            else:
+                raise NotImplementedError(kind)
+        host = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8)
+        desc = host.to(self.device)
+        rp = dict(subs=subs, steps=merged, desc=desc, frames=frames)
+        self._ragged.put(key, rp, desc.numel())       # (the clips' buffers are accounted for in self._plans)
+        return rp
+
+    def run_ragged(self, rp):
+        L, st, base = hip.lib(), hip.stream(), rp["desc"].data_ptr()
+        for s in rp["steps"]:
+            if s[0] == "rwino":
+                _, off, ng, wpad, maxlen, dil, wcfg, pmflag = s
+                hip.check(L.fh_conv_wino_f32(base + off, ng, 1, wpad, maxlen, dil, pmflag, wcfg, st), "fh_conv_wino_f32")
+            elif s[0] == "rconv":
+                _, off, ng, cpad, maxlen, tcfg, ck = s
+                hip.check(L.fh_conv_grouped_f32(base + off, ng, 1, cpad, maxlen, tcfg, ck, st), "fh_conv_grouped_f32")
+            elif s[0] == "ract":
+                _, off, ng, c, din, dout, tiles = s
+                hip.check(L.fh_act1d_ragged_f32(base + off, ng, c, din, dout, tiles, st), "fh_act1d_ragged_f32")
+            elif s[0] == "rsum":
+                _, off, nj, max_n = s
+                hip.check(L.fh_sum_multi_f32(base + off, nj, max_n, st), "fh_sum_multi_f32")
+            else:
+                self._launch(s, 1, st)
+
+    def forward_ragged(self, mels):
+        """mels: list of [N_i, num_mels] (token-major rows of each clip) -> list of wav [1, hop * N_i] (plan-owned
+        buffers), every one bit-identical to forward() on that clip alone."""
+        rp = self.plan_ragged([m.shape[0] for m in mels])
+        for sp, m in zip(rp["subs"], mels):
+            sp["mel_in"].copy_(m.view(1, m.shape[0], -1).transpose(1, 2))
+        self.run_ragged(rp)
+        return [sp["wav"] for sp in rp["subs"]]
 
     # ---- time-chunked execution (SURVEY.md 8f-4: streaming / chunked vocoder) ----------------------------------
     def chunk_geometry(self):

@@ -157,6 +157,18 @@ int fh_sum_f32(const float* const* srcs, int n_srcs, float* out, long long n, fl
 /* Debug: per-block timeline of the conv kernel.  buf = device array of uint64, buf[0] = record
  * counter (zero it), then 4 words per block {blockIdx | hw_id << 32 | xcc << 56, start, end
  * (100 MHz ticks), K steps}; NULL switches tracing off.  Synchronous (hipMemcpyToSymbol). */
+/* out = scale * (((p0 + p1) + p2) + ...) for several independent jobs in one launch (the averaging / partial-sum
+ * passes of a ragged batch: one job per clip; same order of additions as fh_sum_f32 / fh_mean_f32). */
+typedef struct {
+  const float* src[12];
+  float* out;
+  int64_t n;             /* floats, % 4 == 0 */
+  int32_t n_src;
+  float scale;
+} fh_sum_job;
+int fh_sizeof_sum_job(void);
+int fh_sum_multi_f32(const fh_sum_job* jobs, int n_jobs, long long max_n, void* stream);
+
 int fh_debug_set_conv_trace(void* buf);
 /* Same for the Winograd kernel: one record per WAVE, word 3 = wave index in the block. */
 int fh_debug_set_wino_trace(void* buf);
@@ -184,6 +196,8 @@ typedef struct {
   const float* inv_beta; /* [C] */
   float up_taps[12];
   float down_taps[12];
+  int32_t len;           /* fh_act1d_ragged_f32 only: L of THIS group (batch 1) */
+  int32_t tile_base;     /* fh_act1d_ragged_f32 only: C * sum over the groups before of ceil(len / fh_act_tile_len()) */
 } fh_act_group;
 
 int fh_sizeof_act_group(void);
@@ -193,6 +207,12 @@ int fh_act1d_grouped_f32(const fh_act_group* groups, int n_groups, int batch, in
  * use, 1 = plain [B, C, len].  Used on both sides of a dilated Winograd conv. */
 int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups, int batch, int channels, int len,
                             int din, int dout, void* stream);
+/* Ragged batches (clips of different lengths in ONE launch): group g = one clip's [C, groups[g].len] tensor,
+ * total_tiles = groups[n-1].tile_base + C * ceil(groups[n-1].len / fh_act_tile_len()).  Same arithmetic per
+ * sample as the launches above (replicate padding at each clip's own ends). */
+int fh_act_tile_len(void);
+int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, int din, int dout,
+                        long long total_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 MFMA GEMM:  C[M, N] = epilogue( A[M, K] * W[N, K]^T )
@@ -249,6 +269,19 @@ int fh_qknorm_rope_f32(float* qkv, const float* gq, const float* gk, const float
  * qkv as above (q | k | v along the feature axis), out [B*n, heads*64].  dim_head 64. */
 int fh_attention_f32(const float* qkv, float* out, int batch, int n, int heads, float scale,
                      void* stream);
+
+/* Ragged batches: clips of DIFFERENT lengths packed back to back in the token-major tensors, no padding rows.
+ * seg: device int32 [n_seg][2] = (first row, rows) of every clip; max_n = the longest clip.  These are the
+ * reference's mask paths -- the key mask of Attend (attend.py:127-128), the mask of ConvPositionEmbed
+ * (transformer.py:35-44) -- for the layout in which masked positions simply do not exist; rotary positions
+ * restart at 0 in every clip (pos_emb.py:47-51).  Every clip gets the bits it gets alone.
+ * cos_t / sin_t must cover max_n positions. */
+int fh_attention_seg_f32(const float* qkv, float* out, const int* seg, int n_seg, int max_n, int heads,
+                         float scale, void* stream);
+int fh_dwconv_gelu_res_seg_f32(const float* x, const float* w, const float* bias, float* y, const int* seg,
+                               int n_seg, int max_n, int dim, int ksz, void* stream);
+int fh_qknorm_rope_seg_f32(float* qkv, const float* gq, const float* gk, const float* cos_t,
+                           const float* sin_t, const int* seg, int n_seg, int max_n, int heads, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * STFT framing, post-processing (postprocessing.py:5-41) and peak normalisation.

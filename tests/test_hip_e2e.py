@@ -169,7 +169,7 @@ def test_generate_many_ragged_list_equals_single_calls():
     clips = [synth.lowres_clip(40 + i, s, 12000) for i, s in enumerate(secs)]
     clips[3] = (clips[3] * 20000).astype(np.int16)
     noise = [synth.prior_noise(40 + i, (len(c) * 4) // 480) for i, c in enumerate(clips)]
-    many = m.generate_many(clips, 12000, 48000, 1, noise=noise, max_batch=2)
+    many = m.generate_many(clips, 12000, 48000, 1, noise=noise, max_batch=2, ragged=False)      # bucketed by length
     assert len(many) == len(clips)
     for i, c in enumerate(clips):
         one = m.generate(c, 12000, 48000, 1, noise=noise[i])
@@ -368,3 +368,27 @@ def test_two_minute_clip_runs_through_the_chunked_vocoder(monkeypatch):
     monkeypatch.setenv("FH_VOCODER_CHUNK_FRAMES", "2400")
     out2 = m.generate(audio, 12000, 48000, 1, noise=noise)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("cfgname,method,cfm", [("TINY_CFG", "euler", "basic_cfm"), ("SYNTH_CFG", "midpoint", "basic_cfm"),
+                                                ("TINY_CFG", "midpoint", "independent_cfm_adaptive"),
+                                                ("TINY_CFG", "euler", "independent_cfm_mix")])
+def test_generate_many_ragged_batch_equals_single_calls_bitwise(cfgname, method, cfm):
+    """Masked / ragged batches (reference mask paths transformer.py:35-44, attend.py:127-128): clips of
+    different lengths -- odd sample counts, an int16 clip, two of equal length, sub-2-s clips whose wide stages run as
+    input-channel slices -- go through ONE launch sequence and come back bit-identical to generate() per clip."""
+    cfg = getattr(synth, cfgname)
+    m, _ = model_for(cfg, 0, method, cfm, sigma=1e-4 if cfm != "basic_cfm" else 0.0)
+    secs = [0.5, 1.31, 0.2, 0.5, 2.2, 0.7713, 0.05]
+    clips = [synth.lowres_clip(140 + i, s_, 12000) for i, s_ in enumerate(secs)]
+    clips[2] = (clips[2] * 20000).astype(np.int16)
+    noise = [synth.prior_noise(140 + i, (len(c) * 4) // 480) for i, c in enumerate(clips)]
+    many = m.generate_many(clips, 12000, 48000, 2, noise=noise, ragged=True)
+    assert len(many) == len(clips)
+    for i, c in enumerate(clips):
+        one = m.generate(c, 12000, 48000, 2, noise=noise[i])
+        assert tuple(many[i].shape) == tuple(one.shape) == (1, len(c) * 4)
+        assert torch.equal(many[i], one), f"clip {i} ({secs[i]} s) differs from generate() alone"
+    # max_frames splits the list into several launch sequences; same results
+    again = m.generate_many(clips, 12000, 48000, 2, noise=noise, ragged=True, max_frames=200)
+    assert all(torch.equal(a, b) for a, b in zip(again, many))

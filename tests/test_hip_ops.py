@@ -520,6 +520,53 @@ def test_attention_bits_do_not_depend_on_batch(n, big):
         assert torch.equal(one, att[b * n:(b + 1) * n])
 
 
+def test_ragged_transformer_ops_equal_per_clip_calls_bitwise():
+    """fh_*_seg_f32: clips of different lengths packed back to back (no padding rows) -- the reference's mask paths
+    (attend.py:127-128 key mask, transformer.py:35-44 conv mask, rotary positions from 0 per clip).  Every clip must
+    get exactly the bits of a call on that clip alone."""
+    H, D = 16, 1024
+    frames = [50, 333, 1, 64, 129, 1000]
+    M, max_n = sum(frames), max(frames)
+    L = hip.lib()
+    sd = synth.make_flow_state_dict(seed=3)
+    p = "flowhigh.transformer.layers.0.3."
+    gq = sd[p + "q_norm.gamma"].reshape(H, 64).contiguous().to(DEV)
+    gk = sd[p + "k_norm.gamma"].reshape(H, 64).contiguous().to(DEV)
+    cos_t, sin_t = tables.rotary_tables(sd["flowhigh.transformer.rotary_emb.inv_freq"], max_n)
+    cd, sn = cos_t.to(DEV), sin_t.to(DEV)
+    starts = np.concatenate([[0], np.cumsum(frames)[:-1]])
+    seg = torch.tensor(np.stack([starts, frames], 1), dtype=torch.int32).to(DEV)
+    qkv0 = rnd(M, 3 * D, seed=157, scale=2.0).to(DEV)
+    x = rnd(M, D, seed=158).to(DEV)
+    dw_w, dw_b = rnd(31, D, seed=159, scale=0.2).to(DEV), rnd(D, seed=160).to(DEV)
+    # packed
+    qkv = qkv0.clone()
+    hip.check(L.fh_qknorm_rope_seg_f32(qkv.data_ptr(), gq.data_ptr(), gk.data_ptr(), cd.data_ptr(), sn.data_ptr(),
+                                       seg.data_ptr(), len(frames), max_n, H, hip.stream()), "rope seg")
+    att = torch.empty(M, D, device=DEV)
+    hip.check(L.fh_attention_seg_f32(qkv.data_ptr(), att.data_ptr(), seg.data_ptr(), len(frames), max_n, H, 10.0,
+                                     hip.stream()), "attention seg")
+    y = torch.empty(M, D, device=DEV)
+    hip.check(L.fh_dwconv_gelu_res_seg_f32(x.data_ptr(), dw_w.data_ptr(), dw_b.data_ptr(), y.data_ptr(), seg.data_ptr(),
+                                           len(frames), max_n, D, 31, hip.stream()), "dwconv seg")
+    # per clip
+    for s0, n in zip(starts.tolist(), frames):
+        q1 = qkv0[s0:s0 + n].clone()
+        c1, s1 = tables.rotary_tables(sd["flowhigh.transformer.rotary_emb.inv_freq"], n)
+        c1, s1 = c1.to(DEV), s1.to(DEV)
+        hip.check(L.fh_qknorm_rope_f32(q1.data_ptr(), gq.data_ptr(), gk.data_ptr(), c1.data_ptr(), s1.data_ptr(), 1, n, H,
+                                       hip.stream()), "rope")
+        assert torch.equal(q1, qkv[s0:s0 + n])
+        a1 = torch.empty(n, D, device=DEV)
+        hip.check(L.fh_attention_f32(q1.data_ptr(), a1.data_ptr(), 1, n, H, 10.0, hip.stream()), "attention")
+        assert torch.equal(a1, att[s0:s0 + n])
+        x1 = x[s0:s0 + n].clone()
+        y1 = torch.empty(n, D, device=DEV)
+        hip.check(L.fh_dwconv_gelu_res_f32(x1.data_ptr(), dw_w.data_ptr(), dw_b.data_ptr(), y1.data_ptr(), 1, n, D, 31,
+                                           hip.stream()), "dwconv")
+        assert torch.equal(y1, y[s0:s0 + n])
+
+
 @pytest.mark.parametrize("B,n,t", [(1, 25, 0.0), (2, 200, 0.3)])
 def test_flow_forward(B, n, t):
     from flowhigh_amd.flow import FlowNet
@@ -578,6 +625,31 @@ def test_vocoder_chunked_equals_unchunked_bitwise(cfgname, B, N, chunk):
     # every chunk plan is smaller than the whole-clip plan
     chunk_plans = [k for k in dict.keys(voc._plans) if len(k) == 3]
     assert chunk_plans and all(k[1] <= chunk + 2 * halo for k in chunk_plans)
+
+
+@pytest.mark.parametrize("cfgname,frames", [("SYNTH_CFG", [50, 333, 50, 77, 201, 3]), ("TINY_CFG", [25, 7, 160, 25, 91]),
+                                            ("ALT_CFG", [20, 33, 9]), ("ALT2_CFG", [30, 12, 45]), ("ALT3_CFG", [16, 40])])
+def test_vocoder_ragged_equals_per_clip_runs_bitwise(cfgname, frames):
+    """Vocoder.forward_ragged: clips of different lengths in ONE launch sequence (one group per clip in every conv /
+    activation launch, per-group lengths).  Every clip -- including the short ones whose wide stages run as
+    input-channel slices, and two clips of EQUAL length -- gets the bits of forward() on that clip alone."""
+    cfg = getattr(synth, cfgname)
+    sd = synth.make_vocoder_state_dict(cfg, seed=1)
+    voc = V.Vocoder(cfg, sd, DEV)
+    mels = [(rnd(n, 256, seed=180 + i, scale=2.0) - 3.0).to(DEV) for i, n in enumerate(frames)]
+    alone = [voc.forward(m[None]).clone() for m in mels]
+    got = voc.forward_ragged(mels)
+    assert len(got) == len(frames)
+    for a, g in zip(alone, got):
+        assert a.shape == g.shape and torch.equal(a, g)
+    rp = voc.plan_ragged(frames)
+    per_clip = sum(len(voc.plan(1, n)["steps"]) for n in frames)
+    assert len(rp["steps"]) < per_clip and len(rp["steps"]) <= 125 + len(frames)
+    # a second call with other data reuses the merged plan
+    mels2 = [m * 0.5 for m in mels]
+    got2 = [g.clone() for g in voc.forward_ragged(mels2)]
+    for m, g in zip(mels2, got2):
+        assert torch.equal(voc.forward(m[None]), g)
 
 
 @pytest.mark.parametrize("T", [4999, 9600, 12345])
