@@ -292,10 +292,13 @@ constexpr int ACT_NTILE = ACT_NTILE_N;
 // PIN / POUT: input / output rows are phase-major for dilation din / dout (see act1d_kernel).
 // DIL > 0: the dilation of the phase-major side is this compile-time value (3 and 5 are instantiated: the per-tile
 // divisions by it become multiplies); 0: run-time value.
-template <bool VEC, bool PIN, bool POUT, int DIL = 0>
+// RAGGED (fh_act1d_ragged_f32): every group is one clip's [C, len_g] tensor (batch 1) with its own length: the row
+// geometry (len, phase length, pitch, tiles per row) is then a per-tile, wave-uniform value instead of a launch constant,
+// and a block finds its first tile through the groups' tile_base prefix.
+template <bool VEC, bool PIN, bool POUT, int DIL = 0, bool RAGGED = false>
 __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __restrict__ groups, int batch,
                                                           int channels, int len, int tiles_per_row,
-                                                          long long total_tiles, int din_arg, int dout_arg) {
+                                                          long long total_tiles, int din_arg, int dout_arg, int n_groups) {
   const int din = (DIL > 0 && PIN) ? DIL : din_arg, dout = (DIL > 0 && POUT) ? DIL : dout_arg;
   static_assert(ACT_THREADS == 256 && ACT_PPT == 4, "strip kernel is written for 256 threads x 4 outputs");
   __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
@@ -306,10 +309,8 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   // cost two s_load round trips, ~10 SGPR moves and 8 packed adds per tile.
   __shared__ __attribute__((aligned(16))) f32x2 taps[2][16];
   const int tid = threadIdx.x;
-  const int zlast = 2 * len - 1;
   const long long g0 = (long long)blockIdx.x * ACT_NTILE;
-  const int lp_in = ((len + din - 1) / din + 3) & ~3, lp_out = ((len + dout - 1) / dout + 3) & ~3;
-  const int pitch_in = PIN ? din * lp_in : len, pitch_out = POUT ? dout * lp_out : len;
+  auto lp_of = [](int l, int d) { return ((l + d - 1) / d + 3) & ~3; };
   // phase-major input: chunk q = (phase p, 4 consecutive decimated samples); <= 2 chunks per thread
   const int nq_in = PIN ? ((ACT_XS + din - 1) / din + 3) / 4 : 1;
   const int nq_out = POUT ? ((ACT_TT + dout - 1) / dout + 3) / 4 : 1;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   struct Tile {                       // wave-uniform description of one flattened tile
     __amdgpu_buffer_rsrc_t rx, ry;
     const fh_act_group* G;
-    int t0, c, gi;
+    int t0, c, gi, len;
     float alpha, inv_beta;            // vector loads, requested one tile ahead together with the tile itself
     f32x2 tap;                        // thread e < 14: tap pair e of the tile's group (loaded only if the group changes)
   };
@@ -347,13 +348,16 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   }
   // position of a flattened tile: (tile in row, channel, batch, group); the first one of the block is found by
   // 32-bit divisions, the following ones by carrying (a 64-bit division per tile cost ~400 scalar instructions)
-  struct Pos { int tile, c, bb, gi; };
+  struct Pos { int tile, c, bb, gi, tpr; };       // tpr: tiles per row of group gi
   auto pos_next = [&](Pos p) {
-    if (++p.tile == tiles_per_row) {
+    if (++p.tile == p.tpr) {
       p.tile = 0;
       if (++p.c == channels) {
         p.c = 0;
-        if (++p.bb == batch) { p.bb = 0; ++p.gi; }
+        if (RAGGED) {
+          ++p.gi;
+          p.tpr = (uni(groups[p.gi].len) + ACT_TT - 1) / ACT_TT;
+        } else if (++p.bb == batch) { p.bb = 0; ++p.gi; }
       }
     }
     return p;
@@ -363,6 +367,8 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     T.c = p.c;
     T.gi = p.gi;
     T.G = groups + p.gi;
+    T.len = RAGGED ? uni(T.G->len) : len;
+    const int pitch_in = PIN ? din * lp_of(T.len, din) : T.len, pitch_out = POUT ? dout * lp_of(T.len, dout) : T.len;
     const size_t rowi = (size_t)p.bb * channels + p.c;
     T.rx = make_rsrc(uni(T.G->x) + rowi * (size_t)pitch_in, ok ? (unsigned)pitch_in * 4u : 0u);
     T.ry = make_rsrc(uni((const float*)T.G->y) + rowi * (size_t)pitch_out, ok ? (unsigned)pitch_out * 4u : 0u);
@@ -388,6 +394,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
         const int p = pin_p[rep], k = pin_k[rep];
         const int ul = qt - 8 + (rt > p ? 1 : 0);                  // ceil((t0 - 8 - p) / din)
         const int u = (ul > 0 ? ul : 0) + 4 * k;
+        const int lp_in = lp_of(T.len, din);
         // (past the row: reads a neighbour phase or falls out of range; such samples are not used)
         xr[rep] = __builtin_amdgcn_raw_buffer_load_b128(T.rx, p < din ? (unsigned)((p * lp_in + u) * 4) : 0x80000000u, 0, 0);
         continue;
@@ -404,7 +411,21 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   };
 
   Pos pos;
-  {
+  if (RAGGED) {
+    int cnt = 0;
+    for (int base = 0; base < n_groups; base += 64) {
+      const int idx = base + (tid & 63);
+      const bool le = idx < n_groups && (long long)groups[idx].tile_base <= g0;
+      cnt += __popcll(__ballot(le));
+    }
+    pos.gi = uni(cnt - 1);
+    pos.bb = 0;
+    pos.tpr = (uni(groups[pos.gi].len) + ACT_TT - 1) / ACT_TT;
+    const unsigned local = (unsigned)g0 - (unsigned)uni(groups[pos.gi].tile_base);
+    const unsigned row = local / (unsigned)pos.tpr;
+    pos.tile = uni((int)(local - row * (unsigned)pos.tpr));
+    pos.c = uni((int)row);
+  } else {
     const unsigned g32 = (unsigned)g0;                       // total_tiles < 2^31 (checked by the launcher)
     const unsigned row = g32 / (unsigned)tiles_per_row;
     pos.tile = uni((int)(g32 - row * (unsigned)tiles_per_row));
@@ -412,6 +433,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     pos.c = uni((int)(row - gb * (unsigned)channels));
     pos.gi = uni((int)(gb / (unsigned)batch));
     pos.bb = uni((int)(gb - (unsigned)pos.gi * (unsigned)batch));
+    pos.tpr = tiles_per_row;
   }
   Tile T = tile_of(pos, true, -1);
   int tbuf = 0, gi_prev = -1;
@@ -430,6 +452,8 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     gi_prev = T.gi;
     const f32x2* tp = taps[tbuf];
     const float alpha = T.alpha, inv_beta = T.inv_beta;
+    const int len = T.len, zlast = 2 * len - 1;              // (shadow the launch value: this tile's row length)
+    const int lp_out = POUT ? lp_of(len, dout) : 0;
     if (PIN) {                 // scatter the phase chunks to their natural positions (stride din, odd: conflict free)
       const int tb = T.t0 - 8;
       const int tb8 = uni(tb + 8 * din);
@@ -619,10 +643,10 @@ extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups,
     const bool vec = (len & 3) == 0;   // rows 16-byte aligned provided the tensors are (checked by the host plan)
 #define FH_ACT_LAUNCH(V, PI, PO)                                                                              \
   hipLaunchKernelGGL((act1d_strip_kernel<V, PI, PO>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
-                     groups, batch, channels, len, tiles, blocks, din, dout)
+                     groups, batch, channels, len, tiles, blocks, din, dout, n_groups)
 #define FH_ACT_LAUNCH_D(PI, PO, D)                                                                            \
   hipLaunchKernelGGL((act1d_strip_kernel<true, PI, PO, D>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
-                     groups, batch, channels, len, tiles, blocks, din, dout)
+                     groups, batch, channels, len, tiles, blocks, din, dout, n_groups)
     if (din > 1 && dout > 1) FH_ACT_LAUNCH(false, true, true);
     else if (din > 1) {
       if (vec && din == 3) FH_ACT_LAUNCH_D(true, false, 3);
@@ -649,10 +673,24 @@ extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups,
 extern "C" int fh_act_tile_len(void) { return ACT_TT; }
 
 extern "C" int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, int din, int dout,
-                                   long long total_tiles, void* stream) {
+                                   long long total_tiles, int all_len_mult4, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && channels > 0 && total_tiles > 0 && total_tiles < (1ll << 31),
                "fh_act1d_ragged_f32: bad sizes");
   FH_CHECK_ARG(din >= 1 && dout >= 1 && din <= 64 && dout <= 64, "fh_act1d_ragged_f32: bad dilations %d / %d", din, dout);
+  if (din <= 16 && dout <= 16 && !getenv("FH_ACT_NO_STRIP")) {      // (row bytes < 2^31: checked by the host plan)
+    const long long strips = (total_tiles + ACT_NTILE - 1) / ACT_NTILE;
+    const bool vec = all_len_mult4 != 0;
+#define FH_ACT_RLAUNCH(V, PI, PO)                                                                                       \
+  hipLaunchKernelGGL((act1d_strip_kernel<V, PI, PO, 0, true>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
+                     groups, 1, channels, 0, 1, total_tiles, din, dout, n_groups)
+    if (din > 1 && dout > 1) FH_ACT_RLAUNCH(false, true, true);
+    else if (din > 1) { if (vec) FH_ACT_RLAUNCH(true, true, false); else FH_ACT_RLAUNCH(false, true, false); }
+    else if (dout > 1) { if (vec) FH_ACT_RLAUNCH(true, false, true); else FH_ACT_RLAUNCH(false, false, true); }
+    else { if (vec) FH_ACT_RLAUNCH(true, false, false); else FH_ACT_RLAUNCH(false, false, false); }
+#undef FH_ACT_RLAUNCH
+    FH_CHECK_LAUNCH("fh_act1d_ragged_f32");
+    return FH_OK;
+  }
   hipLaunchKernelGGL(act1d_kernel<true>, dim3((unsigned)total_tiles), dim3(ACT_THREADS), 0, (hipStream_t)stream, groups,
                      1, channels, 0, 1, din, dout, n_groups);
   FH_CHECK_LAUNCH("fh_act1d_ragged_f32");

@@ -102,7 +102,7 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
 template <int MT, int NT, int SUBS, bool VL>
 __global__ __attribute__((amdgpu_flat_work_group_size(W_THREADS, W_THREADS), amdgpu_waves_per_eu(3, 3)))
 void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles,
-                      int n_tiles, int run_len, int dil, int pm) {
+                      int n_tiles, int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs) {
   using Cfg = WCfg<MT, NT, SUBS>;
   constexpr int W_BM = Cfg::BM, W_BT = Cfg::BT, W_P = Cfg::P, W_RP2 = Cfg::RP2, W_XPT = Cfg::XPT, W_SLAB = Cfg::SLAB;
   constexpr int W_SUB = (W_CK / 2) * W_RP2;          // floats of one 16-channel chunk inside a slab buffer
@@ -119,7 +119,15 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const int total_runs = panels * runs_per_panel;
   const int bid = blockIdx.x;
   const int slot = bid >> 3;
-  const int run = (slot / run_len) * 8 + (bid & 7);
+  int run = (slot / run_len) * 8 + (bid & 7);
+  // Ragged launches (groups of different lengths, grid sized for the longest): only the runs that hold real tiles
+  // are launched, listed heavy-first in run_map -- otherwise the empty runs of the short clips, which fall on
+  // the same XCDs for every panel (run r of a panel -> XCD (panel * runs_per_panel + r) % 8), leave the real work
+  // on 2-4 of the 8 XCDs.
+  if (run_map) {
+    if (run >= n_runs) return;
+    run = uni(run_map[run]);
+  }
   if (run >= total_runs) return;
   const int panel = uni(run / runs_per_panel);
   const int ntile = uni((run % runs_per_panel) * run_len + (slot % run_len));
@@ -627,14 +635,14 @@ namespace {
 
 template <int MT, int NT, int SUBS, bool VL>
 int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
-                int phase_major, hipStream_t stream) {
+                int phase_major, hipStream_t stream, const int* run_map = nullptr, int n_runs = 0) {
   using Cfg = WCfg<MT, NT, SUBS>;
   FH_CHECK_ARG(cout_pad > 0 && cout_pad % Cfg::BM == 0, "fh_conv_wino_f32: cout_pad %d not a multiple of %d", cout_pad, Cfg::BM);
   const int co_tiles = cout_pad / Cfg::BM;
   const int n_tiles = fh_cdiv(fh_cdiv(len, dilation), 4 * Cfg::BT) * dilation;
   const long long panels = (long long)n_groups * batch * co_tiles;
   const int run_len = fh_cdiv(n_tiles, fh_cdiv(n_tiles, W_RUN));
-  const long long runs = panels * fh_cdiv(n_tiles, run_len);
+  const long long runs = run_map ? (long long)n_runs : panels * fh_cdiv(n_tiles, run_len);
   const long long blocks = (long long)fh_cdiv(runs, 8) * 8 * run_len;
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino_f32: grid too large");
   static bool lds_opt_in = false;      // > 64 KB of dynamic LDS needs the attribute once per process
@@ -648,21 +656,21 @@ int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cou
     lds_opt_in = true;
   }
   hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS, VL>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
-                     stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major);
+                     stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major, run_map, n_runs);
   FH_CHECK_LAUNCH("fh_conv_wino_f32");
   return FH_OK;
 }
 
 template <int MT, int NT, int SUBS>
 int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
-                int phase_major, hipStream_t stream) {
+                int phase_major, hipStream_t stream, const int* run_map = nullptr, int n_runs = 0) {
   // 16-byte slab loads need contiguous aligned rows (tensors themselves 16-byte aligned: host plan)
   // (phase_major bit 1: the caller rules the vector loader out -- ragged launches in which some group's rows are
   // not 16-byte aligned; `len` is then only the longest group's length)
   const bool pm = (phase_major & 1) != 0;
   const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2) && !getenv("FH_WINO_NO_VL");
-  return vl ? launch_wino_vl<MT, NT, SUBS, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream)
-            : launch_wino_vl<MT, NT, SUBS, false>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream);
+  return vl ? launch_wino_vl<MT, NT, SUBS, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs)
+            : launch_wino_vl<MT, NT, SUBS, false>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs);
 }
 
 }  // namespace
@@ -673,19 +681,36 @@ extern "C" int fh_wino_tile_m(int tile_cfg) {
 
 extern "C" int fh_phase_len(int len, int dilation) { return ((len + dilation - 1) / dilation + 3) & ~3; }
 
+namespace {
+int wino_dispatch(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
+                  int phase_major, int tile_cfg, hipStream_t st, const int* run_map, int n_runs) {
+  switch (tile_cfg) {
+    case 0: return launch_wino<2, 2, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 1: return launch_wino<3, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 4: return launch_wino<2, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 5: return launch_wino<1, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 6: return launch_wino<4, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+  }
+  fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
+  return FH_E_ARG;
+}
+}  // namespace
+
 extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad,
                                 int len, int dilation, int phase_major, int tile_cfg, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && len > 0, "fh_conv_wino_f32: bad sizes");
   FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino_f32: dilation %d unsupported", dilation);
   // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cin * len * 4 < 2^31
   // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
-  switch (tile_cfg) {
-    case 0: return launch_wino<2, 2, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
-    case 1: return launch_wino<3, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
-    case 4: return launch_wino<2, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
-    case 5: return launch_wino<1, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
-    case 6: return launch_wino<4, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, (hipStream_t)stream);
-  }
-  fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
-  return FH_E_ARG;
+  return wino_dispatch(groups, n_groups, batch, cout_pad, len, dilation, phase_major, tile_cfg, (hipStream_t)stream, nullptr, 0);
+}
+
+extern "C" int fh_wino_tile_n(int tile_cfg) { return tile_cfg == 0 ? 512 : (fh_wino_tile_m(tile_cfg) > 0 ? 256 : -1); }
+extern "C" int fh_wino_run_len(int n_tiles) { return n_tiles > 0 ? fh_cdiv(n_tiles, fh_cdiv(n_tiles, W_RUN)) : -1; }
+
+extern "C" int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
+                                       int phase_major, int tile_cfg, const int* run_map, int n_runs, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && max_len > 0 && run_map && n_runs > 0, "fh_conv_wino_ragged_f32: bad sizes");
+  FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino_ragged_f32: dilation %d unsupported", dilation);
+  return wino_dispatch(groups, n_groups, 1, cout_pad, max_len, dilation, phase_major, tile_cfg, (hipStream_t)stream, run_map, n_runs);
 }

@@ -69,6 +69,9 @@ _SIGS = {
     "fh_wino_tile_m": [_I],
     "fh_phase_len": [_I, _I],
     "fh_conv_wino_f32": [_P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fh_wino_tile_n": [_I],
+    "fh_wino_run_len": [_I],
+    "fh_conv_wino_ragged_f32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "fh_mean_f32": [_P, _P, _P, _P, C.c_longlong, _F, _P],
     "fh_sum_f32": [_P, C.c_int, _P, C.c_longlong, _F, _P],
     "fh_debug_set_conv_trace": [_P],
@@ -77,7 +80,7 @@ _SIGS = {
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_pm_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
     "fh_act_tile_len": [],
-    "fh_act1d_ragged_f32": [_P, _I, _I, _I, _I, C.c_longlong, _P],
+    "fh_act1d_ragged_f32": [_P, _I, _I, _I, _I, C.c_longlong, _I, _P],
     "fh_sizeof_sum_job": [],
     "fh_sum_multi_f32": [_P, _I, C.c_longlong, _P],
     "fh_attention_seg_f32": [_P, _P, _P, _I, _I, _I, _F, _P],

@@ -891,8 +891,33 @@ class Vocoder:
                         # the launch model takes one length: the mean one keeps the block count honest
                         mean_len = max(1, sum(t[1] for t in allg) // len(allg))
                         wcfg, _ = choose_wino_cfg([t[0] for t in allg], 1, wpad, mean_len, dil, default=default)
+                    if os.environ.get("FH_RAGGED_WCFG"):            # (A/B experiments)
+                        forced = int(os.environ["FH_RAGGED_WCFG"])
+                        if wpad % _WINO_TILES[forced][0] == 0:
+                            wcfg = forced
                     novl = 0 if (pm or all(t[1] % 4 == 0 for t in allg)) else 2
-                    merged.append(("rwino", blob([t[2] for t in allg]), len(allg), wpad, maxlen, dil, wcfg, int(pm) | novl))
+                    # runs (consecutive tiles of one (group, co tile) panel, dealt to one XCD) that hold real tiles
+                    bm, bt = _WINO_TILES[wcfg]
+                    cot = wpad // bm
+                    n_tiles = -(-(-(-maxlen // dil)) // bt) * dil
+                    run_len = hip.lib().fh_wino_run_len(n_tiles)
+                    rpp = -(-n_tiles // run_len)
+                    runs = []
+                    for gi, (_, length, _) in enumerate(allg):
+                        # tile index = (block of bt outputs within the phase) * dil + phase: real while its first
+                        # output (phase + dil * bt * block) lies inside the row
+                        # (blocks per phase differ by at most one, so the real tiles are 0 .. t_last without holes)
+                        nb = [max(0, -(-(length - ph) // (dil * bt))) for ph in range(dil)]
+                        t_last = dil * (nb[0] - 1) + sum(1 for v in nb if v == nb[0]) - 1
+                        own = range(t_last // run_len + 1)
+                        for ct in range(cot):
+                            runs += [(gi * cot + ct) * rpp + r for r in own]
+                    rmap = (C.c_int32 * len(runs))(*runs)
+                    off_map = sum(len(b) for b in blobs)
+                    raw = bytes(rmap)
+                    blobs.append(raw + bytes(-len(raw) % 16))
+                    merged.append(("rwino", blob([t[2] for t in allg]), len(allg), wpad, maxlen, dil, wcfg,
+                                   int(pm) | novl, off_map, len(runs)))
             elif kind == "conv":
                 classes = {}
                 for ci, st_, groups in items:
@@ -917,7 +942,7 @@ class Vocoder:
                             g2.len, g2.tile_base = length, base
                             base += c * -(-length // tt)
                             out.append(g2)
-                    merged.append(("ract", blob(out), len(out), c, din, dout, base))
+                    merged.append(("ract", blob(out), len(out), c, din, dout, base, int(all(g.len % 4 == 0 for g in out))))
             elif kind == "sum":
                 jobs = []
                 for ci, st_, _ in items:
@@ -949,14 +974,15 @@ class Vocoder:
         L, st, base = hip.lib(), hip.stream(), rp["desc"].data_ptr()
         for s in rp["steps"]:
             if s[0] == "rwino":
-                _, off, ng, wpad, maxlen, dil, wcfg, pmflag = s
-                hip.check(L.fh_conv_wino_f32(base + off, ng, 1, wpad, maxlen, dil, pmflag, wcfg, st), "fh_conv_wino_f32")
+                _, off, ng, wpad, maxlen, dil, wcfg, pmflag, off_map, n_runs = s
+                hip.check(L.fh_conv_wino_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, wcfg, base + off_map, n_runs, st),
+                          "fh_conv_wino_ragged_f32")
             elif s[0] == "rconv":
                 _, off, ng, cpad, maxlen, tcfg, ck = s
                 hip.check(L.fh_conv_grouped_f32(base + off, ng, 1, cpad, maxlen, tcfg, ck, st), "fh_conv_grouped_f32")
             elif s[0] == "ract":
-                _, off, ng, c, din, dout, tiles = s
-                hip.check(L.fh_act1d_ragged_f32(base + off, ng, c, din, dout, tiles, st), "fh_act1d_ragged_f32")
+                _, off, ng, c, din, dout, tiles, mult4 = s
+                hip.check(L.fh_act1d_ragged_f32(base + off, ng, c, din, dout, tiles, mult4, st), "fh_act1d_ragged_f32")
             elif s[0] == "rsum":
                 _, off, nj, max_n = s
                 hip.check(L.fh_sum_multi_f32(base + off, nj, max_n, st), "fh_sum_multi_f32")

@@ -143,6 +143,15 @@ int fh_phase_len(int len, int dilation);
  * every group are phase-major for this dilation (see above), else plain [B, C, len]. */
 int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
                      int dilation, int phase_major, int tile_cfg, void* stream);
+/* Ragged form (clips of different lengths, one group per clip and AMP block, batch 1): the grid is laid out for
+ * max_len; a "run" is fh_wino_run_len(n_tiles) consecutive output tiles of one (group, co tile) panel
+ * (n_tiles = ceil(ceil(max_len / dilation) / fh_wino_tile_n(tile_cfg)) * dilation), run id = panel * runs_per_panel +
+ * run-in-panel with panel = group * co_tiles + co tile.  run_map (device int32 [n_runs]) lists the runs that hold
+ * real tiles, in launch order (heavy groups first): they are dealt round-robin to the 8 XCDs. */
+int fh_wino_tile_n(int tile_cfg);
+int fh_wino_run_len(int n_tiles);
+int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
+                            int phase_major, int tile_cfg, const int* run_map, int n_runs, void* stream);
 
 /* out = ((a + b) + c) * scale over n floats (c may be NULL; n % 4 == 0, 16-byte aligned pointers): the
  * `xs += resblock(x); x = xs / num_kernels` of BigVGAN.forward (models/bigvgan/models.py:183-188) for the
@@ -209,10 +218,11 @@ int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups, int batch,
                             int din, int dout, void* stream);
 /* Ragged batches (clips of different lengths in ONE launch): group g = one clip's [C, groups[g].len] tensor,
  * total_tiles = groups[n-1].tile_base + C * ceil(groups[n-1].len / fh_act_tile_len()).  Same arithmetic per
- * sample as the launches above (replicate padding at each clip's own ends). */
+ * sample as the launches above (replicate padding at each clip's own ends).  all_len_mult4: every group's len is a
+ * multiple of 4 (rows 16-byte aligned: vector accesses). */
 int fh_act_tile_len(void);
 int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, int din, int dout,
-                        long long total_tiles, void* stream);
+                        long long total_tiles, int all_len_mult4, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 MFMA GEMM:  C[M, N] = epilogue( A[M, K] * W[N, K]^T )

@@ -644,7 +644,7 @@ def test_vocoder_ragged_equals_per_clip_runs_bitwise(cfgname, frames):
         assert a.shape == g.shape and torch.equal(a, g)
     rp = voc.plan_ragged(frames)
     per_clip = sum(len(voc.plan(1, n)["steps"]) for n in frames)
-    assert len(rp["steps"]) < per_clip and len(rp["steps"]) <= 125 + len(frames)
+    assert len(rp["steps"]) <= 150 and (len(frames) < 3 or 2 * len(rp["steps"]) < per_clip)      # merged, not concatenated
     # a second call with other data reuses the merged plan
     mels2 = [m * 0.5 for m in mels]
     got2 = [g.clone() for g in voc.forward_ragged(mels2)]
