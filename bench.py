@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 1 for --config 2, 32 for --config 4)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("FH_BENCH_GRAPH", "0")),
+                    help="1: a step replays the HIP graph of generate_from_device (same launches, one enqueue)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -151,6 +153,16 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    eager_step = step
+    if args.graph and not conf["sharded"]:
+        graphed = model.capture(B, n_in, sr_in, STEPS_ODE)       # the ~150 launches of a step recorded once
+        graphed.x.copy_(x)
+        graphed.noise.copy_(z.reshape(graphed.noise.shape))
+
+        def step():                                               # noqa: F811
+            return graphed.replay()
+        for _ in range(2):
+            out = step()
     voc = model.flowhigh.vocoder
     # HIP events (on the launch stream = torch's current stream) around every conv and every Activation1d launch
     # of every 8th timed step: an event pair costs ~6 us of stream time, sampling keeps that under 0.5 %
@@ -162,7 +174,7 @@ def main():
         voc.conv_timing = conv_ev if sampled else None
         voc.act_timing = act_ev if sampled else None
         timed_steps += sampled
-        out = step()
+        out = eager_step() if sampled else step()          # (HIP events cannot be recorded inside a graph replay)
     barrier()
     elapsed = time.perf_counter() - t0
     voc.conv_timing = voc.act_timing = None
@@ -224,7 +236,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "hip_graph": bool(args.graph and not conf["sharded"]),
             "config": {"workload": f"{conf['name']}: B={B} per GPU x 10 s clip, {sr_in // 1000}->48 kHz, time_step=1 euler, "
                                    "transformer 2x16x64, BigVGAN-48k-256band SYNTH-CFG (rates 5,4,3,2,2,2; C0 1536), "
                                    "random-init weights",
