@@ -41,3 +41,108 @@ def test_checkpoints_load_with_the_safe_unpickler(tmp_path, monkeypatch):
     monkeypatch.delenv("FH_UNSAFE_LOAD", raising=False)
     with pytest.raises(RuntimeError, match="weights_only"):
         _load_checkpoint(tmp_path / "evil.pt")
+
+
+# ------------------------------------------------------------------------------------------
+# vocoder launch plans: host logic only (descriptors are built against CPU tensors, nothing is launched)
+# ------------------------------------------------------------------------------------------
+def _cpu_vocoder(cfgname):
+    from flowhigh_amd.vocoder import Vocoder
+    cfg = getattr(synth, cfgname)
+    return Vocoder(cfg, synth.make_vocoder_state_dict(cfg, 1), "cpu")
+
+
+@pytest.mark.parametrize("cfgname", ["SYNTH_CFG", "ALT_CFG", "ALT2_CFG", "ALT3_CFG"])
+def test_plan_steps_have_unique_sorted_position_keys(cfgname):
+    """Every launch of a plan is tagged (stage, sub-block, slot, index); plan_ragged merges the plans of different
+    clips by that key, so within one plan the keys must be unique and already in launch order."""
+    voc = _cpu_vocoder(cfgname)
+    for n in (7, 50, 333):
+        p = voc.plan(1, n)
+        keys = [m[0] for m in p["meta"]]
+        assert len(keys) == len(p["steps"]) and len(set(keys)) == len(keys) and keys == sorted(keys)
+        for step, (_, structs) in zip(p["steps"], p["meta"]):
+            assert (structs is not None) == (step[0] in ("conv", "wino", "act"))
+            if structs is not None:
+                assert len(structs) == step[2]
+
+
+def test_plan_ragged_merges_launch_by_launch():
+    """One merged launch per position and kernel class: the group count of a merged launch is the sum over the
+    clips, activation groups carry their own length and an exact tile prefix, Winograd run maps list only runs that
+    hold real tiles, and two clips of equal length get plans (buffers) of their own."""
+    import ctypes as C
+    from flowhigh_amd import hip
+    voc = _cpu_vocoder("SYNTH_CFG")
+    frames = [50, 333, 50, 120]
+    rp = voc.plan_ragged(frames)
+    assert rp["subs"][0] is not rp["subs"][2] and rp["subs"][0]["wav"].data_ptr() != rp["subs"][2]["wav"].data_ptr()
+    per_clip = [voc.plan(1, n, inst=i) for n, i in zip(frames, (0, 0, 1, 0))]
+    assert all(a is b for a, b in zip(per_clip, rp["subs"]))
+    raw = bytes(rp["desc"].numpy().tobytes())
+    tt = hip.lib().fh_act_tile_len()
+    n_act_groups = sum(s[2] for p in per_clip for s in p["steps"] if s[0] == "act")
+    n_wino_groups = sum(s[2] for p in per_clip for s in p["steps"] if s[0] == "wino")
+    got_act = got_wino = 0
+    for s in rp["steps"]:
+        if s[0] == "ract":
+            _, off, ng, c, din, dout, tiles, mult4 = s
+            gs = (hip.ActGroup * ng).from_buffer_copy(raw[off:off + ng * C.sizeof(hip.ActGroup)])
+            base = 0
+            for g in gs:
+                assert g.tile_base == base and g.len > 0
+                base += c * -(-g.len // tt)
+            assert base == tiles and mult4 == int(all(g.len % 4 == 0 for g in gs))
+            assert [g.len for g in gs] == sorted((g.len for g in gs), reverse=True)
+            got_act += ng
+        elif s[0] == "rwino":
+            _, off, ng, wpad, maxlen, dil, wcfg, pmflag, off_map, n_runs = s
+            gs = (hip.WinoGroup * ng).from_buffer_copy(raw[off:off + ng * C.sizeof(hip.WinoGroup)])
+            assert max(g.len for g in gs) == maxlen
+            runs = (C.c_int32 * n_runs).from_buffer_copy(raw[off_map:off_map + 4 * n_runs])
+            bm, bt = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256)}[wcfg]
+            n_tiles = -(-(-(-maxlen // dil)) // bt) * dil
+            run_len = hip.lib().fh_wino_run_len(n_tiles)
+            rpp = -(-n_tiles // run_len)
+            assert len(set(runs)) == n_runs and all(0 <= r < ng * (wpad // bm) * rpp for r in runs)
+            for r in runs:                                   # the run's first tile starts inside its group's row
+                g = gs[(r // rpp) // (wpad // bm)]
+                t = (r % rpp) * run_len
+                assert (t % dil) + dil * bt * (t // dil) < g.len
+            # ... and every real tile is covered
+            want = sum((wpad // bm) * len({t // run_len for t in range(n_tiles) if (t % dil) + dil * bt * (t // dil) < g.len})
+                       for g in gs)
+            assert want == n_runs
+            got_wino += ng
+    assert got_act == n_act_groups and got_wino == n_wino_groups
+    assert voc.plan_ragged(frames) is rp                               # cached
+
+
+def test_chunk_geometry_covers_the_receptive_field():
+    """halo >= the receptive field of a waveform sample in mel frames (counted layer by layer here), and chunk starts
+    keep every stage's Winograd tile position and dilation phase."""
+    import math
+    for cfgname in ("SYNTH_CFG", "ALT_CFG", "ALT2_CFG", "ALT3_CFG"):
+        voc = _cpu_vocoder(cfgname)
+        halo, align = voc.chunk_geometry()
+        cfg = getattr(synth, cfgname)
+        rates, ks, dils = cfg["upsample_rates"], cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"]
+        h = 3 + 6                                                # conv_post, activation_post (samples at the output rate)
+        for i in reversed(range(len(rates))):
+            per_block = []
+            for k, dl in zip(ks, dils):
+                if str(cfg["resblock"]) == "1":
+                    per_block.append(sum(6 + (k - 1) // 2 * d + 6 + (k - 1) // 2 for d in dl))
+                else:
+                    per_block.append(sum(6 + (k - 1) // 2 * d for d in dl))
+            h += max(per_block)
+            h = math.ceil((h + cfg["upsample_kernel_sizes"][i]) / rates[i])      # transposed conv, seen from its input
+        h += 3                                                   # conv_pre
+        assert halo >= h, (cfgname, halo, h)
+        rate = 1
+        for u in rates:
+            assert (align * rate) % 4 == 0                       # input of the (Winograd) transposed conv
+            rate *= u
+            for dl in dils:
+                for d in dl:
+                    assert (align * rate) % (4 * d) == 0         # tile position and phase at this stage
