@@ -74,6 +74,41 @@ def cpu_baseline(sd, cfg, sr_in):
                       f"({warm:.1f} s) + median of {runs} run(s), {threads} torch threads of {avail} visible host CPUs"}
 
 
+def alt_bf16x6(sd, cfg, dev, sr_in, x, z, out_fp32, B, n_frames, steps):
+    """NOT the headline: the same workload with the vocoder's Winograd convs in the opt-in bf16 x 6 form
+    (FLowHigh(..., conv_bf16x6=True): every fp32 operand split exactly into three bf16 pieces, six
+    v_mfma_f32_32x32x16_bf16 per 16-channel k-block, fp32 accumulation -- fp32-grade products on the BF16 matrix
+    cores).  Reported next to the fp32-MFMA headline with its distance from that form's waveform."""
+    from flowhigh_amd import FLowHigh, FlowHighSR
+    model = FlowHighSR(FLowHigh(sd, cfg, dev, conv_bf16x6=True), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
+    voc = model.flowhigh.vocoder
+    for _ in range(3):
+        out = model.generate_from_device(x, sr_in, STEPS_ODE, noise=z)
+    conv_ev, timed = [], 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        voc.conv_timing = conv_ev if i % EVENT_EVERY == 0 else None
+        timed += i % EVENT_EVERY == 0
+        out = model.generate_from_device(x, sr_in, STEPS_ODE, noise=z)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    voc.conv_timing = None
+    conv_ms = sum(a.elapsed_time(b) for a, b in conv_ev) / max(timed, 1)
+    plan = voc.plan(B, n_frames)
+    # matrix-core FLOPs actually issued: 6 bf16 MFMAs per fp32 k-block in the Winograd launches, fp32 MFMAs in the rest
+    bf16_tflops = 6.0 * (plan["conv_executed_flops"] - plan["conv_direct_flops"]) / (conv_ms / 1e3) / 1e12 if conv_ms > 0 else 0.0
+    return {"value": round(B * SECS / dt, 3), "unit": "audio-seconds/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "conv_ms_per_step": round(conv_ms, 3),
+            "dtype": "f32 in / out / accumulate; Winograd-conv products as 6 bf16 MFMAs over exact 3-piece splits",
+            "max_abs_diff_vs_fp32_mfma_waveform": float((out - out_fp32).abs().max().item()),
+            "fp32_equivalent_tflops_executed": round(plan["conv_executed_flops"] / (conv_ms / 1e3) / 1e12, 2) if conv_ms > 0 else 0.0,
+            "bf16_mfma_tflops_issued": round(bf16_tflops, 1), "bf16_peak": 2500.0,
+            "bf16_frac": round(bf16_tflops / 2500.0, 4),
+            "note": "opt-in (conv_bf16x6=True / FH_CONV_BF16X6=1), not the headline; bf16_frac = bf16 MFMA FLOPs of the "
+                    "Winograd launches / time of ALL conv launches (the direct-kernel ones stay fp32 MFMA) / 2.5 PFLOP/s"}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (never exec:
     nothing here has touched a GPU yet, and nothing will in this process)."""
@@ -97,6 +132,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 1 for --config 2, 32 for --config 4)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the opt-in bf16 x 6 conv form's side measurement")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("FH_BENCH_GRAPH", "0")),
                     help="1: a step replays the HIP graph of generate_from_device (same launches, one enqueue)")
     args = ap.parse_args()
@@ -277,6 +313,8 @@ def main():
                              "algorithmic_mb_per_launch": round(act_bytes_per_launch / 1e6, 2),
                              "act_ms_per_step": round(act_ms / max(timed_steps, 1), 3)},
         }
+        if not args.no_alt and world == 1 and args.config == 2:
+            line["alt_conv_bf16x6"] = alt_bf16x6(sd, cfg, dev, sr_in, x, z, out, B, n_frames, max(10, args.steps // 2))
         if not args.no_cpu_baseline and world == 1 and args.config == 2:
             line["cpu_baseline"] = cpu_baseline(sd, cfg, sr_in)
         else:

@@ -43,6 +43,36 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// ---- fp32 operands as three bf16 pieces (BF = true kernels) ---------------------------------------------------------
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest even; the two
+// subtractions are exact in fp32): 3 x 8 significant bits.  A product a b is summed over the six leading piece
+// pairs (hh, hm, mh, mm, hl, lh) by six v_mfma_f32_32x32x16_bf16 per 16-channel k-block into the SAME fp32
+// accumulator; the dropped pairs (ml, lm, ll) are <= 2^-24 |a b|, below the rounding of the fp32 accumulation itself
+// (tools/micro/bf16x6.hip: a 32 x 32 x 1024 product against float64: 4.17e-7 of sum |a b| for this form, 4.19e-7 for
+// v_mfma_f32_32x32x2_f32).  6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64: 0.375 of the matrix-pipe cycles.
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {          // v_cvt_pk_bf16_f32
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+  unsigned hp[4], mp[4], lp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    hp[i] = pack_bf16(a, b);
+    const float ra = a - __uint_as_float(hp[i] << 16), rb = b - __uint_as_float(hp[i] & 0xffff0000u);
+    mp[i] = pack_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(mp[i] << 16), sb = rb - __uint_as_float(mp[i] & 0xffff0000u);
+    lp[i] = pack_bf16(sa, sb);
+  }
+  h = __builtin_bit_cast(bf16x8, (u32x4){hp[0], hp[1], hp[2], hp[3]});
+  m = __builtin_bit_cast(bf16x8, (u32x4){mp[0], mp[1], mp[2], mp[3]});
+  l = __builtin_bit_cast(bf16x8, (u32x4){lp[0], lp[1], lp[2], lp[3]});
+}
+constexpr int W_A3 = 24;             // floats (96 bytes) per output row and 16-channel chunk of the 3-piece weights
 
 constexpr int W_CK = 16;             // input channels per chunk
 constexpr int W_THREADS = 768;       // 12 waves = 6 transform points x 2 tile halves
@@ -99,7 +129,11 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
 
 // VL: the slab is fetched with 16-byte loads (4 consecutive samples of 2 channels per thread) and written with
 // 8-byte LDS stores; needs contiguous, 16-byte aligned rows: phase-major tensors, or dilation 1 and len % 4 == 0.
-template <int MT, int NT, int SUBS, bool VL>
+// BF: the transformed weights are stored as three bf16 pieces, [C_in/16][tap group][6][C_out_pad][3][16] (96 bytes per
+// row and chunk: lane (row, half) reads its 8 channels of each piece as one 16-byte load), the B fragments are
+// split in registers, and a 16-channel k-block is six v_mfma_f32_32x32x16_bf16 (see split8 above).  The lane <->
+// channel assignment is the one of the fp32 form: lane half h owns channels 8 h .. 8 h + 7 of the chunk.
+template <int MT, int NT, int SUBS, bool VL, bool BF>
 __global__ __attribute__((amdgpu_flat_work_group_size(W_THREADS, W_THREADS), amdgpu_waves_per_eu(3, 3)))
 void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles,
                       int n_tiles, int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs) {
@@ -249,6 +283,19 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       areg[mt][h] = __builtin_amdgcn_raw_buffer_load_b128(r, a_lane + mt * 32 * W_CK * 4 + 16 * h, 0, 0);
   };
 
+  // BF: the three pieces of one step, [mt][piece]
+  u32x4 a3[BF ? MT : 1][3];
+  const int a3_lane = (l31 * W_A3 + lh * 4) * 4;
+  auto load_a3 = [&](const WSeg& S, int chunk, int g, bool valid) {
+    const float* up = uni(S.u + ((size_t)((chunk * S.ngrp + g) * 6 + xi) * cout_pad + co0) * W_A3);
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? W_BM * W_A3 * 4 : 0);
+#pragma unroll
+    for (int mt = 0; mt < (BF ? MT : 1); ++mt)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        a3[mt][pc] = __builtin_amdgcn_raw_buffer_load_b128(r, a3_lane + mt * 32 * W_A3 * 4 + 32 * pc, 0, 0);
+  };
+
   // L2 warm-up of the A tiles of the NEXT chunk (all its tap groups, this wave's xi): the register
   // prefetch above is only half a step deep, enough for an L2 hit but not for HBM, and the blocks
   // that share a weight panel run in lockstep, so without this every tile is a first touch for all
@@ -256,21 +303,27 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   // result is never read (pf stays live so that its register is not reused under the late write).
   unsigned pf = 0;
   auto prefetch_a = [&](const WSeg& S, int chunk, bool valid) {
-    const float* up = uni(S.u + ((size_t)(chunk * S.ngrp * 6 + xi) * cout_pad + co0) * W_CK);
-    const unsigned gstride = 6u * (unsigned)cout_pad * W_CK * 4u;          // bytes between tap groups
-    const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? (unsigned)(S.ngrp - 1) * gstride + W_BM * W_CK * 4 : 0u);
+    constexpr int ROWF = BF ? W_A3 : W_CK;                                 // floats per weight row and chunk
+    const float* up = uni(S.u + ((size_t)(chunk * S.ngrp * 6 + xi) * cout_pad + co0) * ROWF);
+    const unsigned gstride = 6u * (unsigned)cout_pad * ROWF * 4u;          // bytes between tap groups
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? (unsigned)(S.ngrp - 1) * gstride + W_BM * ROWF * 4 : 0u);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      // (lanes past the tile's BM / 2 lines: out of range)
-      const unsigned off = l31 < W_BM / 2 ? (unsigned)(2 * j + lh) * gstride + (unsigned)l31 * 128u : 0x80000000u;
+      // (lanes past the tile's lines: out of range; the 96-byte rows of the BF form are 0.75 W_BM lines, the first
+      // 32 lanes' worth of which is touched: enough to start the L2 fill of the tile)
+      const unsigned off = l31 < W_BM * ROWF / 32 ? (unsigned)(2 * j + lh) * gstride + (unsigned)l31 * 128u : 0x80000000u;
       asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pf) : "v"(off), "s"(r) : "memory");
     }
   };
 
   // ---- prologue -------------------------------------------------------------------------------
   WSeg S0 = load_wseg(&G->seg[0]);
-  load_a_half(0, S0, 0, 0, true);
-  load_a_half(1, S0, 0, 0, true);
+  if constexpr (BF) {
+    load_a3(S0, 0, 0, true);
+  } else {
+    load_a_half(0, S0, 0, 0, true);
+    load_a_half(1, S0, 0, 0, true);
+  }
   int xbuf = 0;
 #pragma unroll
   for (int sub = 0; sub < SUBS; ++sub) {
@@ -321,10 +374,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           for (int nt = 0; nt < NT; ++nt) xr[slot][r][nt] = *reinterpret_cast<const f32x2*>(q + 128 * nt);
         }
       };
-      fetch(0, 0);
-#pragma unroll
-      for (int p = 0; p < 4 * GC; ++p) {
-        const int g = p >> 2, kp = p & 3, h = kp >> 1;
+      // staging of the NEXT chunk's slab, spread over this chunk's pairs (called with the pair index)
+      auto stage = [&](int p) {
 #if !(defined(WINO_ABL) && (WINO_ABL & 8))       // timing experiment: slab of the first chunk only
         if constexpr (VL) {
           // item 0 at the first pair; with two items per thread the first is stored (the other buffer is
@@ -348,6 +399,62 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           if (GC > 1 && p == 4 * (GC - 1) && has_slab) store_x(xbuf ^ 1, sub);
         }
 #endif
+      };
+      if constexpr (BF) {
+        // bf16 x 6 form, one tap group (16-channel k-block) at a time, one tile column at a time: the lane's 8
+        // channels of the column -- 4 pairs x 4 samples from the slab, the same packed transform as below -- are
+        // split into three bf16 pieces and meet the three weight pieces in 6 MFMAs per 32 x 32 tile.
+        const int o[4] = {bo0, bo1, bo2, bo3};
+#pragma unroll
+        for (int g = 0; g < GC; ++g) {
+          stage(4 * g);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            // (one column at a time, also for the instruction scheduler: with both columns' 32 LDS reads hoisted to
+            // the top the 64 x 512 tile needs 240 VGPRs more than the 168 a 12-wave block may use)
+            if (nt > 0) __builtin_amdgcn_sched_barrier(0);
+            float v[8];
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+              f32x2 x[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int j = 3 * g + sh + o[r];
+                x[r] = *reinterpret_cast<const f32x2*>(xsb + ((j & 3) * W_P + (j >> 2)) * 2 + kp * W_RP2 + 128 * nt);
+              }
+              f32x2 t = c0 * x[0];
+              t = __builtin_elementwise_fma(c1, x[1], t);
+              t = __builtin_elementwise_fma(c2, x[2], t);
+              t = __builtin_elementwise_fma(c3, x[3], t);
+              v[2 * kp] = t[0];
+              v[2 * kp + 1] = t[1];
+            }
+            bf16x8 bh, bm, bl;
+            split8(v, bh, bm, bl);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, a3[mt][0]), am = __builtin_bit_cast(bf16x8, a3[mt][1]),
+                           al = __builtin_bit_cast(bf16x8, a3[mt][2]);
+              f32x16 t = acc[mt][nt];              // small terms first
+              t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, t, 0, 0, 0);
+              acc[mt][nt] = t;
+            }
+          }
+          const bool same_chunk = g + 1 < GC;      // the A registers are free: request the next tap group's pieces
+          const WSeg& Sa = same_chunk ? S : Sx;
+          load_a3(Sa, same_chunk ? c : cx, same_chunk ? g + 1 : 0, same_chunk || has_next);
+        }
+      } else {
+      fetch(0, 0);
+#pragma unroll
+      for (int p = 0; p < 4 * GC; ++p) {
+        const int g = p >> 2, kp = p & 3, h = kp >> 1;
+        stage(p);
         if (p + 1 < 4 * GC) fetch((p + 1) & 1, p + 1);
         f32x2 bf[NT];                              // [column] = B values of k-steps 2 kp, 2 kp + 1
 #pragma unroll
@@ -386,6 +493,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           load_a_half(h, Sa, same_chunk ? c : cx, same_chunk ? g + 1 : 0, same_chunk || has_next);
         }
 #endif
+      }
       }
 #if !(defined(WINO_ABL) && (WINO_ABL & 8))
       if constexpr (VL) {
@@ -633,7 +741,7 @@ extern "C" int fh_sizeof_wino_group(void) { return (int)sizeof(fh_wino_group); }
 
 namespace {
 
-template <int MT, int NT, int SUBS, bool VL>
+template <int MT, int NT, int SUBS, bool VL, bool BF>
 int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
                 int phase_major, hipStream_t stream, const int* run_map = nullptr, int n_runs = 0) {
   using Cfg = WCfg<MT, NT, SUBS>;
@@ -647,7 +755,7 @@ int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cou
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino_f32: grid too large");
   static bool lds_opt_in = false;      // > 64 KB of dynamic LDS needs the attribute once per process
   if (!lds_opt_in) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<MT, NT, SUBS, VL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<MT, NT, SUBS, VL, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        Cfg::LDS_FLOATS * 4);
     if (e != hipSuccess) {
       fh_set_error("fh_conv_wino_f32: cannot reserve %d bytes of LDS: %s", Cfg::LDS_FLOATS * 4, hipGetErrorString(e));
@@ -655,13 +763,13 @@ int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cou
     }
     lds_opt_in = true;
   }
-  hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS, VL>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
+  hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS, VL, BF>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
                      stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major, run_map, n_runs);
   FH_CHECK_LAUNCH("fh_conv_wino_f32");
   return FH_OK;
 }
 
-template <int MT, int NT, int SUBS>
+template <int MT, int NT, int SUBS, bool BF>
 int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
                 int phase_major, hipStream_t stream, const int* run_map = nullptr, int n_runs = 0) {
   // 16-byte slab loads need contiguous aligned rows (tensors themselves 16-byte aligned: host plan)
@@ -669,13 +777,14 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
   // not 16-byte aligned; `len` is then only the longest group's length)
   const bool pm = (phase_major & 1) != 0;
   const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2) && !getenv("FH_WINO_NO_VL");
-  return vl ? launch_wino_vl<MT, NT, SUBS, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs)
-            : launch_wino_vl<MT, NT, SUBS, false>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs);
+  return vl ? launch_wino_vl<MT, NT, SUBS, true, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs)
+            : launch_wino_vl<MT, NT, SUBS, false, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs);
 }
 
 }  // namespace
 
 extern "C" int fh_wino_tile_m(int tile_cfg) {
+  tile_cfg &= ~FH_WINO_BF16X6;
   return tile_cfg == 6 ? 128 : tile_cfg == 5 ? 32 : tile_cfg == 4 ? 64 : tile_cfg == 1 ? 96 : tile_cfg == 0 ? 64 : -1;
 }
 
@@ -685,11 +794,17 @@ namespace {
 int wino_dispatch(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
                   int phase_major, int tile_cfg, hipStream_t st, const int* run_map, int n_runs) {
   switch (tile_cfg) {
-    case 0: return launch_wino<2, 2, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-    case 1: return launch_wino<3, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-    case 4: return launch_wino<2, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-    case 5: return launch_wino<1, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-    case 6: return launch_wino<4, 1, 1>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 0: return launch_wino<2, 2, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 1: return launch_wino<3, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 4: return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 5: return launch_wino<1, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case 6: return launch_wino<4, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    // + FH_WINO_BF16X6: the groups' weights are three-piece bf16 (pack_wino_weight_bf3), six bf16 MFMAs per k-block
+    case FH_WINO_BF16X6 + 0: return launch_wino<2, 2, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case FH_WINO_BF16X6 + 1: return launch_wino<3, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case FH_WINO_BF16X6 + 4: return launch_wino<2, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case FH_WINO_BF16X6 + 5: return launch_wino<1, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    case FH_WINO_BF16X6 + 6: return launch_wino<4, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
   }
   fh_set_error("fh_conv_wino_f32: unknown tile_cfg %d", tile_cfg);
   return FH_E_ARG;
@@ -705,7 +820,7 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
   return wino_dispatch(groups, n_groups, batch, cout_pad, len, dilation, phase_major, tile_cfg, (hipStream_t)stream, nullptr, 0);
 }
 
-extern "C" int fh_wino_tile_n(int tile_cfg) { return tile_cfg == 0 ? 512 : (fh_wino_tile_m(tile_cfg) > 0 ? 256 : -1); }
+extern "C" int fh_wino_tile_n(int tile_cfg) { tile_cfg &= ~FH_WINO_BF16X6; return tile_cfg == 0 ? 512 : (fh_wino_tile_m(tile_cfg) > 0 ? 256 : -1); }
 extern "C" int fh_wino_run_len(int n_tiles) { return n_tiles > 0 ? fh_cdiv(n_tiles, fh_cdiv(n_tiles, W_RUN)) : -1; }
 
 extern "C" int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,

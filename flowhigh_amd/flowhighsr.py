@@ -159,7 +159,7 @@ class FLowHigh:
     """Device-resident weights of the vector-field net + its mel codec (the reference's
     `FLowHigh` with `audio_enc_dec = MelVoco`, models/flow.py:54-142, models/melvoco.py:16-46)."""
 
-    def __init__(self, state_dict, vocoder_config, device="cuda", depth=2):
+    def __init__(self, state_dict, vocoder_config, device="cuda", depth=2, conv_bf16x6=None):
         device = torch.device(device)
         if device.type != "cuda":
             raise hip.HipError(f"flowhigh_amd runs on MI355X only (got device '{device}'); there is no CPU path")
@@ -172,7 +172,9 @@ class FLowHigh:
         if missing:
             raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
         self.net = FlowNet(state_dict, device, depth=depth)
-        self.vocoder = Vocoder(self.vocoder_config, state_dict, device)
+        # conv_bf16x6 (None: FH_CONV_BF16X6, default off): the vocoder's Winograd convs on the BF16 matrix cores with
+        # every fp32 operand split exactly into three bf16 pieces (vocoder.use_bf16x6)
+        self.vocoder = Vocoder(self.vocoder_config, state_dict, device, bf16x6=conv_bf16x6)
         self.logmel = LogMel(device)
         self.n_mels = self.net.dim_in
 

@@ -141,6 +141,13 @@ int fh_wino_tile_m(int tile_cfg);
 int fh_phase_len(int len, int dilation);
 /* groups: device array; all groups share cout_pad, len and the dilation.  phase_major != 0: x, res and out of
  * every group are phase-major for this dilation (see above), else plain [B, C, len]. */
+/* tile_cfg | FH_WINO_BF16X6: the groups' `u` pointers name THREE-PIECE bf16 weights
+ * ([C_in/16][tap group][6][cout_pad][3 pieces][16 channels] bf16 = 96 bytes per row and chunk; every fp32 value
+ * x = h + m + l, h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)) and the contraction runs on the BF16 matrix cores as
+ * six v_mfma_f32_32x32x16_bf16 per 16-channel k-block (pairs hh, hm, mh, mm, hl, lh; fp32 accumulation): fp32-grade
+ * products (dropped terms <= 2^-24 |a b|) at 0.375 of the matrix-pipe cycles.  Inputs, outputs and accumulation stay
+ * float32; results differ from the fp32-MFMA form by rounding only. */
+#define FH_WINO_BF16X6 16
 int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
                      int dilation, int phase_major, int tile_cfg, void* stream);
 /* Ragged form (clips of different lengths, one group per clip and AMP block, batch 1): the grid is laid out for

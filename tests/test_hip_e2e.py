@@ -15,11 +15,11 @@ TOL_WAVEFORM = 1e-4
 _MODELS = {}
 
 
-def model_for(cfg, seed, method="euler", cfm_method="basic_cfm", sigma=0.0, upsampling="scipy"):
-    key = (repr(sorted(cfg.items())), seed)
+def model_for(cfg, seed, method="euler", cfm_method="basic_cfm", sigma=0.0, upsampling="scipy", bf16x6=False):
+    key = (repr(sorted(cfg.items())), seed, bf16x6)
     if key not in _MODELS:
         sd = synth.make_state_dict(cfg, seed)
-        _MODELS[key] = (FLowHigh(sd, cfg, "cuda"), sd)
+        _MODELS[key] = (FLowHigh(sd, cfg, "cuda", conv_bf16x6=bf16x6), sd)
     fh, sd = _MODELS[key]
     m = FlowHighSR(fh, sigma=sigma, cfm_method=cfm_method, torchdiffeq_ode_method=method,
                    upsampling_method=upsampling)
@@ -392,3 +392,58 @@ def test_generate_many_ragged_batch_equals_single_calls_bitwise(cfgname, method,
     # max_frames splits the list into several launch sequences; same results
     again = m.generate_many(clips, 12000, 48000, 2, noise=noise, ragged=True, max_frames=200)
     assert all(torch.equal(a, b) for a, b in zip(again, many))
+
+
+# ------------------------------------------------------------------------------------------
+# Opt-in bf16 x 6 form of the Winograd convs (FLowHigh(..., conv_bf16x6=True) / FH_CONV_BF16X6=1): every fp32 operand
+# split exactly into three bf16 pieces, six bf16 MFMAs per 16-channel k-block, fp32 accumulation.  Same tolerances as
+# the fp32-MFMA form everywhere; same bitwise invariants (batch / ragged / chunked against a clip alone).
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", E2E_CASES)
+def test_bf16x6_generate_matches_reference_golden(name):
+    g = load_golden(name)
+    m, _ = model_for(g["cfg"], g["seed"], g["method"], g["cfm_method"], g["sigma"], bf16x6=True)
+    assert m.flowhigh.vocoder.bf and m.flowhigh.vocoder.wino_flag == 16
+    out, st = m.generate_batch([g["audio"]], g["sr_in"], 48000, g["steps"], noise=torch.from_numpy(g["noise"]),
+                               return_stages=True)
+    assert int(st["cr"][0].item()) == g["cr"]
+    assert np.abs(st["wav"].cpu().numpy() - g["wav"]).max() <= TOL_WAVEFORM
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_WAVEFORM
+
+
+def test_bf16x6_full_size_vs_oracle_and_vs_fp32_form():
+    """BASELINE configs[1] at full size in the bf16 x 6 form: against the CPU oracle at the 1e-4 bar, and its distance
+    from the fp32-MFMA form next to both forms' distance from the oracle (the split is fp32-grade: the two errors are
+    of the same size and the two forms differ by rounding only)."""
+    torch.set_num_threads(min(16, max(1, torch.get_num_threads())))
+    cfg = synth.SYNTH_CFG
+    m16, sd = model_for(cfg, 0, "euler", bf16x6=True)
+    m32, _ = model_for(cfg, 0, "euler")
+    audio = synth.lowres_clip(0, 10.0, 12000)
+    noise = synth.prior_noise(0, 1000)
+    o16, s16 = m16.generate_batch([audio], 12000, 48000, 1, noise=noise, return_stages=True)
+    o32, s32 = m32.generate_batch([audio], 12000, 48000, 1, noise=noise, return_stages=True)
+    ref, rs = ref_cpu.generate(sd, cfg, audio, 12000, noise, 1, "euler", return_stages=True)
+    assert int(s16["cr"][0].item()) == rs["cr"]
+    e16 = (s16["wav"].cpu() - rs["wav"]).abs().max().item()
+    e32 = (s32["wav"].cpu() - rs["wav"]).abs().max().item()
+    print(f"vocoder output vs oracle: bf16 x 6 {e16:.2e}, fp32 MFMA {e32:.2e}; between the forms "
+          f"{(s16['wav'] - s32['wav']).abs().max().item():.2e}")
+    assert e16 <= TOL_WAVEFORM and (o16.cpu() - ref).abs().max().item() <= TOL_WAVEFORM
+    assert e16 <= 3.0 * e32 + 2e-6                  # fp32-grade, not merely inside the bar
+
+
+def test_bf16x6_batch_ragged_and_chunked_invariants_bitwise():
+    cfg = synth.SYNTH_CFG
+    m, _ = model_for(cfg, 0, "euler", bf16x6=True)
+    secs = [0.5, 1.31, 0.5, 2.2]
+    clips = [synth.lowres_clip(240 + i, s_, 12000) for i, s_ in enumerate(secs)]
+    noise = [synth.prior_noise(240 + i, (len(c) * 4) // 480) for i, c in enumerate(clips)]
+    alone = [m.generate(c, 12000, 48000, 1, noise=z).clone() for c, z in zip(clips, noise)]
+    many = m.generate_many(clips, 12000, 48000, 1, noise=noise, ragged=True)
+    assert all(torch.equal(a, b) for a, b in zip(alone, many))
+    both = m.generate_batch([clips[0], clips[2]], 12000, 48000, 1, noise=torch.cat([noise[0], noise[2]], 0))
+    assert torch.equal(both[0:1], alone[0]) and torch.equal(both[1:2], alone[2])
+    voc = m.flowhigh.vocoder
+    mel = (torch.randn(1, 150, 256, generator=torch.Generator().manual_seed(5)) * 2.0 - 3.0).cuda()
+    assert torch.equal(voc.forward_chunked(mel, 48), voc.forward(mel))

@@ -131,6 +131,26 @@ def test_conv_wino(c, k, d, L, B):
     del keep
 
 
+def test_conv_wino_bf16x6_fuzz():
+    """tests/tools/wino_fuzz.py in the three-piece bf16 form: all tiles, layouts, dilations, residuals, K segments
+    against float64, SAME tolerance as the fp32-MFMA form (3e-5 per segment)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tests" / "tools" / "wino_fuzz.py"), "150", "3", "bf"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "FAIL" not in r.stdout and "150 cases (bf16 x 6)" in r.stdout, r.stdout[-2000:]
+
+
+def test_split_bf3_is_exact():
+    """x = h + m + l exactly (the weights' three bf16 pieces; the kernel splits the activations the same way)."""
+    x = rnd(4096, 16, seed=99, scale=1.0) * torch.exp(rnd(4096, 16, seed=98, scale=3.0))
+    p3 = V.split_bf3(x).view(torch.bfloat16).float()           # [..., 3, 16]
+    assert torch.equal(p3[:, 0] + p3[:, 1] + p3[:, 2], x)
+
+
 @pytest.mark.parametrize("wcfg", [0, 4, 5, 6])
 @pytest.mark.parametrize("k,d,L,pm", [(11, 1, 1000, False), (7, 3, 777, True), (3, 5, 2049, False)])
 def test_conv_wino_every_tile_shape_gives_the_same_bits(wcfg, k, d, L, pm):

@@ -1,11 +1,13 @@
 """Randomised check of fh_conv_wino_f32 (all tiles, layouts, dilations, residuals, ragged lengths) against
-float64 F.conv1d.  python tests/tools/wino_fuzz.py [n_cases] [seed]"""
+float64 F.conv1d.  python tests/tools/wino_fuzz.py [n_cases] [seed] [bf]
+bf: the three-piece bf16 form (tile_cfg | FH_WINO_BF16X6, weights split by vocoder.split_bf3), same tolerance."""
 import sys, random, torch, torch.nn.functional as F
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, vocoder as V
 DEV = torch.device('cuda:0')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+BF = len(sys.argv) > 3 and sys.argv[3] == "bf"
 worst = 0.0
 for case in range(n_cases):
     c = rng.choice([16, 32, 48, 64, 96, 128, 192])
@@ -32,11 +34,11 @@ for case in range(n_cases):
     xd = [conv(x) for x in xs]
     rd = [conv(r) for r in res]
     out = torch.full_like(xd[0], float("nan"))
-    ud = [V.pack_wino_weight(w, cpad).to(DEV) for w in ws]
+    ud = [(V.split_bf3(V.pack_wino_weight(w, cpad)) if BF else V.pack_wino_weight(w, cpad)).to(DEV) for w in ws]
     bd = bias.to(DEV)                      # (descriptors hold raw pointers: every tensor must stay referenced)
     grp = V.make_wino_group([V.make_wino_seg(xd[i], ud[i], c, kk) for i, kk in enumerate(ks)], bd, rd, out,
                             c, cpad, L, scale=scale)
-    keep = V.conv_wino([grp], B, cpad, L, d, DEV, wcfg, phase_major=pm)
+    keep = V.conv_wino([grp], B, cpad, L, d, DEV, wcfg | (V.WINO_BF16X6 if BF else 0), phase_major=pm)
     torch.cuda.synchronize()
     got = V.from_phase_major(out.cpu(), d, L) if pm else out.cpu()
     err = (got - ref).abs().max().item()
@@ -44,4 +46,4 @@ for case in range(n_cases):
     ok = err <= 3e-5 * nseg and bool(torch.isfinite(got).all())
     if not ok:
         print(f"FAIL case {case}: c={c} ks={ks} d={d} B={B} L={L} pm={pm} nres={nres} cfg={wcfg} err={err}")
-print(f"{n_cases} cases, worst error {worst:.2e}")
+print(f"{n_cases} cases{' (bf16 x 6)' if BF else ''}, worst error {worst:.2e}")
