@@ -430,7 +430,13 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
               v[2 * kp + 1] = t[1];
             }
             bf16x8 bh, bm, bl;
+#if defined(WINO_ABL) && (WINO_ABL & 32)         // timing experiment: no split (one cvt, pieces reused)
+            bh = __builtin_bit_cast(bf16x8, (u32x4){pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])});
+            bm = bh;
+            bl = bh;
+#else
             split8(v, bh, bm, bl);
+#endif
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const bf16x8 ah = __builtin_bit_cast(bf16x8, a3[mt][0]), am = __builtin_bit_cast(bf16x8, a3[mt][1]),
@@ -445,9 +451,11 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
               acc[mt][nt] = t;
             }
           }
+#if !(defined(WINO_ABL) && (WINO_ABL & 4))       // timing experiment: A pieces of the first step only
           const bool same_chunk = g + 1 < GC;      // the A registers are free: request the next tap group's pieces
           const WSeg& Sa = same_chunk ? S : Sx;
           load_a3(Sa, same_chunk ? c : cx, same_chunk ? g + 1 : 0, same_chunk || has_next);
+#endif
         }
       } else {
       fetch(0, 0);

@@ -163,8 +163,11 @@ _WINO_RUN = 8                      # W_RUN of conv_wino.hip
 _WINO_AUTO = os.environ.get("FH_WINO_AUTO", "1") == "1"
 
 
-# K-loop time of the bf16 x 6 form relative to the fp32 form (tools/wino_time.py ... bf)
-_WINO_BF_SPEED = float(os.environ.get("FH_WINO_BF_SPEED", "0.66"))
+# K-loop time per step of the bf16 x 6 form relative to the fp32 form, per tile shape (tools/wino_cost_fit.py:
+# 2.47 / 1.72 / 1.34 / 1.08 / 2.43 us against 3.28 / 2.27 / 1.86 / 1.14 / 3.22): the matrix pipe needs 0.375 of the
+# cycles, but the B split (36 VALU instructions per 8 values), 1.5 x the weight bytes and the unchanged slab / transform
+# work keep the loop issue-bound (ablations: no weight loads -10 %, no split -10 %, neither and no slab -35 %)
+_WINO_BF_SPEED = {0: 0.75, 1: 0.76, 4: 0.72, 5: 0.94, 6: 0.75}
 
 
 def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=False):
@@ -177,7 +180,7 @@ def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=F
     bm, bt = _WINO_TILES[cfg]
     a, b = _WINO_COST[cfg]
     if bf:
-        a *= _WINO_BF_SPEED
+        a *= _WINO_BF_SPEED[cfg]
     n_tiles = -(-(-(-length // dil)) // bt) * dil
     cot = wpad // bm
     panel_w = [a * k + b for k in ksteps for _ in range(batch * cot)]
