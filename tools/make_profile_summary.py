@@ -22,7 +22,7 @@ rl, rh = line['roofline'], line['roofline_hbm']
 rnd = int(''.join(ch for ch in tag[1:] if ch.isdigit()))
 prl, prh = prof['roofline'], prof['roofline_hbm']
 o = [f"# Round {rnd} profile summary (1 x MI355X, B = 1, 10 s clip, 12 -> 48 kHz, euler x 1, SYNTH-CFG)", "",
-     f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {prof['steps']} --warmup {prof['warmup']} --no-cpu-baseline`",
+     f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {prof['steps']} --warmup {prof['warmup']} --no-cpu-baseline --no-alt`",
      f"(raw: `{tag}_kernel_stats_bench_B1.csv`; HBM traffic PMC passes `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of `bench.py --steps 1 --warmup 1`:",
      "`conv_hbm_bytes_per_launch.json`, `act_hbm_bytes_per_launch.json`; reproduce with `tools/profile_round.sh` on the GPU box).", "",
      f"* all conv launches (conv_wino_kernel + conv_mfma_kernel): {ccalls} launches, average duration **{ctot / ccalls / 1e3:.1f} us** under the "

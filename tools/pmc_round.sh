@@ -9,7 +9,7 @@ for set in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES" \
            "SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_LEVEL_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d $out/p$i --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1
+  rocprofv3 --pmc $set -d $out/p$i --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt > $out/p$i.log 2>&1
   python3 tools/pmc_generic.py $out/p$i > $out/p$i.txt
 done
 cat $out/p1.txt $out/p2.txt $out/p3.txt > gpurun_out/pmc_$tag.txt

@@ -5,9 +5,9 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline > $out/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-alt > $out/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt > $out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt > $out/pmc_write.log 2>&1
 python tools/make_traffic_json.py $out/pmc_fetch $out/pmc_write $out/conv_hbm_bytes_per_launch.json conv > /dev/null
 python tools/make_traffic_json.py $out/pmc_fetch $out/pmc_write $out/act_hbm_bytes_per_launch.json act > /dev/null
 cp $out/conv_hbm_bytes_per_launch.json $out/act_hbm_bytes_per_launch.json profiles/
