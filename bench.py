@@ -222,26 +222,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- the scatter / gather path against rank-0-only runs (outside the timed region) ---------------------------
-    sharded_check = None
-    if world > 1:
-        try:
-            if conf["sharded"]:
-                xa, za, got = x_all, z_all, out
-            else:
-                xa, za = make_inputs(range(world * B)) if rank == 0 else (None, None)
-                got = parallel.generate_sharded(gen, xa, za, n_in, n_frames, device=dev, n_total=world * B, t48=t48)
-            if rank == 0:
-                got = got.clone()
-                same = all(torch.equal(gen(xa[s:s + B], za[s:s + B]), got[s:s + B]) for s in range(0, world * B, B))
-                sharded_check = (f"{world * B} clips over {world} ranks through RCCL scatter/gather: "
-                                 + ("bit-identical to rank-0-only runs" if same else "MISMATCH against rank-0-only runs"))
-                assert same, sharded_check
-        except AssertionError:
-            raise
-        except Exception as e:                   # noqa: BLE001  (report, keep the measured line)
-            sharded_check = f"failed: {type(e).__name__}: {e}"
-
     # ---- roofline of the dominant kernels ---------------------------------------------------------------------------
     plan = voc.plan(B, n_frames)
     conv_ms = sum(a.elapsed_time(b) for a, b in conv_ev)          # conv launches of the sampled timed steps
@@ -257,6 +237,7 @@ def main():
     act_bytes_per_launch = plan["act_bytes"] * timed_steps / max(n_act, 1)
     act_gbs = act_bytes_per_launch / act_s / 1e9 if act_s > 0 else 0.0
 
+    line = None
     if rank == 0:
         def pmc(name):
             f = ROOT / "profiles" / name
@@ -280,7 +261,7 @@ def main():
                        "parallelism": (f"{n_clips} clips on rank 0, RCCL P2P scatter -> generate -> gather, x{world}"
                                        if conf["sharded"] else f"clip-sharded x{world}, no data-path collective"),
                        "rccl_world_size": world if dist is not None else None,
-                       "sharded_check": sharded_check},
+                       "sharded_check": None},
             "roofline": {"bound": "mfma",
                          "kernel": "conv_wino_kernel + conv_mfma_kernel (all conv launches of BigVGAN: 97 % of the path's FLOPs)",
                          "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -319,6 +300,42 @@ def main():
             line["cpu_baseline"] = cpu_baseline(sd, cfg, sr_in)
         else:
             line["cpu_baseline"] = None
+    # ---- the scatter / gather path against rank-0-only runs (outside the timed region, after the line is built) ------
+    # A watchdog on every rank: should the P2P exchange not finish, rank 0 still prints the measured line (without
+    # the check) and every rank exits, instead of leaving the launcher waiting.
+    if world > 1:
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["config"]["sharded_check"] = "not finished within 180 s: line printed without it"
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(180.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        sharded_check = None
+        try:
+            if conf["sharded"]:
+                xa, za, got = x_all, z_all, out
+            else:
+                xa, za = make_inputs(range(world * B)) if rank == 0 else (None, None)
+                got = parallel.generate_sharded(gen, xa, za, n_in, n_frames, device=dev, n_total=world * B, t48=t48)
+            if rank == 0:
+                got = got.clone()
+                same = all(torch.equal(gen(xa[s:s + B], za[s:s + B]), got[s:s + B]) for s in range(0, world * B, B))
+                sharded_check = (f"{world * B} clips over {world} ranks through RCCL scatter/gather: "
+                                 + ("bit-identical to rank-0-only runs" if same else "MISMATCH against rank-0-only runs"))
+                assert same, sharded_check
+            torch.cuda.synchronize()
+        except AssertionError:
+            raise
+        except Exception as e:                   # noqa: BLE001  (report, keep the measured line)
+            sharded_check = f"failed: {type(e).__name__}: {e}"
+        watchdog.cancel()
+        if rank == 0:
+            line["config"]["sharded_check"] = sharded_check
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
