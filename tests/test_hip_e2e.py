@@ -447,3 +447,34 @@ def test_bf16x6_batch_ragged_and_chunked_invariants_bitwise():
     voc = m.flowhigh.vocoder
     mel = (torch.randn(1, 150, 256, generator=torch.Generator().manual_seed(5)) * 2.0 - 3.0).cuda()
     assert torch.equal(voc.forward_chunked(mel, 48), voc.forward(mel))
+
+
+@pytest.mark.parametrize("args,workload", [(["--steps", "9", "--warmup", "1", "--no-cpu-baseline"], "configs[1]"),
+                                           (["--config", "4", "--batch", "2", "--steps", "2", "--warmup", "1"], "configs[3]")])
+def test_bench_prints_one_contract_line(args, workload):
+    """bench.py on the GPU box: exactly one JSON line with the driver's keys, both roofline objects measured live
+    (HIP events) and self-consistent, and -- for the default workload -- the opt-in bf16 x 6 side measurement with its
+    distance from the fp32 form."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "bench.py")] + args, cwd=root, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_hbm", "cpu_baseline"):
+        assert k in line, k
+    assert workload in line["config"]["workload"] and line["n_gpus"] == 1 and line["dtype"] == "f32"
+    clips = line["config"]["clips_per_gpu"]
+    assert abs(line["value"] - clips * 10.0 / (line["ms_per_step"] / 1e3)) / line["value"] < 0.02
+    rl, rh = line["roofline"], line["roofline_hbm"]
+    assert rl["bound"] == "mfma" and 0.2 < rl["frac"] <= 1.0 and abs(rl["frac"] - rl["achieved"] / 157.3) < 1e-3
+    assert rl["achieved"] < rl["algorithmic_equiv"] and rl["conv_ms_per_step"] < line["ms_per_step"]
+    assert rh["bound"] == "hbm" and 0.1 < rh["frac"] <= 1.0 and rh["act_ms_per_step"] < line["ms_per_step"]
+    if "--config" not in args:
+        alt = line["alt_conv_bf16x6"]
+        assert alt["max_abs_diff_vs_fp32_mfma_waveform"] <= 5e-5 and alt["value"] > 0
