@@ -1,10 +1,10 @@
 """Batched front for the serving caller of the reference (`/root/reference/app.py:8-15`: one
 `generate((sr_in, audio), sr_out, timestep)` per HTTP request, one clip at a time).
 
-Requests from any number of caller threads are collected for a few milliseconds, bucketed by
-(input rate, length, steps) and pushed through `FlowHighSR.generate_many`, so concurrent requests of equal
-shape share one batch on the GPU while every caller still gets exactly what `generate()` would have
-returned for its clip alone (same per-clip noise draw when a seed is given).  Host logic only: no gradio,
+Requests from any number of caller threads are collected for a few milliseconds, grouped by (input rate,
+steps) and pushed through `FlowHighSR.generate_many`: clips of ANY lengths then run as one ragged launch
+sequence on the GPU (equal lengths as one batch) while every caller still gets exactly what `generate()` would
+have returned for its clip alone (same per-clip noise draw when a seed is given).  Host logic only: no gradio,
 no sockets (the reference's UI / network layers are out of scope); `generate()` below has the signature of
 the function `app.py` hands to `gr.Interface`.
 """
