@@ -109,11 +109,32 @@ def alt_bf16x6(sd, cfg, dev, sr_in, x, z, out_fp32, B, n_frames, steps):
                     "Winograd launches / time of ALL conv launches (the direct-kernel ones stay fp32 MFMA) / 2.5 PFLOP/s"}
 
 
+def visible_gpus():
+    """GPUs of this node counted WITHOUT the HIP runtime: the kfd topology nodes that have SIMDs (CPUs have none),
+    cut by *_VISIBLE_DEVICES.  None when the topology is not readable (the ranks then find out themselves)."""
+    if not Path("/sys/class/kfd").exists():       # no amdgpu compute driver: no AMD GPU
+        return 0
+    try:
+        nodes = list(Path("/sys/class/kfd/kfd/topology/nodes").iterdir())
+        n = 0
+        for node in nodes:
+            props = dict(line.split()[:2] for line in (node / "properties").read_text().splitlines() if line.strip())
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([v for v in os.environ[var].split(",") if v.strip()]))
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (never exec:
     nothing here has touched a GPU yet, and nothing will in this process)."""
-    n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU
-    if n_dev < args.gpus:
+    # (the parent never asks the HIP runtime anything, not even the device count: without amdsmi torch falls back to
+    # hipGetDeviceCount, which initialises the runtime; a rank whose device is missing fails loudly by itself)
+    n_dev = visible_gpus()
+    if n_dev is not None and n_dev < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -146,9 +167,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:           # under a launcher, also with ONE rank: the RCCL init path runs on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev)
 
     from flowhigh_amd import FLowHigh, FlowHighSR, parallel, synth
@@ -302,15 +324,21 @@ def main():
             line["cpu_baseline"] = None
     # ---- the scatter / gather path against rank-0-only runs (outside the timed region, after the line is built) ------
     # A watchdog on every rank: should the P2P exchange not finish, rank 0 still prints the measured line (without
-    # the check) and every rank exits, instead of leaving the launcher waiting.
-    if world > 1:
+    # the check) and every rank exits NON-ZERO, instead of leaving the launcher waiting or reporting success.
+    rc = 0
+    if dist is not None:
         import threading
+        printed = threading.Lock()           # exactly one JSON line, whoever gets there first
+
+        def emit():
+            if rank == 0 and printed.acquire(blocking=False):
+                print(json.dumps(line), flush=True)
 
         def bail():
             if rank == 0:
-                line["config"]["sharded_check"] = "not finished within 180 s: line printed without it"
-                print(json.dumps(line), flush=True)
-            os._exit(0)
+                line["config"]["sharded_check"] = "failed: not finished within 180 s: line printed without it"
+            emit()
+            os._exit(3)
         watchdog = threading.Timer(180.0, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -326,19 +354,25 @@ def main():
                 same = all(torch.equal(gen(xa[s:s + B], za[s:s + B]), got[s:s + B]) for s in range(0, world * B, B))
                 sharded_check = (f"{world * B} clips over {world} ranks through RCCL scatter/gather: "
                                  + ("bit-identical to rank-0-only runs" if same else "MISMATCH against rank-0-only runs"))
-                assert same, sharded_check
             torch.cuda.synchronize()
-        except AssertionError:
-            raise
-        except Exception as e:                   # noqa: BLE001  (report, keep the measured line)
+        except Exception as e:                   # noqa: BLE001  (report, keep the measured line, fail the run)
             sharded_check = f"failed: {type(e).__name__}: {e}"
+        flag = torch.tensor([0 if rank != 0 or (sharded_check and "bit-identical" in sharded_check) else 1], device=dev)
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)      # every rank leaves with rank 0's verdict
+            rc = 4 if int(flag.item()) else 0
+        except Exception:                        # noqa: BLE001
+            rc = 4
         watchdog.cancel()
         if rank == 0:
             line["config"]["sharded_check"] = sharded_check
-    if rank == 0:
+        emit()
+    elif rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -761,15 +761,22 @@ int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cou
   const long long runs = run_map ? (long long)n_runs : panels * fh_cdiv(n_tiles, run_len);
   const long long blocks = (long long)fh_cdiv(runs, 8) * 8 * run_len;
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino_f32: grid too large");
-  static bool lds_opt_in = false;      // > 64 KB of dynamic LDS needs the attribute once per process
-  if (!lds_opt_in) {
+  // > 64 KB of dynamic LDS needs the attribute once per DEVICE (a kernel has one function object per device, and
+  // a process may hold models on several): one flag per device ordinal and template instance.
+  static std::atomic<bool> lds_opt_in[FH_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) {
+    fh_set_error("fh_conv_wino_f32: no current HIP device (or ordinal >= %d)", FH_MAX_DEVICES);
+    return FH_E_LAUNCH;
+  }
+  if (!lds_opt_in[dev].load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<MT, NT, SUBS, VL, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        Cfg::LDS_FLOATS * 4);
     if (e != hipSuccess) {
-      fh_set_error("fh_conv_wino_f32: cannot reserve %d bytes of LDS: %s", Cfg::LDS_FLOATS * 4, hipGetErrorString(e));
+      fh_set_error("fh_conv_wino_f32: cannot reserve %d bytes of LDS on device %d: %s", Cfg::LDS_FLOATS * 4, dev, hipGetErrorString(e));
       return FH_E_LAUNCH;
     }
-    lds_opt_in = true;
+    lds_opt_in[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS, VL, BF>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
                      stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major, run_map, n_runs);
@@ -825,15 +832,16 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
   FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino_f32: dilation %d unsupported", dilation);
   // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cin * len * 4 < 2^31
   // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
-  return wino_dispatch(groups, n_groups, batch, cout_pad, len, dilation, phase_major, tile_cfg, (hipStream_t)stream, nullptr, 0);
+  return wino_dispatch(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0 ? 1 : 0, tile_cfg, (hipStream_t)stream, nullptr, 0);
 }
 
 extern "C" int fh_wino_tile_n(int tile_cfg) { tile_cfg &= ~FH_WINO_BF16X6; return tile_cfg == 0 ? 512 : (fh_wino_tile_m(tile_cfg) > 0 ? 256 : -1); }
 extern "C" int fh_wino_run_len(int n_tiles) { return n_tiles > 0 ? fh_cdiv(n_tiles, fh_cdiv(n_tiles, W_RUN)) : -1; }
 
 extern "C" int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
-                                       int phase_major, int tile_cfg, const int* run_map, int n_runs, void* stream) {
+                                       int layout_flags, int tile_cfg, const int* run_map, int n_runs, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && max_len > 0 && run_map && n_runs > 0, "fh_conv_wino_ragged_f32: bad sizes");
+  FH_CHECK_ARG(layout_flags >= 0 && layout_flags <= 3, "fh_conv_wino_ragged_f32: layout_flags %d (bit 0 phase-major, bit 1 no vector loads)", layout_flags);
   FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino_ragged_f32: dilation %d unsupported", dilation);
-  return wino_dispatch(groups, n_groups, 1, cout_pad, max_len, dilation, phase_major, tile_cfg, (hipStream_t)stream, run_map, n_runs);
+  return wino_dispatch(groups, n_groups, 1, cout_pad, max_len, dilation, layout_flags, tile_cfg, (hipStream_t)stream, run_map, n_runs);
 }

@@ -4,12 +4,17 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/flowhigh_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void fh_set_error(const char* fmt, ...);
+
+// per-device host state (opt-in flags) is kept in arrays of this many ordinals
+#define FH_MAX_DEVICES 64
 
 #define FH_CHECK_ARG(cond, ...)        \
   do {                                 \

@@ -109,14 +109,19 @@ __global__ __launch_bounds__(64) void cutoff_kernel(const float* __restrict__ en
 }
 
 // energy[b, d] = sum_n exp(mel[b, n, d])   (locate_cutoff_freq on exp(mel), cfm_superresolution.py:134-159)
+// seg != nullptr: clips of different lengths packed back to back, clip b = rows seg[2b] .. seg[2b] + seg[2b+1]
+// (the ragged serving path); the sum runs over the clip's own rows in the same order either way.
 __global__ __launch_bounds__(256) void mel_energy_kernel(const float* __restrict__ mel,
-                                                         float* __restrict__ energy, int n, int d) {
+                                                         float* __restrict__ energy, int n, int d,
+                                                         const int32_t* __restrict__ seg) {
   const int b = blockIdx.y;
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= d) return;
-  const float* m = mel + (size_t)b * n * d + col;
+  const size_t row0 = seg ? (size_t)seg[2 * b] : (size_t)b * n;
+  const int rows = seg ? seg[2 * b + 1] : n;
+  const float* m = mel + row0 * d + col;
   double acc = 0.0;
-  for (int t = 0; t < n; ++t) acc += (double)expf(m[(size_t)t * d]);
+  for (int t = 0; t < rows; ++t) acc += (double)expf(m[(size_t)t * d]);
   energy[b * d + col] = (float)acc;
 }
 
@@ -124,12 +129,13 @@ __global__ __launch_bounds__(256) void mel_energy_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void mel_splice_kernel(const float* __restrict__ low,
                                                          const float* __restrict__ high,
                                                          const int32_t* __restrict__ cut,
-                                                         float* __restrict__ out, int n, int d) {
+                                                         float* __restrict__ out, int n, int d,
+                                                         const int32_t* __restrict__ seg) {
   const int b = blockIdx.y;
-  const size_t per = (size_t)n * d;
+  const size_t per = (size_t)(seg ? seg[2 * b + 1] : n) * d;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= per) return;
-  const size_t g = (size_t)b * per + i;
+  const size_t g = (seg ? (size_t)seg[2 * b] : (size_t)b * n) * d + i;
   out[g] = (int)(i % d) < cut[b] ? low[g] : high[g];
 }
 
@@ -277,8 +283,17 @@ extern "C" int fh_cutoff_index_f32(const float* energy, int32_t* cr, int batch, 
 extern "C" int fh_mel_energy_f32(const float* mel, float* energy, int batch, int n, int d, void* stream) {
   FH_CHECK_ARG(mel && energy && batch > 0 && n > 0 && d > 0, "fh_mel_energy_f32: bad args");
   hipLaunchKernelGGL(mel_energy_kernel, dim3(fh_cdiv(d, 256), batch), dim3(256), 0, (hipStream_t)stream, mel,
-                     energy, n, d);
+                     energy, n, d, (const int32_t*)nullptr);
   FH_CHECK_LAUNCH("fh_mel_energy_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_mel_energy_seg_f32(const float* mel, float* energy, const int32_t* seg, int n_seg, int d,
+                                     void* stream) {
+  FH_CHECK_ARG(mel && energy && seg && n_seg > 0 && n_seg < 65536 && d > 0, "fh_mel_energy_seg_f32: bad args");
+  hipLaunchKernelGGL(mel_energy_kernel, dim3(fh_cdiv(d, 256), n_seg), dim3(256), 0, (hipStream_t)stream, mel,
+                     energy, 0, d, seg);
+  FH_CHECK_LAUNCH("fh_mel_energy_seg_f32");
   return FH_OK;
 }
 
@@ -286,8 +301,18 @@ extern "C" int fh_mel_splice_f32(const float* low, const float* high, const int3
                                  int batch, int n, int d, void* stream) {
   FH_CHECK_ARG(low && high && cut && out && batch > 0 && n > 0 && d > 0, "fh_mel_splice_f32: bad args");
   hipLaunchKernelGGL(mel_splice_kernel, dim3(fh_cdiv((long long)n * d, 256), batch), dim3(256), 0,
-                     (hipStream_t)stream, low, high, cut, out, n, d);
+                     (hipStream_t)stream, low, high, cut, out, n, d, (const int32_t*)nullptr);
   FH_CHECK_LAUNCH("fh_mel_splice_f32");
+  return FH_OK;
+}
+
+extern "C" int fh_mel_splice_seg_f32(const float* low, const float* high, const int32_t* cut, float* out,
+                                     const int32_t* seg, int n_seg, int max_n, int d, void* stream) {
+  FH_CHECK_ARG(low && high && cut && out && seg && n_seg > 0 && n_seg < 65536 && max_n > 0 && d > 0,
+               "fh_mel_splice_seg_f32: bad args");
+  hipLaunchKernelGGL(mel_splice_kernel, dim3(fh_cdiv((long long)max_n * d, 256), n_seg), dim3(256), 0,
+                     (hipStream_t)stream, low, high, cut, out, 0, d, seg);
+  FH_CHECK_LAUNCH("fh_mel_splice_seg_f32");
   return FH_OK;
 }
 

@@ -55,7 +55,7 @@ class FlowNet:
     def __init__(self, sd, device, depth=2, heads=16, dim_head=64):
         if dim_head != 64:
             raise NotImplementedError("dim_head must be 64")
-        self.device = torch.device(device)
+        self.device = hip.norm_device(device)
         dev = self.device
         g = lambda name: sd[FH + name].detach().float().cpu()
         self.depth, self.heads = depth, heads
@@ -102,6 +102,7 @@ class FlowNet:
         self.inv_freq = g("transformer.rotary_emb.inv_freq")
         self._ws = hip.ShapeCache()
 
+    @hip.on_device
     def workspace(self, batch, n):
         key = (batch, n)
         if key in self._ws:
@@ -118,31 +119,39 @@ class FlowNet:
         self._ws[key] = ws
         return ws
 
+    @hip.on_device
     def ragged_workspace(self, frames):
         """Workspace for a ragged batch: clips of `frames` frames each packed back to back (M = sum rows, no padding).
         Carries the device segment table [n_seg][2] = (first row, rows) the seg kernels take."""
         frames = tuple(int(n) for n in frames)
         key = ("ragged",) + frames
-        if key in self._ws:
-            return self._ws[key]
         M, max_n = sum(frames), max(frames)
-        ws = dict(self.workspace(1, M))                         # same buffers as one clip of M frames ...
-        cos_t, sin_t = rotary_tables(self.inv_freq, max_n)      # ... but positions restart in every clip
-        ws["cos"], ws["sin"] = cos_t.to(self.device), sin_t.to(self.device)
-        starts = [0]
-        for n in frames[:-1]:
-            starts.append(starts[-1] + n)
-        ws["seg"] = torch.tensor([[s_, n] for s_, n in zip(starts, frames)], dtype=torch.int32).to(self.device)
-        ws["frames"], ws["rows"], ws["max_n"] = frames, M, max_n
-        self._ws.put(key, ws, ws["cos"].numel() * 8 + ws["seg"].numel() * 4)
+        if key in self._ws:
+            small = self._ws[key]
+        else:
+            cos_t, sin_t = rotary_tables(self.inv_freq, max_n)      # positions restart in every clip
+            starts = [0]
+            for n in frames[:-1]:
+                starts.append(starts[-1] + n)
+            small = dict(cos=cos_t.to(self.device), sin=sin_t.to(self.device),
+                         seg=torch.tensor([[s_, n] for s_, n in zip(starts, frames)], dtype=torch.int32).to(self.device),
+                         frames=frames, rows=M, max_n=max_n)
+            self._ws[key] = small           # (accounted with what it owns: the tables)
+        # The row buffers are the ones of ONE clip of >= M frames, looked up on every call and never held by the
+        # cached entry (an entry that kept them would pin workspace(1, M) for every mix of lengths, outside the byte
+        # bound of the cache); M is rounded up so that mixes of similar total length share them.
+        ws = dict(self.workspace(1, -(-M // 256) * 256))
+        ws.update(small)
         return ws
 
+    @hip.on_device
     def set_cond(self, cond, batch, n, ragged=None):
         """cond [B*n, dim_in] (log-mel of the low-res clip): e_cond = cond @ W_c^T + b."""
         ws = ragged if ragged is not None else self.workspace(batch, n)
         M = ragged["rows"] if ragged is not None else batch * n
         hip.gemm(cond, self.w_c, ws["e_cond"], M, self.dim, self.dim_in, bias=self.b_embed)
 
+    @hip.on_device
     def forward(self, x, t, out, batch, n, alpha=1.0, res=None, null_cond=False, ragged=None):
         """out = alpha * v(x, t) + res  with v the vector field; x/out/res [B*n, dim_in].
         null_cond=True evaluates v with every frame's condition replaced by `null_cond`

@@ -119,7 +119,11 @@ class GraphedGenerate:
     """One captured generate_from_device call (FlowHighSR.capture)."""
 
     def __init__(self, model, batch, n_in, sr, timestep):
-        dev = model.device
+        self.device = dev = model.device
+        with hip.device_guard(dev):
+            self._capture(model, batch, n_in, sr, timestep, dev)
+
+    def _capture(self, model, batch, n_in, sr, timestep, dev):
         self.x = torch.zeros(batch, n_in, dtype=torch.float32, device=dev)
         t48 = -(-n_in * 48000 // sr)
         self.noise = torch.zeros(batch * (t48 // 480), model.flowhigh.n_mels, dtype=torch.float32, device=dev)
@@ -150,6 +154,7 @@ class GraphedGenerate:
                                "for this shape: raise FH_CACHE_GB)")
         self._keep.append(model)
 
+    @hip.on_device
     def replay(self):
         self.graph.replay()
         return self.out
@@ -166,16 +171,20 @@ class FLowHigh:
         hip.lib()                                   # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise hip.HipError("no HIP device visible")
-        self.device = device
+        # 'cuda' = the device current NOW; the model then stays on that ordinal whatever the caller makes current
+        # later: every public entry below runs under hip.on_device (the reference's from_local(ckpt_dir, device),
+        # flowhighsr.py:110-137)
+        self.device = device = hip.norm_device(device)
         self.vocoder_config = dict(vocoder_config)
         missing = [k for k in ("flowhigh.to_embed.weight", VOC + "conv_pre.weight") if k not in state_dict]
         if missing:
             raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
-        self.net = FlowNet(state_dict, device, depth=depth)
-        # conv_bf16x6 (None: FH_CONV_BF16X6, default off): the vocoder's Winograd convs on the BF16 matrix cores with
-        # every fp32 operand split exactly into three bf16 pieces (vocoder.use_bf16x6)
-        self.vocoder = Vocoder(self.vocoder_config, state_dict, device, bf16x6=conv_bf16x6)
-        self.logmel = LogMel(device)
+        with hip.device_guard(device):
+            self.net = FlowNet(state_dict, device, depth=depth)
+            # conv_bf16x6 (None: FH_CONV_BF16X6, default off): the vocoder's Winograd convs on the BF16 matrix cores
+            # with every fp32 operand split exactly into three bf16 pieces (vocoder.use_bf16x6)
+            self.vocoder = Vocoder(self.vocoder_config, state_dict, device, bf16x6=conv_bf16x6)
+            self.logmel = LogMel(device)
         self.n_mels = self.net.dim_in
 
 
@@ -218,6 +227,7 @@ class FlowHighSR:
     def eval(self):
         return self
 
+    @hip.on_device
     def load(self, path, strict=True):
         path = Path(path)
         assert path.exists()
@@ -321,6 +331,7 @@ class FlowHighSR:
             y = out
         return y
 
+    @hip.on_device
     def mel_cutoff_bins(self, cond_mel, batch, n):
         """Device version of mel_cutoff_bins (cfm:134-159): int32 [B], no host loop, no sync."""
         L, st = hip.lib(), hip.stream()
@@ -338,6 +349,7 @@ class FlowHighSR:
         return out
 
     @torch.no_grad()
+    @hip.on_device
     def sample(self, *, cond=None, cond_mask=None, time_steps=4, cond_scale=1., decode_to_audio=True,
                std_1=None, std_2=None, mel_pp=False, cfm_method=None, noise=None, generator=None):
         """The reference's `sample` (cfm:162-284).  The returned tensor is the caller's own (the vocoder's output
@@ -390,12 +402,33 @@ class FlowHighSR:
             return mel
         return fh.vocoder.forward(mel).unsqueeze(1)           # [B, 1, hop * n]
 
-    def _sample_ragged(self, conds, noises, time_steps, cfm_method, std_2=None, mels=None):
-        """`sample()` (cfm:162-284, cond_scale 1, no mel_pp) for clips of DIFFERENT lengths as one launch sequence.
+    def _cutoff_bins_seg(self, cond_mel, seg, n_seg):
+        """mel_cutoff_bins per clip of a packed batch: int32 [n_seg], two launches for the whole list."""
+        L, st = hip.lib(), hip.stream()
+        d = cond_mel.shape[-1]
+        energy = torch.empty(n_seg, d, dtype=torch.float32, device=self.device)
+        cut = torch.empty(n_seg, dtype=torch.int32, device=self.device)
+        hip.check(L.fh_mel_energy_seg_f32(cond_mel.data_ptr(), energy.data_ptr(), seg.data_ptr(), n_seg, d, st),
+                  "fh_mel_energy_seg_f32")
+        hip.check(L.fh_cutoff_index_f32(energy.data_ptr(), cut.data_ptr(), n_seg, d, 0.9995, st), "fh_cutoff_index_f32")
+        return cut
+
+    def _mel_replace_seg(self, high, low, cut, seg, n_seg, max_n):
+        out = torch.empty_like(high)
+        hip.check(hip.lib().fh_mel_splice_seg_f32(low.data_ptr(), high.data_ptr(), cut.data_ptr(), out.data_ptr(),
+                                                  seg.data_ptr(), n_seg, max_n, high.shape[-1], hip.stream()),
+                  "fh_mel_splice_seg_f32")
+        return out
+
+    def _sample_ragged(self, conds, noises, time_steps, cfm_method, std_2=None, mels=None, cond_scale=1., mel_pp=False,
+                       decode_to_audio=True):
+        """`sample()` (cfm:162-284, incl. cond_scale != 1 and mel_pp, cfm:162-175,278-279) for clips of DIFFERENT
+        lengths as one launch sequence.
         conds: list of [T48_i] device tensors (peak-normalised), noises: list of [1, N_i, n_mels] host tensors.
-        Returns the vocoder's waveforms, a list of [1, 480 N_i] (plan-owned buffers), each what _sample gives for
-        that clip alone: the log-mels are made per clip, every row-wise operator runs on the packed rows, the
-        operators that look across rows take the clip boundaries, the vocoder runs its merged plan."""
+        Returns the vocoder's waveforms, a list of [1, 480 N_i] (plan-owned buffers; decode_to_audio=False: the mels,
+        a list of [N_i, n_mels]), each what _sample gives for that clip alone: the log-mels are made per clip, every
+        row-wise operator runs on the packed rows, the operators that look across rows take the clip boundaries (the
+        mel cutoff bins are per clip: fh_mel_*_seg_f32), the vocoder runs its merged plan."""
         fh = self.flowhigh
         std_1 = None
         if cfm_method in _CFM_METHODS[1:]:
@@ -408,27 +441,49 @@ class FlowHighSR:
         if noise.shape != cond_mel.shape:
             raise ValueError(f"noise rows {tuple(noise.shape)} do not match the clips' frames {tuple(cond_mel.shape)}")
         rws = fh.net.ragged_workspace(frames)
+        seg, n_seg, max_n = rws["seg"], len(frames), max(frames)
+        cut = None
         if cfm_method == 'basic_cfm':
             y0 = noise
         else:
             y0 = torch.empty_like(noise)
             hip.check(hip.lib().fh_axpby_f32(cond_mel.data_ptr(), float(std_1), noise.data_ptr(), float(std_2),
                                              y0.data_ptr(), y0.numel(), hip.stream()), "fh_axpby_f32")
-            if cfm_method == 'independent_cfm_mix':          # per-clip cutoff bins (cfm:231-237): per-clip launches
-                parts, r = [], 0
-                for n in frames:
-                    cm, nz, yy = cond_mel[r:r + n], noise[r:r + n], y0[r:r + n]
-                    parts.append(self._mel_replace(nz, yy, self.mel_cutoff_bins(cm, 1, n), 1, n))
-                    r += n
-                y0 = torch.cat(parts, 0)
-        mel = self._integrate(y0, cond_mel, len(frames), max(frames), time_steps, 1., ragged=rws)
+            if cfm_method == 'independent_cfm_mix':          # per-clip cutoff bins (cfm:231-237)
+                cut = self._cutoff_bins_seg(cond_mel, seg, n_seg)
+                y0 = self._mel_replace_seg(noise, y0, cut, seg, n_seg, max_n)
+        mel = self._integrate(y0, cond_mel, n_seg, max_n, time_steps, float(cond_scale), ragged=rws)
+        if mel_pp:                                           # cfm:278-279, per clip
+            cut = cut if cut is not None else self._cutoff_bins_seg(cond_mel, seg, n_seg)
+            mel = self._mel_replace_seg(mel, cond_mel, cut, seg, n_seg, max_n)
         rows, out = 0, []
         for n in frames:
             out.append(mel[rows:rows + n])
             rows += n
-        return fh.vocoder.forward_ragged(out)
+        return fh.vocoder.forward_ragged(out) if decode_to_audio else out
 
     @torch.no_grad()
+    @hip.on_device
+    def sample_many(self, conds, *, time_steps=4, cond_scale=1., decode_to_audio=True, mel_pp=False, cfm_method=None,
+                    noise=None, generator=None):
+        """`sample()` for a LIST of conditioning clips of different lengths (each [T48_i], 48 kHz, peak-normalised) as
+        one masked / ragged launch sequence, with the reference's sampler options (cond_scale: classifier-free
+        guidance against null_cond, mel_pp: low-band replacement with per-clip cutoff bins; cfm:162-175,278-279).
+        Every result is bit-identical to `sample(cond=clip[None], ...)` on that clip alone.  Returns a list of
+        [1, 1, 480 N_i] waveforms (or [1, N_i, n_mels] mels)."""
+        if cfm_method not in _CFM_METHODS:
+            cfm_method = self.cfm_method
+        conds = [c.to(self.device, torch.float32).reshape(-1) for c in conds]
+        frames = [c.shape[0] // 480 for c in conds]
+        if noise is None:
+            noise = [self._draw_noise(1, n, generator) for n in frames]
+        kw = dict(std_2=1.) if cfm_method == 'independent_cfm_adaptive' else {}
+        outs = self._sample_ragged(conds, noise, time_steps, cfm_method, cond_scale=cond_scale, mel_pp=mel_pp,
+                                   decode_to_audio=decode_to_audio, **kw)
+        return [o.clone().unsqueeze(1) if decode_to_audio else o.clone()[None] for o in outs]
+
+    @torch.no_grad()
+    @hip.on_device
     def generate_batch(self, clips, sr, target_sampling_rate=48000, timestep=1, *, noise=None,
                        generator=None, return_stages=False):
         cond = self._prepare_cond(list(clips), sr, target_sampling_rate)
@@ -442,6 +497,7 @@ class FlowHighSR:
         return out
 
     @torch.no_grad()
+    @hip.on_device
     def generate_many(self, clips, sr, target_sampling_rate=48000, timestep=1, *, noise=None, generator=None,
                       max_batch=64, streams=None, ragged=None, max_frames=None):
         """Serving-side entry (the gradio caller of app.py:8-26, many requests at once): clips of ANY lengths,
@@ -474,7 +530,10 @@ class FlowHighSR:
             ragged = os.environ.get("FH_RAGGED", "1") != "0"
         lengths = [int(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a).shape[-1]) for a in clips]
         if ragged and len(set(lengths)) > 1 and target_sampling_rate == 48000:
-            return self._generate_many_ragged(clips, lengths, sr, timestep, noise, max_frames)
+            try:
+                return self._generate_many_ragged(clips, lengths, sr, timestep, noise, max_frames)
+            except NotImplementedError:
+                pass        # a vocoder configuration whose launch positions cannot be merged: one batch per length
         buckets = {}
         for i, a in enumerate(clips):
             key = (int(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a).shape[-1]), tuple(noise[i].shape))
@@ -546,6 +605,7 @@ class FlowHighSR:
         return pool[:n]
 
     @torch.no_grad()
+    @hip.on_device
     def generate_from_device(self, x, sr, timestep=1, *, noise):
         """Device-resident variant (no host work, no sync; graph-capturable): x [B, T_in] float32
         low-rate clips already in HBM (|x| <= 1), noise [B, N, n_mels] -> [B, T48].  Same
@@ -556,6 +616,7 @@ class FlowHighSR:
         return self.postproc(wav, cond, cond.size(-1))
 
     @torch.no_grad()
+    @hip.on_device
     def capture(self, batch, n_in, sr, timestep=1):
         """HIP-graph form of generate_from_device for one input shape: the ~150 launches of a call are recorded once
         and replayed with a single enqueue (short clips are launch-bound from Python).  Returns a `GraphedGenerate`
@@ -563,6 +624,7 @@ class FlowHighSR:
         return GraphedGenerate(self, batch, n_in, sr, timestep)
 
     @torch.no_grad()
+    @hip.on_device
     def generate(self, audio, sr: int, target_sampling_rate=48000, timestep=1, *, noise=None, generator=None):
         """One clip, reference contract: returns float32 [1, T48] on the model device."""
         return self.generate_batch([audio], sr, target_sampling_rate, timestep, noise=noise, generator=generator)

@@ -25,24 +25,26 @@ class _Const:
 
     @classmethod
     def get(cls, device):
-        device = torch.device(device)
+        device = hip.norm_device(device)
         key = (device.type, device.index)
         if key not in cls._cache:
-            cls._cache[key] = dict(
-                hann=tables.hann_window().to(device),
-                w_fwd=tables.dft_forward_weight().to(device),
-                w_inv=tables.dft_inverse_weight().to(device),
-                w_mel=tables.mel_gemm_weight().to(device),
-                tw=tables.fft_twiddles().to(device))
+            c = dict(hann=tables.hann_window().to(device), w_mel=tables.mel_gemm_weight().to(device))
+            if _USE_FFT:
+                c["tw"] = tables.fft_twiddles().to(device)
+            else:               # FH_FFT=0: STFT / iSTFT as DFT-by-GEMM (35 MB of bases, not uploaded otherwise)
+                c["w_fwd"] = tables.dft_forward_weight().to(device)
+                c["w_inv"] = tables.dft_inverse_weight().to(device)
+            cls._cache[key] = c
         return cls._cache[key]
 
 
 class LogMel:
     def __init__(self, device):
-        self.device = torch.device(device)
-        self.c = _Const.get(device)
+        self.device = hip.norm_device(device)
+        self.c = _Const.get(self.device)
         self._ws = hip.ShapeCache()
 
+    @hip.on_device
     def __call__(self, audio):
         """audio [B, T] on device -> log-mel [B*N, 256] (token-major rows), N = T // 480."""
         B, T = audio.shape
@@ -70,10 +72,11 @@ class LogMel:
 
 class PostProcessor:
     def __init__(self, device):
-        self.device = torch.device(device)
-        self.c = _Const.get(device)
+        self.device = hip.norm_device(device)
+        self.c = _Const.get(self.device)
         self._ws = hip.ShapeCache()
 
+    @hip.on_device
     def __call__(self, pred, src, length, return_cr=False):
         """pred [B, Tp], src [B, T] -> [B, length]; per-clip cutoff, splice, iSTFT, 0.99 peak."""
         B, Tp = pred.shape
@@ -119,9 +122,10 @@ class Resampler:
     """Device polyphase resampler + peak normalise (the reference does this on the host in numpy)."""
 
     def __init__(self, device):
-        self.device = torch.device(device)
+        self.device = hip.norm_device(device)
         self._taps = {}
 
+    @hip.on_device
     def __call__(self, x, sr_in, sr_out=48000):
         """x [B, T_in] float32 on device -> [B, T_out], each clip divided by its max |.|."""
         B, n_in = x.shape

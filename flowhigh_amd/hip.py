@@ -4,7 +4,10 @@ There is NO fallback: if the library is missing or a call fails this module rais
 pointers are passed as integers (`tensor.data_ptr()`), the stream as
 `torch.cuda.current_stream().cuda_stream`.
 """
+import contextlib
 import ctypes as C
+import functools
+import inspect
 import os
 from pathlib import Path
 
@@ -100,6 +103,8 @@ _SIGS = {
     "fh_cutoff_index_f32": [_P, _P, _I, _I, _F, _P],
     "fh_mel_energy_f32": [_P, _P, _I, _I, _I, _P],
     "fh_mel_splice_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "fh_mel_energy_seg_f32": [_P, _P, _P, _I, _I, _P],
+    "fh_mel_splice_seg_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "fh_axpby_f32": [_P, _F, _P, _F, _P, C.c_longlong, _P],
     "fh_spec_splice_f32": [_P, _P, _P, _P, _I, _I, _P],
     "fh_istft_ola_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -202,8 +207,51 @@ def check(rc, what=""):
         raise HipError(f"{what}: rc={rc}: {lib().fh_last_error().decode()}")
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+def stream(device=None):
+    """Raw hipStream_t of torch's current stream on `device` (default: the current device; inside an
+    @on_device method that IS the model's device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def norm_device(device):
+    """torch.device with an explicit ordinal: 'cuda' means the device that is current NOW (at construction), so
+    that a model keeps launching there whatever the caller makes current later (the reference's
+    `from_local(ckpt_dir, device)`, flowhighsr.py:110-137)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def device_guard(device):
+    """Context manager making `device` the current HIP device (no-op for the CPU-device objects the host-logic
+    tests build: they plan launches but never enqueue one)."""
+    device = torch.device(device)
+    return torch.cuda.device(device) if device.type == "cuda" else contextlib.nullcontext()
+
+
+def on_device(fn):
+    """Method decorator: run with `self.device` as the current HIP device, so that every allocation, every
+    `hip.stream()` and every kernel launch inside goes to the model's device and its current stream, not to
+    whatever device the calling thread has current.  Generator methods are guarded per resumption."""
+    if inspect.isgeneratorfunction(fn):
+        @functools.wraps(fn)
+        def gen_wrapper(self, *args, **kwargs):
+            gen = fn(self, *args, **kwargs)
+            while True:
+                with device_guard(self.device):
+                    try:
+                        item = next(gen)
+                    except StopIteration:
+                        return
+                yield item
+        return gen_wrapper
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        with device_guard(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 def ptr(t):

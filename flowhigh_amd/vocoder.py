@@ -406,7 +406,7 @@ class Vocoder:
             raise NotImplementedError(f"resblock {cfg['resblock']!r}")
         if cfg["activation"] not in ("snake", "snakebeta"):
             raise NotImplementedError(cfg["activation"])
-        self.device = torch.device(device)
+        self.device = hip.norm_device(device)
         # bf16x6: the Winograd convs contract on the BF16 matrix cores, operands split into three bf16 pieces
         # (None: FH_CONV_BF16X6; see use_bf16x6)
         self.bf = use_bf16x6() if bf16x6 is None else bool(bf16x6)
@@ -540,6 +540,7 @@ class Vocoder:
             f += length * st["c"] ** 2 * 2.0 * 2 * self.nm * sum(self.ks)
         return f
 
+    @hip.on_device
     def plan(self, batch, n_frames, ref_frames=None, inst=0):
         """Launch plan for [batch, num_mels, n_frames].  ref_frames: the frame count of the WHOLE clip when this
         plan runs a time chunk of it (forward_chunked): every choice that changes the order of additions (input-
@@ -875,6 +876,7 @@ class Vocoder:
         return p
 
     # ---- ragged batches (clips of different lengths in ONE launch sequence) ------------------------
+    @hip.on_device
     def plan_ragged(self, frames):
         """Merged launch plan for clips of frame counts `frames` (any mix of lengths, batch 1 each).
         Every clip keeps the plan it has alone (`plan(1, N)`: its own buffers, the same groups, K segments,
@@ -1009,9 +1011,13 @@ class Vocoder:
         host = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8)
         desc = host.to(self.device)
         rp = dict(subs=subs, steps=merged, desc=desc, frames=frames)
-        self._ragged.put(key, rp, desc.numel())       # (the clips' buffers are accounted for in self._plans)
+        # The merged descriptors hold raw pointers into the clips' plans, so the entry keeps them alive -- and is
+        # accounted with everything it keeps alive (the sub-plans' workspaces, ~65 MB per second of audio), so that
+        # FH_CACHE_GB bounds what the ragged cache can pin whatever self._plans has evicted meanwhile.
+        self._ragged[key] = rp
         return rp
 
+    @hip.on_device
     def run_ragged(self, rp):
         L, st, base = hip.lib(), hip.stream(), rp["desc"].data_ptr()
         for s in rp["steps"]:
@@ -1032,6 +1038,7 @@ class Vocoder:
             else:
                 self._launch(s, 1, st)
 
+    @hip.on_device
     def forward_ragged(self, mels):
         """mels: list of [N_i, num_mels] (token-major rows of each clip) -> list of wav [1, hop * N_i] (plan-owned
         buffers), every one bit-identical to forward() on that clip alone."""
@@ -1081,6 +1088,7 @@ class Vocoder:
         halo = -(-int(math.ceil(h)) // align) * align
         return halo, align
 
+    @hip.on_device
     def forward_chunks(self, mel_bnd, chunk_frames):
         """Generator over time chunks of forward(mel): yields (first_sample, wav_chunk [B, n_samples]) in order, each
         chunk bit-identical to the same samples of the whole-clip run; workspace is O(chunk_frames + 2 halo).
@@ -1098,6 +1106,7 @@ class Vocoder:
             yield s * self.hop, p["wav"][:, (s - a) * self.hop:(e - a) * self.hop]
             s = e
 
+    @hip.on_device
     def forward_chunked(self, mel_bnd, chunk_frames, out=None):
         """forward() in time chunks of `chunk_frames` mel frames: same bits, bounded workspace."""
         B, N, D = mel_bnd.shape
@@ -1106,6 +1115,7 @@ class Vocoder:
             wav[:, first:first + w.shape[1]].copy_(w)
         return wav
 
+    @hip.on_device
     def forward(self, mel_bnd):
         """mel [B, N, num_mels] (token-major, as the sampler produces it) -> wav [B, hop * N].  Clips longer than
         FH_VOCODER_CHUNK_FRAMES (default 6000 = 60 s) run in time chunks of that many frames: same result, the
@@ -1119,6 +1129,7 @@ class Vocoder:
         self.run(p)
         return p["wav"]
 
+    @hip.on_device
     def run(self, p):
         self._run_steps(p["steps"], p["B"], hip.stream())
 

@@ -154,11 +154,13 @@ int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int c
  * max_len; a "run" is fh_wino_run_len(n_tiles) consecutive output tiles of one (group, co tile) panel
  * (n_tiles = ceil(ceil(max_len / dilation) / fh_wino_tile_n(tile_cfg)) * dilation), run id = panel * runs_per_panel +
  * run-in-panel with panel = group * co_tiles + co tile.  run_map (device int32 [n_runs]) lists the runs that hold
- * real tiles, in launch order (heavy groups first): they are dealt round-robin to the 8 XCDs. */
+ * real tiles, in launch order (heavy groups first): they are dealt round-robin to the 8 XCDs.
+ * layout_flags (0..3): bit 0 = the groups' tensors are phase-major (as phase_major != 0 above); bit 1 = some group's
+ * rows are not 16-byte aligned (a len that is not a multiple of 4 in a plain-layout launch): no vector loads. */
 int fh_wino_tile_n(int tile_cfg);
 int fh_wino_run_len(int n_tiles);
 int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
-                            int phase_major, int tile_cfg, const int* run_map, int n_runs, void* stream);
+                            int layout_flags, int tile_cfg, const int* run_map, int n_runs, void* stream);
 
 /* out = ((a + b) + c) * scale over n floats (c may be NULL; n % 4 == 0, 16-byte aligned pointers): the
  * `xs += resblock(x); x = xs / num_kernels` of BigVGAN.forward (models/bigvgan/models.py:183-188) for the
@@ -170,9 +172,6 @@ int fh_mean_f32(const float* a, const float* b, const float* c, float* out, long
  * slices (one fh_wino_group per slice; short clips, vocoder.wino_split_k) in a fixed order; out may be srcs[0]. */
 int fh_sum_f32(const float* const* srcs, int n_srcs, float* out, long long n, float scale, void* stream);
 
-/* Debug: per-block timeline of the conv kernel.  buf = device array of uint64, buf[0] = record
- * counter (zero it), then 4 words per block {blockIdx | hw_id << 32 | xcc << 56, start, end
- * (100 MHz ticks), K steps}; NULL switches tracing off.  Synchronous (hipMemcpyToSymbol). */
 /* out = scale * (((p0 + p1) + p2) + ...) for several independent jobs in one launch (the averaging / partial-sum
  * passes of a ragged batch: one job per clip; same order of additions as fh_sum_f32 / fh_mean_f32). */
 typedef struct {
@@ -185,6 +184,9 @@ typedef struct {
 int fh_sizeof_sum_job(void);
 int fh_sum_multi_f32(const fh_sum_job* jobs, int n_jobs, long long max_n, void* stream);
 
+/* Debug: per-block timeline of the conv kernel.  buf = device array of uint64, buf[0] = record
+ * counter (zero it), then 4 words per block {blockIdx | hw_id << 32 | xcc << 56, start, end
+ * (100 MHz ticks), K steps}; NULL switches tracing off.  Synchronous (hipMemcpyToSymbol). */
 int fh_debug_set_conv_trace(void* buf);
 /* Same for the Winograd kernel: one record per WAVE, word 3 = wave index in the block. */
 int fh_debug_set_wino_trace(void* buf);
@@ -335,6 +337,12 @@ int fh_irfft2048_f32(const float* spec, const double* twiddles, float* frames, i
 int fh_mel_energy_f32(const float* mel, float* energy, int batch, int n, int d, void* stream);
 int fh_mel_splice_f32(const float* low, const float* high, const int32_t* cut, float* out, int batch,
                       int n, int d, void* stream);
+/* Same for clips of different lengths packed back to back (the reference's masked batches, cfm:162-175,278-279):
+ * seg = device int32 [n_seg][2] = (first row, rows) of every clip, mel tensors [sum rows, d], energy [n_seg, d],
+ * cut [n_seg]; every clip gets the bits of a call on that clip alone. */
+int fh_mel_energy_seg_f32(const float* mel, float* energy, const int32_t* seg, int n_seg, int d, void* stream);
+int fh_mel_splice_seg_f32(const float* low, const float* high, const int32_t* cut, float* out,
+                          const int32_t* seg, int n_seg, int max_n, int d, void* stream);
 int fh_axpby_f32(const float* x, float a, const float* y, float b, float* out, long long n,
                  void* stream);
 
@@ -358,7 +366,8 @@ int fh_peak_abs_f32(const float* x, uint32_t* peak_bits, int batch, int len, voi
 /* ------------------------------------------------------------------------------------
  * Host pre-step on device: scipy.signal.resample_poly(x, up, down) with zero padding
  * (flowhighsr.py:68).  taps: the scipy FIR (already multiplied by `up`), n_taps odd-centred as
- * scipy pads it; y[b, i] = sum_j taps[j*up + (i*down + pre) % up ...] -- see resample.hip.
+ * scipy pads it; y[b, i] = sum_j taps[j*up + (i*down + pre) % up ...] -- see resample_poly_kernel in
+ * flowhigh_amd/csrc/frontend.hip.
  * --------------------------------------------------------------------------------- */
 int fh_resample_poly_f32(const float* x, const float* taps, float* y, int batch, int len_in,
                          int len_out, int up, int down, int n_taps, int n_pre_remove,

@@ -349,8 +349,41 @@ def test_baseline_config4_share_batch32_8k_euler():
 
 def test_baseline_config5_batch8_30s_midpoint4():
     """configs[4]: B = 8, 30 s clips, 24 -> 48 kHz, time_step = 4 midpoint (8 transformer evaluations at
-    N = 3000)."""
-    _batch_case(30.0, 24000, "midpoint", 4, 8, 500)
+    N = 3000).  Row 0 against the CPU oracle at the 1e-4 bar (~70 s of host time)."""
+    m, sd, clips, noise, out = _batch_case(30.0, 24000, "midpoint", 4, 8, 500)
+    torch.set_num_threads(min(16, max(1, torch.get_num_threads())))
+    ref, rs = ref_cpu.generate(sd, synth.SYNTH_CFG, clips[0], 24000, noise[0:1], 4, "midpoint", return_stages=True)
+    assert (out[0:1].cpu() - ref).abs().max().item() <= TOL_WAVEFORM
+
+
+def test_baseline_config5_mel_level_vs_oracle():
+    """configs[4] at the mel level: one 30 s 24 kHz clip, sample(time_steps=4, midpoint, decode_to_audio=False) =
+    8 transformer evaluations at N = 3000 (cfm_superresolution.py:239-244, pos_emb.py:47-59, attend.py:102-139)
+    against the oracle's sample(decode=False)."""
+    cfg = synth.SYNTH_CFG
+    m, sd = model_for(cfg, 0, "midpoint")
+    torch.set_num_threads(min(16, max(1, torch.get_num_threads())))
+    cond = ref_cpu.preprocess(synth.lowres_clip(510, 30.0, 24000), 24000)
+    noise = synth.prior_noise(510, 3000)
+    ref = ref_cpu.sample(sd, cfg, cond, noise, 4, "midpoint", decode=False)
+    mel = m.sample(cond=cond, time_steps=4, decode_to_audio=False, noise=noise)
+    assert tuple(mel.shape) == tuple(ref.shape) == (1, 3000, 256)
+    assert (mel.cpu() - ref).abs().max().item() <= 2e-4       # |mel| ~ 10: 8 chained fp32 transformer passes
+
+
+def test_baseline_config1_two_second_clip_vs_oracle():
+    """configs[0] at its exact size: one 2 s clip, 12 -> 48 kHz, time_step = 1 euler, transformer 2 x 16 x 64,
+    full-width SYNTH-CFG vocoder, against the CPU oracle."""
+    cfg = synth.SYNTH_CFG
+    m, sd = model_for(cfg, 0, "euler")
+    audio = synth.lowres_clip(20, 2.0, 12000)
+    noise = synth.prior_noise(20, 200)
+    out, st = m.generate_batch([audio], 12000, 48000, 1, noise=noise, return_stages=True)
+    ref, rs = ref_cpu.generate(sd, cfg, audio, 12000, noise, 1, "euler", return_stages=True)
+    assert tuple(out.shape) == (1, 96000)
+    assert int(st["cr"][0].item()) == rs["cr"]
+    assert (st["wav"].cpu() - rs["wav"]).abs().max().item() <= TOL_WAVEFORM
+    assert (out.cpu() - ref).abs().max().item() <= TOL_WAVEFORM
 
 
 def test_two_minute_clip_runs_through_the_chunked_vocoder(monkeypatch):
@@ -478,3 +511,98 @@ def test_bench_prints_one_contract_line(args, workload):
     if "--config" not in args:
         alt = line["alt_conv_bf16x6"]
         assert alt["max_abs_diff_vs_fp32_mfma_waveform"] <= 5e-5 and alt["value"] > 0
+
+
+# ------------------------------------------------------------------------------------------
+# `device` semantics of from_local(ckpt_dir, device) (reference flowhighsr.py:110-137)
+# ------------------------------------------------------------------------------------------
+def test_model_runs_on_its_own_device_whatever_is_current(monkeypatch):
+    """A model built on "cuda:0" launches on cuda:0's current stream whatever device / stream the CALLER has
+    current.  With >= 2 GPUs the caller really sits on cuda:1; on a 1-GPU box every launch is spied on: the device
+    current at launch time and the stream handed to the C ABI must be the model's."""
+    from flowhigh_amd import hip
+    g = load_golden("tiny_euler")
+    sd = synth.make_state_dict(g["cfg"], g["seed"])
+    fh = FLowHigh(sd, g["cfg"], "cuda:0")
+    assert fh.device == torch.device("cuda", 0) == fh.vocoder.device == fh.net.device == fh.logmel.device
+    m = FlowHighSR(fh, torchdiffeq_ode_method=g["method"])
+    assert FLowHigh(sd, g["cfg"], "cuda").device.index == torch.cuda.current_device()      # 'cuda' pins the ordinal
+    seen = []
+    real_stream = hip.stream
+
+    def spy(device=None):
+        h = real_stream(device)
+        seen.append((torch.cuda.current_device(), h))
+        return h
+    monkeypatch.setattr(hip, "stream", spy)
+    side = torch.cuda.Stream(device="cuda:0")
+    other = torch.device("cuda", 1) if torch.cuda.device_count() > 1 else None
+    with torch.cuda.device(other if other is not None else 0):
+        with torch.cuda.stream(side):           # current stream of cuda:0 := side (also while cuda:1 is current)
+            out = m.generate(g["audio"], g["sr_in"], 48000, g["steps"], noise=torch.from_numpy(g["noise"]))
+        assert torch.cuda.current_device() == (1 if other is not None else 0)               # the caller's, restored
+    side.synchronize()
+    assert out.device == torch.device("cuda", 0)
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_WAVEFORM
+    assert len(seen) > 20 and all(d == 0 for d, _ in seen)
+    assert {h for _, h in seen} == {side.cuda_stream}
+
+
+def test_lds_opt_in_is_per_device():
+    """The > 64 KB LDS opt-in of the Winograd kernel is kept per device ordinal, not per process: the entry point
+    works (again) after the current device was set explicitly, and on every visible device."""
+    cfg = synth.TINY_CFG
+    sd = synth.make_vocoder_state_dict(cfg, seed=1)
+    mel = (torch.randn(1, 30, 256, generator=torch.Generator().manual_seed(5)) * 2.0 - 3.0)
+    ref = None
+    for d in range(torch.cuda.device_count()):
+        from flowhigh_amd.vocoder import Vocoder
+        voc = Vocoder(cfg, sd, f"cuda:{d}")
+        wav = voc.forward(mel.to(f"cuda:{d}")).cpu()
+        ref = wav if ref is None else ref
+        assert torch.equal(wav, ref)
+
+
+# ------------------------------------------------------------------------------------------
+# sampler options on the ragged path (cfm_superresolution.py:162-175,278-279)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfm_method", ["basic_cfm", "independent_cfm_mix"])
+def test_sample_many_with_guidance_and_mel_pp_equals_single_calls_bitwise(cfm_method):
+    """sample_many(cond_scale=1.3, mel_pp=True): clips of different lengths in one launch sequence, per-clip mel
+    cutoff bins (fh_mel_energy_seg_f32 / fh_mel_splice_seg_f32): bit-identical to sample() per clip, mels and waveforms."""
+    m, _ = model_for(synth.TINY_CFG, 0, "midpoint", cfm_method=cfm_method, sigma=0.3)
+    secs = [0.5, 0.21, 1.0, 0.5]
+    conds = [torch.from_numpy(ref_cpu.preprocess(synth.lowres_clip(60 + i, s, 12000), 12000).numpy()[0]) for i, s in enumerate(secs)]
+    noise = [synth.prior_noise(60 + i, c.shape[0] // 480) for i, c in enumerate(conds)]
+    for decode in (False, True):
+        many = m.sample_many(conds, time_steps=2, cond_scale=1.3, mel_pp=True, cfm_method=cfm_method, noise=noise,
+                             decode_to_audio=decode)
+        for c, z, got in zip(conds, noise, many):
+            one = m.sample(cond=c[None], time_steps=2, cond_scale=1.3, mel_pp=True, cfm_method=cfm_method, noise=z,
+                           decode_to_audio=decode)
+            assert got.shape == one.shape and torch.equal(got, one)
+
+
+# ------------------------------------------------------------------------------------------
+# bench.py under a launcher with ONE rank: the RCCL init path and the scatter / gather check on a 1-GPU box
+# ------------------------------------------------------------------------------------------
+def test_bench_under_torchrun_one_rank_initialises_rccl_and_checks_the_sharded_path():
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", str(root / "bench.py"), "--gpus", "1", "--config", "4", "--batch", "2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-alt"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["config"]["rccl_world_size"] == 1 and line["n_gpus"] == 1
+    assert "bit-identical" in line["config"]["sharded_check"]

@@ -495,10 +495,12 @@ def test_rmsnorm():
     assert maxdiff(y, F.normalize(x, dim=-1) * 32.0 * g) <= 5e-6
 
 
-@pytest.mark.parametrize("n", [33, 1000])
+@pytest.mark.parametrize("n", [33, 1000, 3000])
 def test_attention_block(n):
-    """qk-norm + RoPE + streaming softmax attention against the oracle's attention()."""
-    B, H, D = 2, 16, 1024
+    """qk-norm + RoPE + streaming softmax attention against the oracle's attention().  n = 3000 is BASELINE
+    configs[4]'s frame count (30 s): rotary angles up to 3000 rad (pos_emb.py:47-59) and 94 key tiles per
+    softmax row (attend.py:102-139)."""
+    B, H, D = (1 if n > 1000 else 2), 16, 1024
     sd = synth.make_flow_state_dict(seed=3)
     p = "flowhigh.transformer.layers.0.3."
     x = rnd(B, n, D, seed=150)
@@ -587,7 +589,7 @@ def test_ragged_transformer_ops_equal_per_clip_calls_bitwise():
         assert torch.equal(y1, y[s0:s0 + n])
 
 
-@pytest.mark.parametrize("B,n,t", [(1, 25, 0.0), (2, 200, 0.3)])
+@pytest.mark.parametrize("B,n,t", [(1, 25, 0.0), (2, 200, 0.3), (1, 3000, 0.5)])
 def test_flow_forward(B, n, t):
     from flowhigh_amd.flow import FlowNet
     sd = synth.make_flow_state_dict(seed=0)

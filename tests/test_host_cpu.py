@@ -146,3 +146,64 @@ def test_chunk_geometry_covers_the_receptive_field():
             for dl in dils:
                 for d in dl:
                     assert (align * rate) % (4 * d) == 0         # tile position and phase at this stage
+
+
+def test_on_device_runs_methods_under_the_models_device(monkeypatch):
+    """hip.on_device: every decorated entry (plain and generator methods) runs with the object's device current, whatever
+    the caller has current (the reference's from_local(ckpt_dir, device), flowhighsr.py:110-137).  No GPU here: the
+    guard is replaced by a recorder."""
+    import contextlib
+    from flowhigh_amd import hip
+    log = []
+
+    @contextlib.contextmanager
+    def fake_guard(device):
+        log.append(("enter", str(device)))
+        yield
+        log.append(("exit", str(device)))
+    monkeypatch.setattr(hip, "device_guard", fake_guard)
+
+    class Obj:
+        device = torch.device("cuda", 3)
+
+        @hip.on_device
+        def f(self, a, b=2):
+            log.append(("f", a, b))
+            return a + b
+
+        @hip.on_device
+        def g(self, n):
+            for i in range(n):
+                log.append(("g", i))
+                yield i
+
+    o = Obj()
+    assert o.f(1, b=5) == 6
+    assert log == [("enter", "cuda:3"), ("f", 1, 5), ("exit", "cuda:3")]
+    del log[:]
+    it = o.g(2)
+    assert log == []                                     # nothing runs before the first next()
+    assert next(it) == 0
+    assert log == [("enter", "cuda:3"), ("g", 0), ("exit", "cuda:3")]     # the consumer's code runs OUTSIDE the guard
+    assert list(it) == [1]
+    assert log.count(("enter", "cuda:3")) == log.count(("exit", "cuda:3")) == 3
+    # every public entry of the product classes is guarded
+    from flowhigh_amd import flow, flowhighsr, frontend, vocoder
+    for cls, names in ((flowhighsr.FlowHighSR, ["generate", "generate_batch", "generate_many", "generate_from_device",
+                                                "sample", "sample_many", "capture", "load", "mel_cutoff_bins"]),
+                       (flowhighsr.GraphedGenerate, ["replay"]),
+                       (vocoder.Vocoder, ["plan", "plan_ragged", "run", "run_ragged", "forward", "forward_ragged",
+                                          "forward_chunks", "forward_chunked"]),
+                       (flow.FlowNet, ["workspace", "ragged_workspace", "set_cond", "forward"]),
+                       (frontend.LogMel, ["__call__"]), (frontend.PostProcessor, ["__call__"]),
+                       (frontend.Resampler, ["__call__"])):
+        for n in names:
+            assert hasattr(getattr(cls, n), "__wrapped__"), f"{cls.__name__}.{n} is not under hip.on_device"
+
+
+def test_norm_device_pins_the_ordinal():
+    from flowhigh_amd import hip
+    assert hip.norm_device("cuda:2") == torch.device("cuda", 2)
+    assert hip.norm_device("cpu") == torch.device("cpu")
+    if not torch.cuda.is_available():
+        assert hip.norm_device("cuda") == torch.device("cuda")          # nothing to pin without a GPU

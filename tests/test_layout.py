@@ -248,3 +248,16 @@ def test_bench_self_launches_multi_gpu_runs_before_touching_a_gpu():
     src = (ROOT / "bench.py").read_text()
     assert "os.exec" not in src and "execv" not in src
     assert src.index("self_launch(args)") < src.index("torch.cuda.set_device")
+
+
+def test_integration_stub_descriptor_matches_the_library():
+    """The ctypes stub INTEGRATION.md shows a reference maintainer must describe fh_act_group as the library lays it
+    out: its _fields_ are parsed from the document and sized against fh_sizeof_act_group()."""
+    from flowhigh_amd import hip
+    text = (ROOT / "INTEGRATION.md").read_text()
+    m = re.search(r"class _ActGroup\(ctypes\.Structure\):.*?\n\s*_fields_ = (\[.*?\])\s*(#[^\n]*)?\n", text, re.S)
+    assert m, "INTEGRATION.md no longer shows the _ActGroup stub"
+    fields = eval(re.sub(r"#[^\n]*", "", m.group(1)), {"ctypes": ctypes})        # noqa: S307 (our own document)
+    stub = type("_ActGroup", (ctypes.Structure,), {"_fields_": fields})
+    assert ctypes.sizeof(stub) == hip.lib().fh_sizeof_act_group() == ctypes.sizeof(hip.ActGroup)
+    assert [f[0] for f in fields] == [f[0] for f in hip.ActGroup._fields_]
