@@ -544,7 +544,7 @@ def test_model_runs_on_its_own_device_whatever_is_current(monkeypatch):
     side.synchronize()
     assert out.device == torch.device("cuda", 0)
     assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_WAVEFORM
-    assert len(seen) > 20 and all(d == 0 for d, _ in seen)
+    assert len(seen) >= 8 and all(d == 0 for d, _ in seen)       # (one hip.stream() per operator group)
     assert {h for _, h in seen} == {side.cuda_stream}
 
 

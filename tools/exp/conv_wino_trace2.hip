@@ -154,6 +154,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   unsigned long long* const trace = g_wino_trace;
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long* rec2 = nullptr;
+  if (trace) rec2 = trace + 1 + 24 * ((unsigned long long)blockIdx.x * 12ull + (unsigned long long)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+#define STAMP(k) do { if (rec2 && (threadIdx.x & 63) == 0) rec2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
   // ---- block -> (panel, n block); panels = (group, batch, co tile), heavy groups first ----------
   const int panels = n_groups * batch * co_tiles;
@@ -327,13 +330,17 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   };
 
   // ---- prologue -------------------------------------------------------------------------------
+  STAMP(3);
   WSeg S0 = load_wseg(&G->seg[0]);
+  STAMP(4);
   if constexpr (BF) {
     load_a3(S0, 0, 0, true);
   } else {
     load_a_half(0, S0, 0, 0, true);
     load_a_half(1, S0, 0, 0, true);
   }
+  if (rec2) { __builtin_amdgcn_s_waitcnt(0); }      // diagnosis only: first A tiles have arrived
+  STAMP(16);
   int xbuf = 0;
 #pragma unroll
   for (int sub = 0; sub < SUBS; ++sub) {
@@ -348,7 +355,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       store_x(0, sub);
     }
   }
+  STAMP(17);
   __syncthreads();
+  STAMP(18);
 
   f32x2 c0 = {bc0, bc0}, c1 = {bc1, bc1}, c2 = {bc2, bc2};       // alpha, beta, gamma of this wave's row of B^T
   // The K loop of a chunk is a flat sequence of k-step PAIRS: pair p = 4 g + kp (tap group g,
@@ -543,6 +552,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   run_all(std::integral_constant<int, 2>{});
   run_all(std::integral_constant<int, 1>{});
   const unsigned long long t_loop1 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  STAMP(6);
 
   // ---- epilogue: exchange M_xi through LDS, y = A^T M, bias + residuals, scale, store ----------
   const int nres = uni(G->nres);
@@ -574,7 +584,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+      const int sk_ = mt * NT + nt, sb_ = sk_ < 3 ? 7 + 3 * sk_ : 19;
       __syncthreads();
+      STAMP(sb_);
       // bias and first residual of this thread's 4 rows: requested here so that their latency hides under the exchange
       const int corow = co0 + mt * 32 + 4 * erq;                        // + i
       const int v0 = tb * (4 * W_BT) + (nt * 64 + eth * 32 + ecol) * 4;   // decimated index of y[0]
@@ -602,6 +614,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
               (f32x4){acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
       }
       __syncthreads();
+      STAMP(sb_ + 1);
       if (eact) {
         const float* er = E + (eth * 6 * 32 + ecol) * W_EP + 4 * erq;
         const f32x4 m0 = *reinterpret_cast<const f32x4*>(er), m1 = *reinterpret_cast<const f32x4*>(er + 32 * W_EP),
@@ -657,20 +670,18 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           }
         }
       }
+      STAMP(sb_ + 2);
     }
   }
   if (pf == 0x7fc12345u && trace) trace[0] = 0;      // keeps pf alive; never true for weights
-  if (trace && (tid & 63) == 0) {
+  if (rec2 && (tid & 63) == 0) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned long long slot = atomicAdd(trace, 1ull);
-    unsigned long long* r = trace + 1 + 5 * slot;
-    r[0] = (unsigned long long)blockIdx.x | ((unsigned long long)(hw & 0xffffff) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
-    r[1] = t_start;
-    r[2] = __builtin_amdgcn_s_memrealtime();
-    r[3] = (unsigned long long)wave | ((t_loop0 - t_start) << 8) | ((t_loop1 - t_start) << 36);
-    r[4] = __builtin_amdgcn_s_memtime() - c_start;       // shader clocks: r[4] / (r[2] - r[1]) x 100 MHz
+    rec2[0] = (unsigned long long)blockIdx.x | ((unsigned long long)(hw & 0xffffff) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
+    rec2[1] = t_start;
+    rec2[2] = __builtin_amdgcn_s_memrealtime();
+    rec2[23] = (unsigned long long)wave | ((__builtin_amdgcn_s_memtime() - c_start) << 8);
   }
 }
 
