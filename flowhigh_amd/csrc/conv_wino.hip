@@ -40,7 +40,9 @@
 
 #include <type_traits>
 
+#ifdef FH_WINO_EXPERIMENTS          // tools/exp/build_wino_variants.sh: tiles 8 / 9 (tools/exp/conv_wino2.hip, conv_wino3.hip)
 #include "conv_wino_int.h"
+#endif
 
 namespace {
 
@@ -80,7 +82,10 @@ constexpr int W_CK = 16;             // input channels per chunk
 constexpr int W_THREADS = 768;       // 12 waves = 6 transform points x 2 tile halves
 constexpr int W_EP = 36;             // pitch (floats) of a COLUMN of the epilogue exchange tiles: 16-byte aligned, and
                                      // 36 col mod 64 takes 16 distinct multiples of 4 over 16 lanes: conflict-free b128
-constexpr int W_RUN = FH_WINO_RUN;         // n-blocks of a panel that run together on one XCD
+#ifndef W_RUN_N
+#define W_RUN_N 8
+#endif
+constexpr int W_RUN = W_RUN_N;             // n-blocks of a panel that run together on one XCD
 
 // Wave tile = (32 MT) co x (32 NT) tiles; block tile = (32 MT) co x (64 NT) tiles (256 NT outputs).
 //   <2, 2>: 64 x 512 outputs  (C % 64 == 0)        <3, 1>: 96 x 256 outputs  (C = 96)
@@ -815,7 +820,10 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
 
 extern "C" int fh_wino_tile_m(int tile_cfg) {
   tile_cfg &= ~FH_WINO_BF16X6;
-  return tile_cfg == 6 ? 128 : tile_cfg == 5 ? 32 : (tile_cfg == 4 || tile_cfg == 8) ? 64 : tile_cfg == 1 ? 96 : tile_cfg == 0 ? 64 : -1;
+#ifdef FH_WINO_EXPERIMENTS
+  if (tile_cfg == 8 || tile_cfg == 9) return 64;
+#endif
+  return tile_cfg == 6 ? 128 : tile_cfg == 5 ? 32 : tile_cfg == 4 ? 64 : tile_cfg == 1 ? 96 : tile_cfg == 0 ? 64 : -1;
 }
 
 extern "C" int fh_phase_len(int len, int dilation) { return ((len + dilation - 1) / dilation + 3) & ~3; }
@@ -829,6 +837,7 @@ int wino_dispatch(const fh_wino_group* groups, int n_groups, int batch, int cout
     case 4: return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case 5: return launch_wino<1, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case 6: return launch_wino<4, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+#ifdef FH_WINO_EXPERIMENTS
     case 8: {
       // 64 x 256 tile in 4-wave blocks, six transform points per wave (conv_wino2.hip): vector loads only; launches
       // that cannot use them run the 12-wave 64 x 256 tile (same block -> work mapping, same bits)
@@ -837,7 +846,16 @@ int wino_dispatch(const fh_wino_group* groups, int n_groups, int batch, int cout
         return fh_wino2_launch(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
       return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     }
+    case 9: {
+      // persistent workgroups of two independent 6-wave teams (conv_wino3.hip), 64 x 256 per team tile; same fallback
+      const bool pm = (phase_major & 1) != 0;
+      if ((pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2) && !getenv("FH_WINO_NO_VL"))
+        return fh_wino3_launch(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
+      return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+    }
+    case FH_WINO_BF16X6 + 9: return launch_wino<2, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case FH_WINO_BF16X6 + 8: return launch_wino<2, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
+#endif
     // + FH_WINO_BF16X6: the groups' weights are three-piece bf16 (pack_wino_weight_bf3), six bf16 MFMAs per k-block
     case FH_WINO_BF16X6 + 0: return launch_wino<2, 2, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case FH_WINO_BF16X6 + 1: return launch_wino<3, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);

@@ -258,12 +258,15 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def to_device_struct_array(structs, device):
-    """ctypes Structure list -> device uint8 tensor holding the packed array."""
+WINO3_WS_BYTES = 128          # experiment builds only (tools/exp/conv_wino3.hip): zeroed bytes behind a descriptor array
+
+
+def to_device_struct_array(structs, device, tail_bytes=0):
+    """ctypes Structure list -> device uint8 tensor holding the packed array (+ tail_bytes zeroed bytes behind it)."""
     if not structs:
         raise ValueError("empty descriptor list")
     arr = (type(structs[0]) * len(structs))(*structs)
-    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    host = torch.frombuffer(bytearray(bytes(arr) + bytes(tail_bytes)), dtype=torch.uint8)
     return host.to(device)
 
 

@@ -373,7 +373,7 @@ def from_phase_major(xp, d, length):
 
 def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0, phase_major=False):
     """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
-    d = hip.to_device_struct_array(groups, device)
+    d = hip.to_device_struct_array(groups, device, int(os.environ.get('FH_DESC_TAIL', '0')))
     hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
                                          int(phase_major), tile_cfg, hip.stream()), "fh_conv_wino_f32")
     return d

@@ -132,9 +132,7 @@ typedef struct {
 int fh_sizeof_wino_group(void);
 /* tile_cfg: 0 = 64 co x 512 outputs per block, 1 = 96 co x 256 outputs (cout_pad % fh_wino_tile_m == 0);
  * 4 = 64 co x 256 outputs (short rows: less padding of the last block of a dilation phase);
- * 5 = 32 co x 256 outputs (short clips: more, shorter blocks); 6 = 128 co x 256 outputs; 8 = 64 co x 256 outputs in
- * 4-wave blocks with all six transform points of an output in one wave (no LDS exchange in the epilogue, three
- * independent blocks per CU; needs 16-byte aligned contiguous rows, else runs as 4).  Every shape gives the
+ * 5 = 32 co x 256 outputs (short clips: more, shorter blocks); 6 = 128 co x 256 outputs.  Every shape gives the
  * same bits (same accumulation order); which one is fastest depends on the block count (vocoder.choose_wino_cfg). */
 int fh_wino_tile_m(int tile_cfg);
 /* Phase-major layout of a [B, C, len] tensor for dilation d: every (batch, channel) row holds its d decimated

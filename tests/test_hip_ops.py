@@ -151,13 +151,11 @@ def test_split_bf3_is_exact():
     assert torch.equal(p3[:, 0] + p3[:, 1] + p3[:, 2], x)
 
 
-@pytest.mark.parametrize("wcfg", [0, 4, 5, 6, 8])
+@pytest.mark.parametrize("wcfg", [0, 4, 5, 6])
 @pytest.mark.parametrize("k,d,L,pm", [(11, 1, 1000, False), (7, 3, 777, True), (3, 5, 2049, False), (7, 1, 1203, False)])
 def test_conv_wino_every_tile_shape_gives_the_same_bits(wcfg, k, d, L, pm):
     """The tile shape is a launch-plan choice (vocoder.choose_wino_cfg): all of them accumulate in the same
-    order, so the result must not depend on it - compared bit for bit with the 96 x 256 tile (cfg 1).  Tile 8 is
-    the second kernel (conv_wino2.hip: 4-wave blocks, all six transform points in one wave, A^T in registers); where
-    it cannot use vector loads (odd lengths, strided rows) the launch runs as tile 4."""
+    order, so the result must not depend on it - compared bit for bit with the 96 x 256 tile (cfg 1)."""
     c, B = 384, 2
     x, w, b = rnd(B, c, L, seed=200), rnd(c, c, k, seed=201, scale=1.0 / (c * k) ** 0.5), rnd(c, seed=202)
     xd = (V.to_phase_major(x, d) if pm else x).to(DEV)
@@ -715,68 +713,3 @@ def test_resample_poly(sr_in):
     got = Resampler(DEV)(torch.from_numpy(x).to(DEV), sr_in)
     assert got.shape == ref.shape
     assert maxdiff(got, torch.from_numpy(ref)) <= 2e-6
-
-
-@pytest.mark.parametrize("k,d,pm,nres,L", [(11, 1, False, 1, 2000), (7, 5, True, 0, 1501), (3, 1, False, 3, 512),
-                                           (11, 3, True, 0, 96), (1, 1, False, 0, 260)])
-def test_conv_wino2_equals_the_twelve_wave_kernel_bitwise(k, d, pm, nres, L):
-    """conv_wino2.hip (tile 8) against conv_wino.hip's 64 x 256 tile (tile 4) on the same descriptors: bias, up to
-    three residuals, scale, phase-major rows, batch 3, a channel count that is not a multiple of the tile (cout 80 in
-    cout_pad 128): same bits."""
-    c, cpad, B = 80, 128, 3
-    x, w, b = rnd(B, c, L, seed=300), rnd(c, c, k, seed=301, scale=1.0 / (c * k) ** 0.5), rnd(c, seed=302)
-    res = [rnd(B, c, L, seed=303 + i) for i in range(nres)]
-    conv = lambda t: (V.to_phase_major(t, d) if pm else t).to(DEV)
-    xd, rd = conv(x), [conv(r) for r in res]
-    ud, bd = V.pack_wino_weight(w, cpad).to(DEV), b.to(DEV)
-    outs = []
-    for cfg in (4, 8):
-        out = torch.full_like(xd, float("nan"))
-        g = V.make_wino_group([V.make_wino_seg(xd, ud, c, k)], bd, rd, out, c, cpad, L, scale=0.5)
-        keep = V.conv_wino([g], B, cpad, L, d, DEV, cfg, phase_major=pm)
-        torch.cuda.synchronize()
-        outs.append(V.from_phase_major(out.cpu(), d, L) if pm else out.cpu())
-        del keep
-    assert torch.equal(outs[0], outs[1])
-    ref = ((F.conv1d(x.double(), w.double(), b.double(), dilation=d, padding=(k - 1) // 2 * d)
-            + sum(r.double() for r in res)) * 0.5).float()
-    assert maxdiff(outs[1], ref) <= 3e-5
-
-
-def test_conv_wino2_three_segments_and_transposed_phases():
-    """Tile 8 on the other two launch forms: the fused stage-closing conv (three K segments of 4 / 3 / 1 tap groups,
-    three residuals, / 3) and the output phases of a ConvTranspose1d (strided stores)."""
-    c, L, B = 64, 1204, 2
-    ks = [11, 7, 3]
-    xs = [rnd(B, c, L, seed=320 + i) for i in range(3)]
-    ws = [rnd(c, c, k, seed=330 + i, scale=0.05) for i, k in enumerate(ks)]
-    rs = [rnd(B, c, L, seed=350 + i) for i in range(3)]
-    bsum = rnd(c, seed=340)
-    ref = (sum(F.conv1d(x, w, None, padding=(k - 1) // 2) + r for x, w, r, k in zip(xs, ws, rs, ks)) + bsum.view(1, -1, 1)) / 3
-    xd, rd, bd = [x.to(DEV) for x in xs], [r.to(DEV) for r in rs], bsum.to(DEV)
-    ud = [V.pack_wino_weight(w, c).to(DEV) for w in ws]
-    outs = []
-    for cfg in (4, 8):
-        out = torch.full((B, c, L), float("nan"), device=DEV)
-        g = V.make_wino_group([V.make_wino_seg(xd[i], ud[i], c, k) for i, k in enumerate(ks)], bd, rd, out, c, c, L,
-                              scale=1.0 / 3)
-        keep = V.conv_wino([g], B, c, L, 1, DEV, cfg)
-        torch.cuda.synchronize()
-        outs.append(out.cpu())
-        del keep
-    assert torch.equal(outs[0], outs[1]) and maxdiff(outs[1], ref) <= 2e-5
-    u, k, cin, cout, L = 4, 8, 64, 64, 1000
-    x, wt, b = rnd(B, cin, L, seed=360), rnd(cin, cout, k, seed=361, scale=0.2), rnd(cout, seed=362)
-    ref = F.conv_transpose1d(x.double(), wt.double(), b.double(), stride=u, padding=(k - u) // 2).float()
-    xd, bd = x.to(DEV), b.to(DEV)
-    out = torch.full((B, cout, u * L), float("nan"), device=DEV)
-    groups, keep = [], []
-    for r, taps in enumerate(V.transposed_conv_phases(k, u)):
-        w, center = V.wino_phase_weight(wt, taps)
-        ud1 = V.pack_wino_weight(w, cout).to(DEV)
-        keep.append(ud1)
-        groups.append(V.make_wino_group([V.make_wino_seg(xd, ud1, cin, w.shape[-1], center)], bd, [], out, cout, cout, L,
-                                        stride=u, phase=r))
-    keep.append(V.conv_wino(groups, B, cout, L, 1, DEV, 8))
-    torch.cuda.synchronize()
-    assert maxdiff(out, ref) <= 2e-5

@@ -1,6 +1,7 @@
-"""Residual-stack launch shapes of the 10 s clip under every Winograd tile, incl. tile 8 (conv_wino2.hip: 4-wave
-blocks, six transform points per wave), with a bitwise comparison against tile 4.
-python tools/wino2_bench.py [B] [frames]"""
+"""Residual-stack launch shapes of the 10 s clip under every Winograd tile.  With the experiment build
+(tools/exp/build_wino_variants.sh; FH_LIB_PATH=flowhigh_amd/lib/abl/winox.so) also tile 8 (conv_wino2.hip: 4-wave blocks,
+six transform points per wave) and tile 9 (conv_wino3.hip: persistent workgroups of two 6-wave teams), each compared
+bit for bit with tile 4.  python tools/wino2_bench.py [B] [frames] [C:up,...]   (profiles/r03_wino_block_shapes.txt)"""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -11,7 +12,9 @@ KS = [11, 7, 3]
 st = hip.stream()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 6: (128, 256), 8: (64, 256)}
+TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 6: (128, 256)}
+if hip.lib().fh_wino_tile_m(8) > 0:          # experiment build
+    TILES.update({8: (64, 256), 9: (64, 256)})
 
 
 def time_launch(dw, ng, wpad, L, d, pm, cfg, reps=20):
@@ -44,7 +47,7 @@ def shape(c, L, d, nres, closing=False):
     else:
         gw = [V.make_wino_group([V.make_wino_seg(xs[i], ud[i], c, k)], bs[i], [rs[i]] * nres, outs[i], c, wpad, L)
               for i, k in enumerate(KS)]
-    dw = hip.to_device_struct_array(gw, DEV)
+    dw = hip.to_device_struct_array(gw, DEV, hip.WINO3_WS_BYTES)
     flops = sum(2.0 * c * c * 1.5 * -(-k // 3) * L * B for k in KS)
     row, ref = [], None
     for cfg, (bm, bt) in TILES.items():
@@ -56,13 +59,15 @@ def shape(c, L, d, nres, closing=False):
         if cfg == 4:
             ref = [o.clone() for o in outs]
         same = ""
-        if cfg == 8 and ref is not None:
-            same = " ==4" if all(torch.equal(o, r) for o, r in zip(outs, ref)) else " DIFFERS from 4"
+        if cfg in (8, 9) and ref is not None:
+            eq = lambda a_, b_: torch.equal(torch.nan_to_num(a_, nan=7.0), torch.nan_to_num(b_, nan=7.0))
+            same = " ==4" if all(eq(o, r) for o, r in zip(outs, ref)) else " DIFFERS from 4"
         row.append(f"cfg{cfg} {t:7.1f} us {flops / t / 1e6:6.1f} TF{same}")
     print(f"c={c:4d} L={L:6d} d={d} nres={nres} {'closing' if closing else 'stack  '} | " + " | ".join(row), flush=True)
 
 
-for c, up in ((768, 5), (384, 20), (192, 60), (96, 120), (48, 240)):
+SHAPES = [(int(a), int(b)) for a, b in (s.split(":") for s in sys.argv[3].split(","))] if len(sys.argv) > 3 else [(768, 5), (384, 20), (192, 60), (96, 120), (48, 240)]
+for c, up in SHAPES:
     L = N * up
     shape(c, L, 1, 1)
     shape(c, L, 3, 0)
