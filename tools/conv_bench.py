@@ -34,7 +34,7 @@ def run(c, L, ks, tile_cfg, B=1, reps=5, res=False, label=""):
     ms = e0.elapsed_time(e1) / reps
     print(f"{label:34s} C={c} L={L} ks={ks} cfg={tile_cfg} blocks={nblocks:5d} {ms*1e3:8.1f} us  {flops/ms/1e9:6.1f} TF/s", flush=True)
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) < 2:
     # equal-size blocks, cfg0 (3 blocks/CU resident): 256 / 512 / 768 / 1536 / 3072 blocks
     for nb, lab in [(256, "1 block/CU"), (512, "2 blocks/CU"), (768, "3 blocks/CU"), (1536, "2 rounds of 3"), (3072, "4 rounds"), (6144, "8 rounds")]:
         L = nb // 6 * 128
