@@ -89,7 +89,7 @@ def pick_ck(*cins):
     """Channel chunk of the K loop: 16 when every segment allows it, else 8 -- except for 24 input channels (the
     narrowest stage), which run as ONE chunk of 24 (a K step is then a tap of 3 x 8 channels: a third of the block
     barriers and weight-tile hand-overs)."""
-    if all(c == 24 for c in cins):
+    if all(c == 24 for c in cins) and os.environ.get('FH_CK24', '1') != '0':
         return 24
     return 16 if all(c % 16 == 0 for c in cins) else 8
 
