@@ -45,10 +45,7 @@ struct ConvCfg {
   static constexpr int XREG = (XW + 63) / 64;            // dwords per lane per row
   static constexpr int WF4 = BM * CK / 4;                // float4s in a weight tile
   static constexpr int WREG = (WF4 + 255) / 256;
-  // CK = 24: the whole input depth of the narrowest stage is ONE chunk, so a step is a tap of 3 x 8 channels (48
-  // MFMAs per wave and barrier instead of 16) and the slab is staged once per K segment: one slab buffer
-  static constexpr int XBUFS = CK == 24 ? 1 : 2;
-  static constexpr int LDS_FLOATS = 2 * BM * WP + XBUFS * CK * XW;
+  static constexpr int LDS_FLOATS = 2 * BM * WP + 2 * CK * XW;
 };
 
 struct SegU {          // wave-uniform copy of the hot fields of one fh_conv_seg
@@ -67,7 +64,7 @@ __device__ __forceinline__ SegU load_seg(const fh_conv_seg* S) {
 }
 
 template <int MT, int NT, int WM, int WN, int CK>
-__global__ __launch_bounds__(256, (MT * NT <= 4 && CK != 24 ? 3 : 2)) void conv_mfma_kernel(const fh_conv_group* __restrict__ groups,
+__global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(const fh_conv_group* __restrict__ groups,
                                                         int n_groups, int batch, int co_tiles,
                                                         int n_tiles) {
   using Cfg = ConvCfg<MT, NT, WM, WN, CK>;
@@ -257,7 +254,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && CK != 24 ? 3 : 2)) void conv_
       }
       if (ks == KS / 2) {                         // LDS stores of the tiles of step it+1
         if (it + 1 < nsteps) store_w(STORE, wbuf ^ 1);
-        if (flip_x && Cfg::XBUFS == 2) store_x(xbuf ^ 1);
+        if (flip_x) store_x(xbuf ^ 1);
       }
       if (ks == KS - 2) xoff_next = toff[k1.s * FH_CONV_MAX_TAPS + k1.j];
       __builtin_amdgcn_sched_barrier(0);
@@ -271,12 +268,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && CK != 24 ? 3 : 2)) void conv_
     }
     __syncthreads();
     wbuf ^= 1;
-    if (Cfg::XBUFS == 2) {
-      if (flip_x) xbuf ^= 1;
-    } else if (flip_x) {                          // single slab buffer (next K segment): everyone has left the old slab
-      store_x(0);
-      __syncthreads();
-    }
+    if (flip_x) xbuf ^= 1;
     xoff_cur = xoff_next;
     k0 = k1;
     S0 = S1;
@@ -477,9 +469,7 @@ extern "C" int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, in
   const int bm = fh_conv_tile_m(tile_cfg);
   FH_CHECK_ARG(bm > 0, "fh_conv_grouped_f32: unknown tile_cfg %d", tile_cfg);
   FH_CHECK_ARG(cout_pad % bm == 0, "fh_conv_grouped_f32: cout_pad %d not a multiple of tile %d", cout_pad, bm);
-  FH_CHECK_ARG(ck == 8 || ck == 16 || (ck == 24 && tile_cfg == 4),
-               "fh_conv_grouped_f32: channel chunk must be 8 or 16, or 24 with the 32 x 512 tile (got %d, tile %d)", ck, tile_cfg);
-  if (ck == 24) return launch_conv<1, 4, 1, 4, 24>(groups, n_groups, batch, cout_pad, n_len, (hipStream_t)stream);
+  FH_CHECK_ARG(ck == 8 || ck == 16, "fh_conv_grouped_f32: channel chunk must be 8 or 16 (got %d)", ck);
   // per-clip tensors are addressed with 32-bit byte offsets (buffer descriptors): cout * lout * 4 < 2^31
   // is checked by the host plan (flowhigh_amd/vocoder.py) where the shapes are known.
   hipStream_t st = (hipStream_t)stream;

@@ -86,11 +86,7 @@ def fold_weight_norm(sd):
 
 
 def pick_ck(*cins):
-    """Channel chunk of the K loop: 16 when every segment allows it, else 8 -- except for 24 input channels (the
-    narrowest stage), which run as ONE chunk of 24 (a K step is then a tap of 3 x 8 channels: a third of the block
-    barriers and weight-tile hand-overs)."""
-    if all(c == 24 for c in cins) and os.environ.get('FH_CK24', '1') != '0':
-        return 24
+    """Channel chunk of the K loop: 16 when every segment allows it, else 8."""
     return 16 if all(c % 16 == 0 for c in cins) else 8
 
 
@@ -468,9 +464,6 @@ class Vocoder:
             tcfg, bm, cpad = pick_tile_cfg(c)
             st = dict(c=c, cin=self.c0 // (2 ** i), u=u, k=k, tile_cfg=tcfg, cpad=cpad,
                       ck=pick_ck(c), up_ck=pick_ck(self.c0 // (2 ** i)))
-            for key in ("ck", "up_ck"):          # (the one-chunk form of 24 channels exists for the 32 x 512 tile only)
-                if st[key] == 24 and tcfg != 4:
-                    st[key] = 8
             st["wcfg"], st["wpad"] = pick_wino_tile(c)
             wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
             st["up_b"] = g(f"ups.{i}.0.bias").to(dev)

@@ -47,9 +47,8 @@ const char* fh_last_error(void);
  * with x read as 0 outside [0, lin).
  *
  * Packed weights: float [cin/ck][ntaps][cout_pad][ck], ck = channel chunk (16, or 8 when some
- * cin % 16 != 0; 24 with tile_cfg 4 when EVERY segment has exactly 24 input channels: the whole depth is one
- * chunk, a K step is one tap of 24 channels), cout_pad = cout rounded up to the tile height of `tile_cfg`
- * (fh_conv_tile_m), zero padded.  cin % ck == 0 for every segment.
+ * cin % 16 != 0), cout_pad = cout rounded up to the tile height of `tile_cfg` (fh_conv_tile_m),
+ * zero padded.  cin % ck == 0 for every segment.
  * --------------------------------------------------------------------------------- */
 #define FH_CONV_MAX_TAPS 16
 #define FH_CONV_MAX_SEG 3

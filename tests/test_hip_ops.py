@@ -713,38 +713,3 @@ def test_resample_poly(sr_in):
     got = Resampler(DEV)(torch.from_numpy(x).to(DEV), sr_in)
     assert got.shape == ref.shape
     assert maxdiff(got, torch.from_numpy(ref)) <= 2e-6
-
-
-@pytest.mark.parametrize("k,d,nres", [(3, 1, 1), (7, 3, 0), (11, 5, 2)])
-def test_conv_one_chunk_of_24_channels(k, d, nres):
-    """ck = 24 (tile 4): the narrowest stage's 24 input channels as ONE chunk, a K step = one tap of 24 channels
-    (bigvgan/models.py:63-72 at the 24-channel stage), with bias, residuals, scale and a ragged length."""
-    B, c, L = 2, 24, 1531
-    x, w, b = rnd(B, c, L, seed=400), rnd(c, c, k, seed=401, scale=0.2), rnd(c, seed=402)
-    res = [rnd(B, c, L, seed=403 + i) for i in range(nres)]
-    ref = (F.conv1d(x, w, b, dilation=d, padding=(k - 1) // 2 * d) + sum(res)) * 0.5
-    got = run_conv(x, w, b, d, 4, res=res, scale=0.5, ck=24)
-    assert maxdiff(got, ref) <= 2e-5
-    assert V.pick_ck(24) == 24 and V.pick_ck(24, 24, 24) == 24 and V.pick_ck(24, 48) == 8 and V.pick_ck(48) == 16
-
-
-def test_conv_one_chunk_of_24_channels_three_segments():
-    """... and the fused stage-closing conv: three K segments (11 / 7 / 3 taps) of 24 channels each: the slab of
-    the next segment goes through the single slab buffer behind a barrier."""
-    B, c, L = 2, 24, 2100
-    ks = [11, 7, 3]
-    xs = [rnd(B, c, L, seed=410 + i) for i in range(3)]
-    ws = [rnd(c, c, k, seed=420 + i, scale=0.1) for i, k in enumerate(ks)]
-    rs = [rnd(B, c, L, seed=430 + i) for i in range(3)]
-    bsum = rnd(c, seed=440)
-    ref = (sum(F.conv1d(x, w, None, padding=(k - 1) // 2) + r for x, w, r, k in zip(xs, ws, rs, ks)) + bsum.view(1, -1, 1)) / 3
-    cpad = 32
-    xd, rd, bd = [x.to(DEV) for x in xs], [r.to(DEV) for r in rs], bsum.to(DEV)
-    wp = [V.pack_conv_weight(w, cpad, 24).to(DEV) for w in ws]
-    out = torch.full((B, c, L), float("nan"), device=DEV)
-    segs = [V.make_conv_seg(xd[i], wp[i], c, [t - (k - 1) // 2 for t in range(k)]) for i, k in enumerate(ks)]
-    g = V.make_conv_group(segs, bd, rd, out, c, cpad, L, L, L, scale=1.0 / 3)
-    keep = V.conv_grouped([g], B, cpad, L, 4, DEV, 24)
-    torch.cuda.synchronize()
-    assert maxdiff(out, ref) <= 1e-5
-    del keep

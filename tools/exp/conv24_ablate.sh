@@ -6,6 +6,7 @@
 # Run on the GPU box: tools/exp/conv24_ablate.sh > gpurun_out/conv24_ablate.txt
 set -e
 cd "$(dirname "$0")/../.."
+# (the ablations were measured on the experiment build with the 24 channels as one chunk; the patches below apply to the product source as well)
 python - <<'PY'
 s = open("flowhigh_amd/csrc/conv_mfma.hip").read()
 a = s.replace("          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q][nt] * scale), ro, off[q][nt], 0, 0);",
