@@ -14,7 +14,7 @@
 //   z[2i+1] = snake( 2 * sum_{q=-2..3} x[i+q] f_up[6-2q] )
 //   y[i]    = sum_{k=0..11} z[2i+k-5] f_dn[k]
 //
-// Block = 256 threads, one (group, batch, channel) row segment of TT = 256 PPT - 8 outputs:
+// Block = 256 threads; a tile = one (group, batch, channel) row segment of TT = 256 PPT - 8 outputs:
 //   phase 1: x[t0-8 .. t0+TT+7] -> LDS                         (258 float4, clamped indices)
 //   phase 2: thread t makes the 4 consecutive (even, odd) pairs 4t .. 4t+3 of z -> LDS
 //   phase 3: thread t makes the 4 consecutive outputs 4t .. 4t+3 and stores them as one 16-byte vector.
@@ -66,221 +66,10 @@ constexpr int ACT_TT = ACT_PAIRS - 8;        // outputs per tile (multiple of 8:
 constexpr int ACT_XS = ACT_TT + 16;          // staged inputs x[t0-8 .. t0+TT+7]
 constexpr int ACT_XF4 = ACT_XS / 4;          // ... as float4s
 
-// One block = one (group, batch, channel, tile).  Thread t owns pairs 4t .. 4t+3 and outputs
-// 4t .. 4t+3: every LDS access is a 16-byte vector, and when rows are 16-byte aligned
-// (len % 4 == 0) so is every global access -- 4-byte-per-lane loads ran this kernel at 2.5 TB/s.
-// din / dout > 1: the input / output tensor is phase-major for that dilation (fh_phase_len, include/
-// flowhigh_hip.h): element t of a row lives at (t % d) * lp + t / d.  A dilated Winograd conv between two
-// such launches then works on contiguous runs.  Consecutive lanes still touch consecutive t, i.e. d runs of
-// 64 / d contiguous floats per wave instruction.
-// RAGGED (fh_act1d_ragged_f32): every group is one clip's [C, len_g] tensor with its own length (fh_act_group.len);
-// block -> (group, channel, tile) through the groups' tile_base prefix (ascending; one ballot per 64 groups).
-template <bool RAGGED>
-__global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const fh_act_group* __restrict__ groups,
-                                                    int batch, int channels, int len,
-                                                    int tiles_per_row, int din, int dout, int n_groups) {
-  __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
-  __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
-
-  int gsel = 0, local = blockIdx.x;
-  if (RAGGED) {
-    int cnt = 0;
-    for (int base = 0; base < n_groups; base += 64) {
-      const int idx = base + (int)(threadIdx.x & 63);
-      const bool le = idx < n_groups && groups[idx].tile_base <= (int)blockIdx.x;
-      cnt += __popcll(__ballot(le));
-    }
-    gsel = __builtin_amdgcn_readfirstlane(cnt - 1);
-    len = __builtin_amdgcn_readfirstlane(groups[gsel].len);
-    tiles_per_row = (len + ACT_TT - 1) / ACT_TT;
-    local = (int)blockIdx.x - __builtin_amdgcn_readfirstlane(groups[gsel].tile_base);
-  }
-  const int tile = local % tiles_per_row;
-  const int row = local / tiles_per_row;          // (g * batch + b) * channels + c
-  const int c = row % channels;
-  const int gb = RAGGED ? gsel : row / channels;
-  const fh_act_group& G = groups[RAGGED ? gsel : gb / batch];
-  const int b = RAGGED ? 0 : gb % batch;
-  const int lp_in = ((len + din - 1) / din + 3) & ~3, lp_out = ((len + dout - 1) / dout + 3) & ~3;
-  const size_t rowi = (size_t)b * channels + c;
-  const float* __restrict__ x = G.x + rowi * (din > 1 ? (size_t)din * lp_in : (size_t)len);
-  float* __restrict__ y = G.y + rowi * (dout > 1 ? (size_t)dout * lp_out : (size_t)len);
-  const float alpha = G.alpha[c];
-  const float inv_beta = G.inv_beta[c];
-  const int t0 = tile * ACT_TT;
-  const int tid = threadIdx.x;
-  const int zlast = 2 * len - 1;
-  const bool vec = (len & 3) == 0 && ((((size_t)G.x) | ((size_t)G.y)) & 15) == 0;
-
-  // phase 1: xs[j] = x[clamp(t0 - 8 + j)], j < XS; thread t stages float4 #t, #256+t, ...
-  if (din > 1) {
-    const int tb = t0 - 8;
-    if (tb >= 0 && tb + ACT_XS <= len) {
-      // tile interior: every thread fetches 4 consecutive samples of ONE phase (16 bytes, contiguous in the
-      // phase-major row) and scatters them to their natural positions in LDS (stride din, odd -> conflict free)
-      const int nq = ((ACT_XS + din - 1) / din + 3) / 4;
-      for (int q = tid; q < din * nq; q += ACT_THREADS) {
-        const int p = q / nq, k = q - p * nq;
-        const int u_lo = (tb - p + din - 1) / din;
-        const int u_hi = (tb + ACT_XS - 1 - p) / din;
-        const int u = u_lo + 4 * k;
-        const float* src = x + p * lp_in + u;
-        if (u + 3 <= u_hi) {
-          const f32x4u v = *reinterpret_cast<const f32x4u*>(src);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xs[(u + e) * din + p - tb] = v[e];
-        } else {
-          for (int e = 0; e < 4 && u + e <= u_hi; ++e) xs[(u + e) * din + p - tb] = src[e];
-        }
-      }
-    } else {
-      for (int j = tid; j < ACT_XS; j += ACT_THREADS) {
-        int t = tb + j;
-        t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
-        const int u = t / din;
-        xs[j] = x[(t - u * din) * lp_in + u];
-      }
-    }
-  } else
-#pragma unroll
-  for (int rep = 0; rep < (ACT_XF4 + ACT_THREADS - 1) / ACT_THREADS; ++rep) {
-    const int f = tid + ACT_THREADS * rep;
-    if (f >= ACT_XF4) break;
-    const int t = t0 - 8 + 4 * f;
-    f32x4 v;
-    if (vec && t >= 0 && t + 3 < len) {
-      v = *reinterpret_cast<const f32x4*>(x + t);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int tt = t + e;
-        tt = tt < 0 ? 0 : (tt > len - 1 ? len - 1 : tt);
-        v[e] = x[tt];
-      }
-    }
-    *reinterpret_cast<f32x4*>(xs + 4 * f) = v;
-  }
-  __syncthreads();
-
-  // phase 2: pairs p = PPT tid + r, sample i = t0 - 4 + p; x[i+q] is xs[p + q + 4], q in [-3, 3]
-  f32x2 fu2[7];             // taps of x[i-3 .. i+3] for (z[2i], z[2i+1]); the unused end tap is 0
-#pragma unroll
-  for (int q = -3; q <= 3; ++q) {
-    fu2[q + 3][0] = q <= 2 ? 2.f * G.up_taps[5 - 2 * q] : 0.f;      // (the 2x of UpSample1d folded in: exact)
-    fu2[q + 3][1] = q >= -2 ? 2.f * G.up_taps[6 - 2 * q] : 0.f;
-  }
-  {
-    float xv[ACT_PPT + 8];  // xs[PPT tid .. PPT tid + PPT + 7]; pair r uses xv[r + 1 .. r + 7]
-#pragma unroll
-    for (int v = 0; v < ACT_PPT / 4 + 2; ++v) {
-      const f32x4 t4 = *reinterpret_cast<const f32x4*>(xs + ACT_PPT * tid + 4 * v);
-      xv[4 * v] = t4[0]; xv[4 * v + 1] = t4[1]; xv[4 * v + 2] = t4[2]; xv[4 * v + 3] = t4[3];
-    }
-    f32x2 zout[ACT_PPT];
-#pragma unroll
-    for (int r = 0; r < ACT_PPT; ++r) {
-      f32x2 z = {0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 7; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + 1 + q]), fu2[q], z);
-      const f32x2 arg = z * alpha;
-      f32x2 s2 = sin_squared2(arg);
-      if (__builtin_expect(fabsf(arg[0]) >= 32768.f || fabsf(arg[1]) >= 32768.f, 0)) {
-        s2[0] = sin_squared_slow(arg[0]);
-        s2[1] = sin_squared_slow(arg[1]);
-      }
-      zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2, z);
-    }
-    // positions outside [0, 2L-1] are never used directly: phase 3 clamps its index instead
-    f32x4* zw = reinterpret_cast<f32x4*>(zs + 2 * ACT_PPT * tid);
-#pragma unroll
-    for (int v = 0; v < ACT_PPT / 2; ++v)
-      zw[v] = (f32x4){zout[2 * v][0], zout[2 * v][1], zout[2 * v + 1][0], zout[2 * v + 1][1]};
-  }
-  __syncthreads();
-
-  // phase 3: outputs o = 4 tid + r (i = t0 + o); z[m] is zs[m - 2 (t0 - 4)], so
-  //          y[i] = sum_k zs[2 o + 3 + k] f_dn[k]  (interior) -- taps on zs[8 tid + 2 r + 3 ..]
-  float fd[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) fd[k] = G.down_taps[k];
-  // taps as aligned (even, odd) z pairs: pair j of output r is (zv[2r + 2 + 2j], zv[2r + 3 + 2j]) = taps (2j - 1, 2j)
-  f32x2 fdp[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    fdp[j][0] = j > 0 ? fd[2 * j - 1] : 0.f;
-    fdp[j][1] = j < 6 ? fd[2 * j] : 0.f;
-  }
-  const int o0 = ACT_PPT * tid;
-  const int i0 = t0 + o0;
-  if (dout == 1 && (o0 >= ACT_TT || i0 >= len)) return;
-  float zv[2 * ACT_PPT + 16];   // zs[2 PPT tid .. + 2 PPT + 15]
-#pragma unroll
-  for (int v = 0; v < ACT_PPT / 2 + 4; ++v) {
-    const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 2 * ACT_PPT * tid + 4 * v);
-    zv[4 * v] = t4[0]; zv[4 * v + 1] = t4[1]; zv[4 * v + 2] = t4[2]; zv[4 * v + 3] = t4[3];
-  }
-  float out[ACT_PPT];
-  const int zbase = 2 * (t0 - 4);
-#pragma unroll
-  for (int r = 0; r < ACT_PPT; ++r) {
-    const int i = i0 + r;
-    float acc = 0.f;
-    if (2 * i - 5 >= 0 && 2 * i + 6 <= zlast) {
-      f32x2 a2 = {0.f, 0.f};                          // even-tap and odd-tap partial sums, packed
-#pragma unroll
-      for (int j = 0; j < 7; ++j)
-        a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
-      acc = a2[0] + a2[1];
-    } else if (i < len) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        int m = 2 * i + k - 5;
-        m = m < 0 ? 0 : (m > zlast ? zlast : m);
-        acc = fmaf(zs[m - zbase], fd[k], acc);
-      }
-    }
-    out[r] = acc;
-  }
-  if (dout > 1) {          // through LDS (xs is free now) so that every store instruction writes runs
-#pragma unroll
-    for (int v = 0; v < ACT_PPT / 4; ++v)
-      *reinterpret_cast<f32x4*>(xs + o0 + 4 * v) = (f32x4){out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
-    __syncthreads();
-    const int t_end = (t0 + ACT_TT < len ? t0 + ACT_TT : len) - 1;      // last output of this tile
-    const int nq = ((ACT_TT + dout - 1) / dout + 3) / 4;
-    for (int q = tid; q < dout * nq; q += ACT_THREADS) {                         // 4 consecutive outputs of one phase
-      const int p = q / nq, k = q - p * nq;
-      const int u_lo = (t0 - p + dout - 1) / dout;
-      const int u_hi = t_end >= p ? (t_end - p) / dout : -1;
-      const int u = u_lo + 4 * k;
-      float* dst = y + p * lp_out + u;
-      if (u + 3 <= u_hi) {
-        f32x4u v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = xs[(u + e) * dout + p - t0];
-        *reinterpret_cast<f32x4u*>(dst) = v;
-      } else {
-        for (int e = 0; e < 4 && u + e <= u_hi; ++e) dst[e] = xs[(u + e) * dout + p - t0];
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int v = 0; v < ACT_PPT / 4; ++v) {   // o0 + PPT - 1 < TT always holds for o0 < TT (TT % PPT == 0)
-    if (vec && i0 + 4 * v + 3 < len) {
-      *reinterpret_cast<f32x4*>(y + i0 + 4 * v) = (f32x4){out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
-    } else {
-#pragma unroll
-      for (int r = 4 * v; r < 4 * v + 4; ++r)
-        if (i0 + r < len) y[i0 + r] = out[r];
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// Plain-layout launches: software-pipelined strips.  The kernel above holds at most ~1/3 of a CU's
-// loads in flight (load -> barrier -> math -> barrier -> math -> store per block, all resident blocks in
-// phase) and stalls at ~3 TB/s where a copy reaches 6-7.  Here a block walks ACT_NTILE consecutive tiles
+// Software-pipelined strips.  A one-tile-per-block form (rounds 1-2) held at most ~1/3 of a CU's loads in flight
+// (load -> barrier -> math -> barrier -> math -> store per block, all resident blocks in phase) and stalled at
+// ~3 TB/s where a copy reaches 6-7.  Here a block walks ACT_NTILE consecutive tiles
 // of the flattened (row, tile) space and requests tile i + 1 before it computes tile i.  All global
 // accesses are unconditional buffer operations (invalid = out-of-range offset), so the compiler's
 // s_waitcnt are exact: the wait for the prefetched tile does not drain the stores issued after it.
@@ -509,20 +298,12 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
         zf[r] = z;
         arg[r] = z * alpha;
       }
-#if defined(ACT_ABL) && (ACT_ABL & 2)
-#pragma unroll
-      for (int r = 0; r < ACT_PPT; ++r) zout[r] = (f32x2){xv[r + 1], xv[r + 2]} * alpha + inv_beta;
-#else
       f32x2 s2[ACT_PPT];
       float amax = 0.f;
 #pragma unroll
       for (int r = 0; r < ACT_PPT; ++r) {
-#if defined(ACT_ABL) && (ACT_ABL & 1)
-        s2[r] = arg[r];
-#else
         s2[r] = sin_squared2(arg[r]);
         amax = fmaxf(amax, fmaxf(fabsf(arg[r][0]), fabsf(arg[r][1])));     // (NaN falls through, as sinf(NaN))
-#endif
       }
       if (__builtin_expect(amax >= 32768.f, 0)) {
 #pragma unroll 1
@@ -534,7 +315,6 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
       }
 #pragma unroll
       for (int r = 0; r < ACT_PPT; ++r) zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2[r], zf[r]);
-#endif
       f32x4* zw = reinterpret_cast<f32x4*>(zs + 2 * ACT_PPT * tid);
 #pragma unroll
       for (int v = 0; v < ACT_PPT / 2; ++v)
@@ -558,10 +338,6 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
       const int zbase = 2 * (t0 - 4);
 #pragma unroll
       for (int r = 0; r < ACT_PPT; ++r) {       // interior form for every output (reads stay inside zs)
-#if defined(ACT_ABL) && (ACT_ABL & 4)
-        out[r] = zv[2 * r + 8];
-        continue;
-#endif
         f32x2 a2 = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 7; ++j)
@@ -631,14 +407,14 @@ extern "C" int fh_sizeof_act_group(void) { return (int)sizeof(fh_act_group); }
 extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups, int batch,
                                        int channels, int len, int din, int dout, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && channels > 0 && len > 0, "fh_act1d_grouped_f32: bad sizes");
-  FH_CHECK_ARG(din >= 1 && dout >= 1 && din <= 64 && dout <= 64, "fh_act1d_grouped_pm_f32: bad dilations %d / %d", din, dout);
+  FH_CHECK_ARG(din >= 1 && dout >= 1, "fh_act1d_grouped_pm_f32: bad dilations %d / %d", din, dout);
   const int tiles = fh_cdiv(len, ACT_TT);
   const long long blocks = (long long)n_groups * batch * channels * tiles;
   FH_CHECK_ARG(blocks < (1ll << 31), "fh_act1d_grouped_f32: grid too large");
-  // chunks of a tile in phase-major form must fit 2 per thread: ceil(ceil(XS / d) / 4) * d <= 512
-  const bool strip_ok = (long long)len * 4 * (din > dout ? din : dout) < (1ll << 31) && din <= 16 && dout <= 16 &&
-                        !getenv("FH_ACT_NO_STRIP");
-  if (strip_ok) {
+  // chunks of a tile in phase-major form must fit 2 per thread: ceil(ceil(XS / d) / 4) * d <= 512; 32-bit row offsets
+  FH_CHECK_ARG(din <= 16 && dout <= 16, "fh_act1d_grouped_pm_f32: phase-major dilations above 16 are not supported (%d / %d)", din, dout);
+  FH_CHECK_ARG((long long)len * 4 * (din > dout ? din : dout) < (1ll << 31), "fh_act1d_grouped_f32: rows of %d samples are too long", len);
+  {
     const long long strips = (blocks + ACT_NTILE - 1) / ACT_NTILE;
     const bool vec = (len & 3) == 0;   // rows 16-byte aligned provided the tensors are (checked by the host plan)
 #define FH_ACT_LAUNCH(V, PI, PO)                                                                              \
@@ -662,11 +438,7 @@ extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups,
 #undef FH_ACT_LAUNCH_D
 #undef FH_ACT_LAUNCH
     FH_CHECK_LAUNCH("fh_act1d_grouped_f32");
-    return FH_OK;
   }
-  hipLaunchKernelGGL(act1d_kernel<false>, dim3((unsigned)blocks), dim3(ACT_THREADS), 0, (hipStream_t)stream, groups,
-                     batch, channels, len, tiles, din, dout, n_groups);
-  FH_CHECK_LAUNCH("fh_act1d_grouped_f32");
   return FH_OK;
 }
 
@@ -676,8 +448,8 @@ extern "C" int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int
                                    long long total_tiles, int all_len_mult4, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && channels > 0 && total_tiles > 0 && total_tiles < (1ll << 31),
                "fh_act1d_ragged_f32: bad sizes");
-  FH_CHECK_ARG(din >= 1 && dout >= 1 && din <= 64 && dout <= 64, "fh_act1d_ragged_f32: bad dilations %d / %d", din, dout);
-  if (din <= 16 && dout <= 16 && !getenv("FH_ACT_NO_STRIP")) {      // (row bytes < 2^31: checked by the host plan)
+  FH_CHECK_ARG(din >= 1 && dout >= 1 && din <= 16 && dout <= 16, "fh_act1d_ragged_f32: bad dilations %d / %d", din, dout);
+  {                                                                  // (row bytes < 2^31: checked by the host plan)
     const long long strips = (total_tiles + ACT_NTILE - 1) / ACT_NTILE;
     const bool vec = all_len_mult4 != 0;
 #define FH_ACT_RLAUNCH(V, PI, PO)                                                                                       \
@@ -689,11 +461,7 @@ extern "C" int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int
     else { if (vec) FH_ACT_RLAUNCH(true, false, false); else FH_ACT_RLAUNCH(false, false, false); }
 #undef FH_ACT_RLAUNCH
     FH_CHECK_LAUNCH("fh_act1d_ragged_f32");
-    return FH_OK;
   }
-  hipLaunchKernelGGL(act1d_kernel<true>, dim3((unsigned)total_tiles), dim3(ACT_THREADS), 0, (hipStream_t)stream, groups,
-                     1, channels, 0, 1, din, dout, n_groups);
-  FH_CHECK_LAUNCH("fh_act1d_ragged_f32");
   return FH_OK;
 }
 

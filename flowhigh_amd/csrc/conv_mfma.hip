@@ -95,16 +95,6 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   const int b = uni(gb % batch);
   const fh_conv_group* __restrict__ G = groups + uni(gb / batch);
 
-  // Static issue priority per block: the three blocks that are co-resident on a CU ({b, b + 256,
-  // b + 512}: observed dispatch order, performance only) would otherwise run in lockstep -- same
-  // program, same start -- and reach their per-step barrier together, leaving the matrix pipe idle.
-  // With distinct priorities one block's sync phase overlaps the others' MFMA phases; the earliest
-  // (heaviest, see vocoder.py) blocks get the highest priority.
-  {
-    const int pr = uni((int)(blockIdx.x >> 8) % 3);
-    if (pr == 0) __builtin_amdgcn_s_setprio(2);
-    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

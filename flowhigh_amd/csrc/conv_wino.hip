@@ -391,7 +391,6 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       };
       // staging of the NEXT chunk's slab, spread over this chunk's pairs (called with the pair index)
       auto stage = [&](int p) {
-#if !(defined(WINO_ABL) && (WINO_ABL & 8))       // timing experiment: slab of the first chunk only
         if constexpr (VL) {
           // item 0 at the first pair; with two items per thread the first is stored (the other buffer is
           // free all chunk long) and the second requested a few pairs later, in the same 8 registers
@@ -413,7 +412,6 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           }
           if (GC > 1 && p == 4 * (GC - 1) && has_slab) store_x(xbuf ^ 1, sub);
         }
-#endif
       };
       if constexpr (BF) {
         // bf16 x 6 form, one tap group (16-channel k-block) at a time, one tile column at a time: the lane's 8
@@ -444,13 +442,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
               v[2 * kp + 1] = t[1];
             }
             bf16x8 bh, bm, bl;
-#if defined(WINO_ABL) && (WINO_ABL & 32)         // timing experiment: no split (one cvt, pieces reused)
-            bh = __builtin_bit_cast(bf16x8, (u32x4){pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])});
-            bm = bh;
-            bl = bh;
-#else
             split8(v, bh, bm, bl);
-#endif
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const bf16x8 ah = __builtin_bit_cast(bf16x8, a3[mt][0]), am = __builtin_bit_cast(bf16x8, a3[mt][1]),
@@ -465,11 +457,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
               acc[mt][nt] = t;
             }
           }
-#if !(defined(WINO_ABL) && (WINO_ABL & 4))       // timing experiment: A pieces of the first step only
           const bool same_chunk = g + 1 < GC;      // the A registers are free: request the next tap group's pieces
           const WSeg& Sa = same_chunk ? S : Sx;
           load_a3(Sa, same_chunk ? c : cx, same_chunk ? g + 1 : 0, same_chunk || has_next);
-#endif
         }
       } else {
       fetch(0, 0);
@@ -504,16 +494,13 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
                                                                  acc[mt][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-#if !(defined(WINO_ABL) && (WINO_ABL & 4))       // timing experiment: A tile of the first step only
         if (kp & 1) {                              // this half of the A registers is free: refill it for the next step
           const bool same_chunk = g + 1 < GC;
           const WSeg& Sa = same_chunk ? S : Sx;
           load_a_half(h, Sa, same_chunk ? c : cx, same_chunk ? g + 1 : 0, same_chunk || has_next);
         }
-#endif
       }
       }
-#if !(defined(WINO_ABL) && (WINO_ABL & 8))
       if constexpr (VL) {
         if (has_slab) {
           if (GC == 1) vl_store(Ss, xbuf ^ 1, sub, 0, 0);
@@ -526,7 +513,6 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
         __syncthreads();
         xbuf ^= 1;
       }
-#endif
     }
   };
 
@@ -811,7 +797,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
   // (phase_major bit 1: the caller rules the vector loader out -- ragged launches in which some group's rows are
   // not 16-byte aligned; `len` is then only the longest group's length)
   const bool pm = (phase_major & 1) != 0;
-  const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2) && !getenv("FH_WINO_NO_VL");
+  const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2);
   return vl ? launch_wino_vl<MT, NT, SUBS, true, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs)
             : launch_wino_vl<MT, NT, SUBS, false, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs);
 }
@@ -842,14 +828,14 @@ int wino_dispatch(const fh_wino_group* groups, int n_groups, int batch, int cout
       // 64 x 256 tile in 4-wave blocks, six transform points per wave (conv_wino2.hip): vector loads only; launches
       // that cannot use them run the 12-wave 64 x 256 tile (same block -> work mapping, same bits)
       const bool pm = (phase_major & 1) != 0;
-      if ((pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2) && !getenv("FH_WINO_NO_VL"))
+      if ((pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2))
         return fh_wino2_launch(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
       return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     }
     case 9: {
       // persistent workgroups of two independent 6-wave teams (conv_wino3.hip), 64 x 256 per team tile; same fallback
       const bool pm = (phase_major & 1) != 0;
-      if ((pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2) && !getenv("FH_WINO_NO_VL"))
+      if ((pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2))
         return fh_wino3_launch(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
       return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     }

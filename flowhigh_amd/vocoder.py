@@ -25,38 +25,23 @@ from . import hip
 VOC = "flowhigh.audio_enc_dec.vocoder."
 # preference order among equal padded heights: tiles that keep 3 blocks per CU resident first
 _TILE_PREF = [(0, 128), (6, 96), (3, 64), (1, 192), (2, 96), (4, 32)]
-# experiments only: FH_CONV_TILE_OVERRIDE="0:5" runs every 128x128 launch with the 128x64 tile
-_TILE_OVERRIDE = {int(a): int(b) for a, b in
-                  (kv.split(":") for kv in os.environ.get("FH_CONV_TILE_OVERRIDE", "").split(",") if kv)}
 
-
-def _parse_wino_rule(text):
-    rule = {}
-    for item in text.split(","):
-        if item:
-            c, ds = item.split(":")
-            rule[int(c)] = None if ds == "*" else {int(v) for v in ds.split("/")}
-    return rule
-
-
-# Dilated Winograd convs work on phase-major tensors written / read by the neighbouring activation launches
-# (contiguous runs instead of stride-d access); FH_WINO_PM=0 keeps the plain layout.
-_WINO_PM = os.environ.get("FH_WINO_PM", "1") != "0"
-# channel count -> dilations that run as Winograd below FH_WINO_MIN_C (measured with tools/wino_bench.py, B = 1)
-_WINO_RULE = _parse_wino_rule(os.environ.get("FH_WINO_RULE", "96:*,48:*" if _WINO_PM else "96:1/3,48:1"))
+# Residual-stack convs run as Winograd F(4,3) from this many channels on, and at the narrower widths where it measured
+# faster (tools/wino_bench.py, B = 1; the dilated ones work on phase-major tensors)
+WINO_MIN_C = 192
+WINO_NARROW = (96, 48)
+# transposed convs run as Winograd phase groups from this many INPUT channels on (366 -> 207 us for 1536 -> 768
+# channels at B = 1, a wash at 768 -> 384, slower below: one-tap-group blocks pay the per-chunk slab cost every step)
+WINO_UPS_MIN_CIN = 768
+WINO_DESC_TAIL = 128          # zeroed bytes behind every Winograd descriptor array (work-list cursors of tools/exp builds)
 
 
 def use_wino(c, d):
-    """Residual-stack convs [c -> c, dilation d] that run as Winograd F(4,3) (conv_wino.hip) instead of the
-    direct implicit GEMM: where it measured faster (tools/wino_bench.py), i.e. for c >= FH_WINO_MIN_C (default
-    192) at every dilation and for the (c, d) pairs of FH_WINO_RULE (default "96:*,48:*"; without the phase-major
-    layout, FH_WINO_PM=0, the dilated convs of the narrow stages lose to stride-d access: "96:1/3,48:1").
-    FH_WINO=0 switches the path off."""
-    if os.environ.get("FH_WINO", "1") == "0" or c % 16:
-        return False
-    if c >= int(os.environ.get("FH_WINO_MIN_C", "192")):
-        return True
-    return c in _WINO_RULE and (_WINO_RULE[c] is None or d in _WINO_RULE[c])
+    """Residual-stack convs [c -> c, dilation d] that run as Winograd F(4,3) (conv_wino.hip) instead of the direct
+    implicit GEMM: c a multiple of 16 and >= WINO_MIN_C or one of WINO_NARROW, at every dilation (a dilated conv works
+    on phase-major tensors written / read by the neighbouring activation launches: contiguous runs instead of stride-d
+    access).  FH_WINO=0 switches the path off (direct kernel everywhere: parity debugging)."""
+    return os.environ.get("FH_WINO", "1") != "0" and c % 16 == 0 and (c >= WINO_MIN_C or c in WINO_NARROW)
 
 
 def pick_tile_cfg(cout):
@@ -146,10 +131,6 @@ def make_act_group(x, y, p):
 
 
 
-# launches with fewer 64 x 256 blocks than this use the 32 x 256 tile (latency of short clips)
-_WINO_SMALL_BLOCKS = int(os.environ.get("FH_WINO_SMALL_BLOCKS", "160"))
-# stage-closing conv (3 K segments in one group): fused only when it yields at least this many blocks
-_WINO_FUSE_MIN_BLOCKS = int(os.environ.get("FH_WINO_FUSE_MIN_BLOCKS", "200"))
 # Winograd tiles (tile_cfg -> rows x outputs) and their measured block time on one CU: _WINO_COST[cfg] = (a, b),
 # a us per K step (16 input channels x one tap group), b us of prologue + epilogue (tools/wino_cfg_sweep.py)
 _WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256)}
@@ -158,9 +139,8 @@ _WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.
 # double the weight bytes a block streams: beyond this panel size (6 x 128 rows x K, bytes) a chip full of
 # such blocks thrashes the 4 MB L2s (C = 768: 857 us against 732 us with 64 x 512 tiles)
 _WINO_WIDE_PANEL_MAX = 6 * 2 ** 20
-_WINO_TILES_OFF = {int(v) for v in os.environ.get("FH_WINO_TILES_OFF", "").split(",") if v}    # (A/B experiments)
+_WINO_TILES_OFF = set()            # (A/B experiments: tools add tile ids here before the first plan)
 _WINO_RUN = 8                      # W_RUN of conv_wino.hip
-_WINO_AUTO = os.environ.get("FH_WINO_AUTO", "1") == "1"
 
 
 # K-loop time per step of the bf16 x 6 form relative to the fp32 form, per tile shape (tools/wino_cost_fit.py:
@@ -295,7 +275,7 @@ def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg, bf=False):
     (cin / 16 x tap groups) each: more than one only where the batch-1 launch model says the blocks are too few and
     too long (clips under ~2 s); never a function of the batch size, so a clip gives the same bits alone and inside a
     batch.  FH_WINO_SPLITK=0 switches it off."""
-    if not _WINO_AUTO or os.environ.get("FH_WINO_SPLITK", "1") == "0":
+    if os.environ.get("FH_WINO_SPLITK", "1") == "0":
         return 1
     base = choose_wino_cfg(ksteps, 1, wpad, length, dil, default_cfg, bf)[1]
     best, n = base, 1
@@ -304,7 +284,7 @@ def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg, bf=False):
             continue
         cost = choose_wino_cfg([k // ns for k in ksteps for _ in range(ns)], 1, wpad, length, dil,
                                default_cfg, bf)[1] + 7.0 * len(ksteps)      # + the adds of the partial outputs
-        if cost < float(os.environ.get("FH_WINO_SPLIT_GAIN", "0.95")) * base and cost < best:
+        if cost < 0.95 * base and cost < best:     # (a slice must be estimated >= 5 % faster)
             best, n = cost, ns
     return n
 
@@ -373,7 +353,7 @@ def from_phase_major(xp, d, length):
 
 def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0, phase_major=False):
     """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
-    d = hip.to_device_struct_array(groups, device, int(os.environ.get('FH_DESC_TAIL', '0')))
+    d = hip.to_device_struct_array(groups, device, WINO_DESC_TAIL)
     hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
                                          int(phase_major), tile_cfg, hip.stream()), "fh_conv_wino_f32")
     return d
@@ -392,6 +372,304 @@ def act1d_grouped(groups, batch, channels, length, device, din=1, dout=1):
     hip.check(hip.lib().fh_act1d_grouped_pm_f32(d.data_ptr(), len(groups), batch, channels, length, din, dout,
                                                 hip.stream()), "fh_act1d_grouped_pm_f32")
     return d
+
+
+class _PlanBuilder:
+    """Builds the launch plan of one [batch, num_mels, n_frames] shape (Vocoder.plan): workspace pool, descriptor
+    arrays and the ordered list of launch steps.
+    steps[i] = (kind, ...) is what Vocoder._launch runs; meta[i] = (position key, host descriptor structs): the position
+    key names the step's place in the model -- (stage, sub-block, slot, index) -- so that the plans of different clips
+    can be merged launch by launch (Vocoder.plan_ragged) although their optional steps differ."""
+
+    def __init__(self, voc, batch, n_frames, ref_frames):
+        self.v, self.B, self.N = voc, batch, n_frames
+        self.f32 = dict(dtype=torch.float32, device=voc.device)
+        self.steps, self.meta, self.keep = [], [], []         # keep: tensors the descriptors point into
+        self.key = None                                       # position key of the steps being added
+        self.executed = 0.0     # FLOPs issued to the matrix cores by all conv launches (Winograd: 1.5 G / k of the algorithmic)
+        self.direct = 0.0       # ... of which by the direct-kernel launches
+        self.L = n_frames                                     # current stage length
+        self.Lref = ref_frames                                # ... of the whole clip (== L unless this plan is a chunk)
+        self.parts = None                                     # split-K partial outputs, allocated on first use
+        v = voc
+        dils = sorted({d for dl in v.dil for d in dl})
+        # (phase-major intermediates of the dilated convs are padded to d * phase_len >= L floats per row)
+        self.max_elems = max(st["c"] * max(d * phase_len(n_frames * math.prod(v.rates[:i + 1]), d) for d in dils + [1])
+                             for i, st in enumerate(v.stages))
+        self.mel_in = torch.empty(batch, v.num_mels, n_frames, **self.f32)
+        self.pool = torch.empty(2 + 4 * v.nk, batch * self.max_elems, **self.f32)
+        self.keep.append(self.pool)
+
+    # ---- step bookkeeping -------------------------------------------------------------------------------------
+    def at(self, *key):
+        self.key = key
+
+    def add(self, step, structs=None, key=None):
+        self.meta.append((key if key is not None else self.key, structs))
+        self.steps.append(step)
+
+    def parts_buffer(self):
+        if self.parts is None:
+            self.parts = torch.empty(2 * self.v.nk, self.B * self.max_elems, **self.f32)
+            self.keep.append(self.parts)
+        return self.parts
+
+    # ---- one launch each ----------------------------------------------------------------------------------------
+    def conv(self, groups, cpad, n_len, tcfg, ck):
+        """Direct-kernel launch.  Few-block launches (first-stage upsampler, fused stage-closing conv at short
+        sequence lengths) switch from the 128 x 128 to the 128 x 64 tile to fill the 256 CUs."""
+        if tcfg == 0 and len(groups) * self.B * (cpad // 128) * -(-n_len // 128) < 512:
+            tcfg = 5
+        d = hip.to_device_struct_array(groups, self.v.device)
+        self.keep.append(d)
+        flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * self.B for g in groups for i in range(g.nseg))
+        self.executed += flops
+        self.direct += flops
+        self.add(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops), groups)
+
+    def wino(self, groups, wpad, length, dil, wcfg, pm=False, flops=None, batch=None):
+        """Winograd launch; the tile shape is the launch model's (choose_wino_cfg).  batch: launches whose groups are
+        per batch item (input-channel slices) pass 1."""
+        B = self.B if batch is None else batch
+        wcfg, _ = choose_wino_cfg([sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg)) for g in groups],
+                                  B, wpad, length, dil, default=wcfg, bf=self.v.bf)
+        d = hip.to_device_struct_array(groups, self.v.device, WINO_DESC_TAIL)
+        self.keep.append(d)
+        if flops is None:
+            flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
+                        for g in groups for i in range(g.nseg))
+        # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
+        self.executed += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
+                             for g in groups for i in range(g.nseg))
+        self.add(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B), groups)
+
+    def act(self, groups, c, length, din=1, dout=1):
+        d = hip.to_device_struct_array(groups, self.v.device)
+        self.keep.append(d)
+        self.add(("act", d, len(groups), c, length, din, dout), groups)
+
+    def res_conv(self, st, ents, xs_in, ks, dil, outs, res, pm=False, defer_sum=False):
+        """One launch of the same conv position in the nk AMP blocks (one group per block) at the current stage
+        length.  Returns, per block, the tensors whose sum is the conv's output (more than one: input-channel slices
+        whose partial outputs the caller adds, defer_sum)."""
+        c, cpad, wpad, L, B = st["c"], st["cpad"], st["wpad"], self.L, self.B
+        biases = [e["b"] for e in ents]
+        all_wino = all("u" in e for e in ents)
+        nsplit = wino_split_k(ks, c, wpad, self.Lref, dil, st["wcfg"], self.v.bf) if all_wino else 1
+        if nsplit > 1:
+            # Short clips: a launch of a few dozen blocks is bound by the K loop of ONE block.  The input channels
+            # are cut into nsplit slices, one group each (first slice: bias and residual), and the partial
+            # outputs are added in a fixed order.  Decided from the clip length alone, so a clip gives the same
+            # bits alone and inside a batch; one group per batch item (a slice is not a whole [B, C, L] tensor).
+            parts = self.parts_buffer()
+            pitch = dil * phase_len(L, dil) if pm else L
+            cs = c // nsplit
+            addr = lambda t, b, ch: t.data_ptr() + 4 * (b * c + ch) * pitch
+            groups = []
+            for i, e in enumerate(ents):
+                for sl in range(nsplit):
+                    dst = outs[i] if sl == 0 else parts[2 * i + sl - 1]
+                    for b in range(B):
+                        seg = make_wino_seg(addr(xs_in[i], b, sl * cs), e["u"][sl * cs // 16:], cs, ks[i])
+                        groups.append(make_wino_group([seg], biases[i] if sl == 0 else None,
+                                                      [addr(r, b, 0) for r in res[i]] if sl == 0 else [],
+                                                      addr(dst, b, 0), c, wpad, L))
+            self.wino(groups, wpad, L, dil, st["wcfg"], pm, batch=1, flops=sum(2.0 * c * c * k * L * B for k in ks))
+            pieces = [[outs[i]] + [parts[2 * i + sl] for sl in range(nsplit - 1)] for i in range(len(ents))]
+            if not defer_sum:
+                for i in range(len(ents)):
+                    self.add(("sum", pieces[i], outs[i], B * c * pitch, 1.0), key=self.key[:2] + (self.key[2] + 1, i))
+            return pieces
+        if all_wino:
+            self.wino([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i])], biases[i], res[i], outs[i],
+                                       c, wpad, L) for i in range(len(ents))], wpad, L, dil, st["wcfg"], pm)
+        else:
+            groups = []
+            for i, e in enumerate(ents):
+                offs = [(t - (ks[i] - 1) // 2) * dil for t in range(ks[i])]
+                groups.append(make_conv_group([make_conv_seg(xs_in[i], e["w"], c, offs)], biases[i], res[i], outs[i],
+                                              c, cpad, L, L, L))
+            self.conv(groups, cpad, L, st["tile_cfg"], st["ck"])
+        return [[o] for o in outs]
+
+    def mixed_dilation_conv(self, st, order, ents, ks, ds, xs_in, outs, res):
+        """The nk convs of one position with DIFFERENT dilations: one direct launch, per-group tap offsets."""
+        c, cpad, L = st["c"], st["cpad"], self.L
+        self.conv([make_conv_group([make_conv_seg(xs_in[n], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])],
+                                   e["b"], res[n], outs[n], c, cpad, L, L, L)
+                   for n, (e, k, d) in enumerate(zip(ents, ks, ds))], cpad, L, st["tile_cfg"], st["ck"])
+
+    # ---- model sections -------------------------------------------------------------------------------------------
+    def conv_pre(self):
+        v, N = self.v, self.N
+        pre = torch.empty(self.B, v.c0, N, **self.f32)
+        self.keep.append(pre)       # descriptors hold raw pointers: every buffer they name must outlive the plan
+        self.at(-1, 0, 0, 0)
+        if v.pre_u is not None:
+            self.wino([make_wino_group([make_wino_seg(self.mel_in, v.pre_u, v.num_mels, 7)], v.pre_b, [], pre, v.c0,
+                                       v.pre_wpad, N)], v.pre_wpad, N, 1, v.pre_wcfg)
+        else:
+            k7 = [j - 3 for j in range(7)]
+            self.conv([make_conv_group([make_conv_seg(self.mel_in, v.pre_w, v.num_mels, k7)], v.pre_b, [], pre, v.c0,
+                                       v.pre_cpad, N, N, N)], v.pre_cpad, N, v.pre_cfg, v.pre_ck)
+        return pre
+
+    def enter_stage(self, i):
+        """Stage i: lengths and the views of the workspace pool (slot 0 = X: upsampled input, 1 = S: stage output,
+        then per AMP block j: 2 + 4 j = T1, 3 + 4 j = T2, 4 / 5 + 4 j = Y ping-pong)."""
+        v, st = self.v, self.v.stages[i]
+        self.lin, self.L = self.L, self.L * st["u"]
+        self.lin_ref, self.Lref = self.Lref, self.Lref * st["u"]
+        c, B, L = st["c"], self.B, self.L
+        view = lambda idx: self.pool[idx, :B * c * L].view(B, c, L)
+        self.X, self.S = view(0), view(1)
+        self.T1 = [view(2 + 4 * j) for j in range(v.nk)]
+        self.T2 = [view(3 + 4 * j) for j in range(v.nk)]
+        self.Y = [[view(4 + 4 * j), view(5 + 4 * j)] for j in range(v.nk)]
+        # heavy kernel sizes first (dispatch order == launch order of the panels)
+        self.order = sorted(range(v.nk), key=lambda j: -st["blocks"][j]["k"])
+
+    def upsampler(self, i, cur):
+        """ConvTranspose1d(cin -> c, stride u) as u output-phase groups: Winograd groups with strided stores for the
+        wide stages, direct-kernel groups otherwise."""
+        v, st, B = self.v, self.v.stages[i], self.B
+        c, u, lin, L, X = st["c"], st["u"], self.lin, self.L, self.X
+        self.at(i, -1, 0, 0)
+        if st["up_wino"] is None:
+            self.conv([make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X, c,
+                                       st["cpad"], lin, L, lin, stride=u, phase=r)
+                       for r, ph in enumerate(st["up_phases"])], st["cpad"], lin, st["tile_cfg"], st["up_ck"])
+            return
+        up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
+        nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"], st["wpad"],
+                                  self.lin_ref, 1, st["wcfg"], v.bf)
+        if nsplit == 1:
+            self.wino([make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"])], st["up_b"], [], X,
+                                       c, st["wpad"], lin, stride=u, phase=r) for r, ph in enumerate(st["up_wino"])],
+                      st["wpad"], lin, 1, st["wcfg"], flops=up_flops)
+            return
+        parts = self.parts_buffer()             # short clips: input channels in slices, as in res_conv
+        cs = st["cin"] // nsplit
+        dsts = [X] + [parts[sl] for sl in range(nsplit - 1)]
+        groups = [make_wino_group([make_wino_seg(cur.data_ptr() + 4 * (b * st["cin"] + sl * cs) * lin,
+                                                 ph["u"][sl * cs // 16:], cs, ph["k"], ph["center"])],
+                                  st["up_b"] if sl == 0 else None, [], dsts[sl].data_ptr() + 4 * b * c * L,
+                                  c, st["wpad"], lin, stride=u, phase=r)
+                  for r, ph in enumerate(st["up_wino"]) for sl in range(nsplit) for b in range(B)]
+        self.wino(groups, st["wpad"], lin, 1, st["wcfg"], flops=up_flops, batch=1)
+        self.add(("sum", dsts, X, B * c * L, 1.0), key=(i, -1, 1, 0))
+
+    def amp1_stack(self, i):
+        """The nk AMPBlock1 of stage i (models.py:21-78), position by position: act -> conv1 (dilated) -> act -> conv2
+        (+ x) per dilation; the last conv2 closes the stage (closing_conv)."""
+        v, st = self.v, self.v.stages[i]
+        c, L, order = st["c"], self.L, self.order
+        T1, T2, Y = self.T1, self.T2, self.Y
+        xin = [self.X] * v.nk
+        blks = [st["blocks"][j] for j in order]
+        ks = [b_["k"] for b_ in blks]
+        for m in range(v.nm):
+            d1 = blks[0]["dil"][m]
+            same_d = all(b_["dil"][m] == d1 for b_ in blks)
+            # dilated Winograd conv: the activations on both sides write / read phase-major tensors
+            pm = same_d and 1 < d1 <= 16 and all("u" in b_["c1"][m] for b_ in blks)
+            dpm = d1 if pm else 1
+            self.at(i, m, 0, 0)
+            self.act([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L, dout=dpm)
+            self.at(i, m, 1, 0)
+            ents = [b_["c1"][m] for b_ in blks]
+            if same_d:
+                self.res_conv(st, ents, [T1[j] for j in order], ks, d1, [T2[j] for j in order], [[] for _ in blks], pm=pm)
+            else:
+                self.mixed_dilation_conv(st, order, ents, ks, [b_["dil"][m] for b_ in blks], [T1[j] for j in order],
+                                         [T2[j] for j in order], [[] for _ in blks])
+            self.at(i, m, 3, 0)
+            self.act([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L, din=dpm)
+            self.at(i, m, 4, 0)
+            ents = [b_["c2"][m] for b_ in blks]
+            if m < v.nm - 1:
+                self.res_conv(st, ents, [T1[j] for j in order], ks, 1, [Y[j][m % 2] for j in order],
+                              [[xin[j]] for j in order])
+                xin = [Y[j][m % 2] for j in range(v.nk)]
+            else:
+                self.closing_conv(i, m, ents, ks, [1] * v.nk, xin)
+
+    def amp2_stack(self, i):
+        """The nk AMPBlock2 of stage i (models.py:81-121): one activation + one conv (+ x) per dilation; the last one
+        closes the stage."""
+        v, st = self.v, self.v.stages[i]
+        c, L, order = st["c"], self.L, self.order
+        T1, Y = self.T1, self.Y
+        xin = [self.X] * v.nk
+        blks = [st["blocks"][j] for j in order]
+        ks = [b_["k"] for b_ in blks]
+        for m in range(v.nm):
+            ents = [b_["c1"][m] for b_ in blks]
+            ds = [b_["dil"][m] for b_ in blks]
+            self.at(i, m, 0, 0)
+            self.act([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][m]) for j in order], c, L)
+            self.at(i, m, 1, 0)
+            if m == v.nm - 1 and all("w" in e for e in ents):
+                self.closing_conv(i, m, ents, ks, ds, xin)          # direct kernel: K segments of one group
+                continue
+            outs = [Y[j][m % 2] for j in order]
+            if all(d == ds[0] for d in ds):
+                self.res_conv(st, ents, [T1[j] for j in order], ks, ds[0], outs, [[xin[j]] for j in order])
+            else:
+                self.mixed_dilation_conv(st, order, ents, ks, ds, [T1[j] for j in order], outs, [[xin[j]] for j in order])
+            xin = [Y[j][m % 2] for j in range(v.nk)]
+            if m == v.nm - 1:            # xs / num_kernels, block order = the reference's xs += order
+                self.add(("mean", xin[0], xin[1], xin[2] if v.nk == 3 else None, self.S, self.B * c * L, 1.0 / v.nk),
+                         key=(i, m, 6, 0))
+
+    def closing_conv(self, i, m, ents, ks, ds, xin):
+        """The stage-closing conv position: xs = sum over blocks of (conv(T1_j) + x_j); S = xs / num_kernels
+        (models.py:181-187).  Fused form: ONE group with nk K segments, the blocks are summed in the accumulator and
+        / nk is the epilogue scale.  Unfused form: nk groups (more blocks for the 256 CUs) + one averaging pass; whichever
+        the launch model says is faster for ONE clip of the whole clip's length (the two forms round differently, and a
+        clip must give the same bits alone, inside a batch and in chunks)."""
+        v, st = self.v, self.v.stages[i]
+        c, cpad, wpad, L, B, order = st["c"], st["cpad"], st["wpad"], self.L, self.B, self.order
+        T1, Y, S = self.T1, self.Y, self.S
+        scale = 1.0 / v.nk
+        if all("u" in e for e in ents):
+            ksteps = [c // 16 * -(-k // 3) for k in ks]
+            Lr = self.Lref
+            unfuse = v.nk in (2, 3) and (choose_wino_cfg(ksteps, 1, wpad, Lr, 1, st["wcfg"], v.bf)[1] + 4.0 + c * Lr * 16 / 4.0e6
+                                         < choose_wino_cfg([sum(ksteps)], 1, wpad, Lr, 1, st["wcfg"], v.bf)[1])
+            if not unfuse:
+                segs = [make_wino_seg(T1[j], e["u"], c, k) for j, e, k in zip(order, ents, ks)]
+                self.wino([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, wpad, L, scale=scale)],
+                          wpad, L, 1, st["wcfg"])
+                return
+            pieces = self.res_conv(st, ents, [T1[j] for j in order], ks, 1, [Y[j][m % 2] for j in order],
+                                   [[xin[j]] for j in order], defer_sum=True)
+            if len(pieces[0]) > 1:                              # input-channel slices: all partial outputs in one pass
+                by_block = {j: pieces[n_] for n_, j in enumerate(order)}
+                self.add(("sum", [t for j in range(v.nk) for t in by_block[j]], S, B * c * L, scale), key=(i, m, 6, 0))
+            else:
+                ys = [Y[j][m % 2] for j in range(v.nk)]         # block order = the reference's xs += order
+                self.add(("mean", ys[0], ys[1], ys[2] if v.nk == 3 else None, S, B * c * L, scale), key=(i, m, 6, 0))
+            return
+        segs = [make_conv_seg(T1[j], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])
+                for j, e, k, d in zip(order, ents, ks, ds)]
+        self.conv([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L, scale=scale)],
+                  cpad, L, st["tile_cfg"], st["ck"])
+
+    def finish(self, cur):
+        """activation_post + conv_post + tanh, and the plan record."""
+        v, B, L = self.v, self.B, self.L
+        c_last = v.stages[-1]["c"]
+        post_t = self.pool[2, :B * c_last * L].view(B, c_last, L)
+        self.at(99, 0, 0, 0)
+        self.act([make_act_group(cur, post_t, v.post_act)], c_last, L)
+        wav = torch.empty(B, L, **self.f32)
+        self.add(("post", post_t, wav, c_last, L), key=(99, 0, 1, 0))
+        # algorithmic HBM bytes of the Activation1d launches: every site reads and writes its [B, C, L] tensor once
+        act_bytes = sum(8.0 * s_[2] * B * s_[3] * s_[4] for s_ in self.steps if s_[0] == "act")
+        return dict(steps=self.steps, meta=self.meta, keep=self.keep, mel_in=self.mel_in, wav=wav, B=B, N=self.N, L=L,
+                    conv_executed_flops=self.executed, conv_direct_flops=self.direct, act_bytes=act_bytes,
+                    n_act=sum(s_[0] == "act" for s_ in self.steps))
 
 
 class Vocoder:
@@ -454,8 +732,7 @@ class Vocoder:
         self.pre_b = g("conv_pre.bias").to(dev)
         # conv_pre (num_mels -> c0, 7 taps) in Winograd form as well when the shapes fit
         self.pre_u = None
-        if os.environ.get("FH_WINO_PRE", "1") != "0" and use_wino(self.c0, 1) and self.num_mels % 16 == 0 \
-                and self.c0 % 64 == 0:
+        if use_wino(self.c0, 1) and self.num_mels % 16 == 0 and self.c0 % 64 == 0:
             self.pre_wcfg, self.pre_wpad = pick_wino_tile(self.c0)
             self.pre_u = pack_wino_weight_any(g("conv_pre.weight"), self.pre_wpad, self.bf).to(dev)
         self.stages = []
@@ -474,10 +751,7 @@ class Vocoder:
                                             offs=[o for _, o in taps]))
             # the same transposed conv as Winograd phase groups (strided output) where the tile shapes fit
             st["up_wino"] = None
-            # (measured at B = 1: 366 -> 207 us for 1536 -> 768 channels, a wash at 768 -> 384, slower below: the
-            # one-tap-group blocks pay the per-chunk slab cost on every step)
-            if use_wino(max(c, 48), 1) and c % 16 == 0 and c >= 48 and st["cin"] % 16 == 0 \
-                    and st["cin"] >= int(os.environ.get("FH_WINO_UPS_MIN_CIN", "768")):
+            if use_wino(max(c, 48), 1) and c % 16 == 0 and c >= 48 and st["cin"] % 16 == 0 and st["cin"] >= WINO_UPS_MIN_CIN:
                 st["up_wino"] = []
                 for taps in transposed_conv_phases(k, u):
                     wph, center = wino_phase_weight(wt, taps)
@@ -526,8 +800,6 @@ class Vocoder:
         self._ragged = hip.ShapeCache()
         self.conv_timing = None
         self.act_timing = None
-        self.chain_streams = os.environ.get("FH_VOCODER_STREAMS", "0") == "1"
-        self._side = None
 
     def conv_flops_per_frame(self):
         """Algorithmic FLOPs of the MFMA conv launches per mel frame (SURVEY.md 8d formula:
@@ -552,326 +824,17 @@ class Vocoder:
             key = (batch, n_frames, "inst", inst, ref_frames)
         if key in self._plans:
             return self._plans[key]
-        dev = self.device
-        B, N = batch, n_frames
-        B_ = B
-        f32 = dict(dtype=torch.float32, device=dev)
-        # (kind, device descriptor tensor, n_groups, args...); meta[i] = (position key, host descriptor structs) of
-        # steps[i]: the position key names the step's place in the model -- (stage, sub-block, slot, index) -- so that
-        # the plans of different clips can be merged launch by launch (plan_ragged) although their optional steps differ
-        steps, meta, kk = [], [], [None]
-
-        def at(*key):
-            kk[0] = key
-
-        class _Steps(list):
-            def append(self_, step, structs=None, key=None):
-                meta.append((key if key is not None else kk[0], structs))
-                list.append(self_, step)
-        steps = _Steps()
-        executed = [0.0]    # FLOPs issued to the matrix cores by all conv launches (Winograd: 1.5 G / k of the algorithmic)
-        direct = [0.0]      # ... of which by the direct-kernel launches
-        keep = []           # tensors that must stay alive
-        L = N
-
-        def conv_step(groups, cpad, n_len, tcfg, ck, sink=None):
-            # few-block launches (first-stage upsampler, fused stage-closing conv at short
-            # sequence lengths) switch from the 128x128 to the 128x64 tile to fill the 256 CUs
-            if tcfg == 0 and len(groups) * B * (cpad // 128) * -(-n_len // 128) < 512:
-                tcfg = 5
-            tcfg = _TILE_OVERRIDE.get(tcfg, tcfg)
-            d = hip.to_device_struct_array(groups, dev)
-            keep.append(d)
-            flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * B
-                        for g in groups for i in range(g.nseg))
-            executed[0] += flops
-            direct[0] += flops
-            if sink is not None:
-                sink.append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops))
+        pb = _PlanBuilder(self, batch, n_frames, ref_frames)
+        cur = pb.conv_pre()
+        for i in range(len(self.stages)):
+            pb.enter_stage(i)
+            pb.upsampler(i, cur)
+            if self.resblock == "1":
+                pb.amp1_stack(i)
             else:
-                steps.append(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops), groups)
-
-        def wino_step(groups, wpad, length, dil, wcfg, sink=None, pm=False, flops=None, batch=None):
-            B = B_ if batch is None else batch          # (split-K launches carry one group per batch item)
-            if _WINO_AUTO and wcfg in (0, 1, 4, 5):
-                wcfg, _ = choose_wino_cfg([sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg))
-                                           for g in groups], B, wpad, length, dil, default=wcfg, bf=self.bf)
-            elif wcfg in (0, 4) and B * len(groups) * (wpad // WINO_BM) * -(-length // 256) < _WINO_SMALL_BLOCKS:
-                wcfg = 5            # short clips: 32 x 256 tiles, 2-4x the blocks, each with a 2-4x shorter K loop
-            if not _WINO_AUTO and wcfg == 0 and B * len(groups) * (wpad // WINO_BM) * -(-length // 512) < 200:
-                wcfg = 4            # too few 512-wide blocks for 256 CUs (first-stage upsampler at batch 1)
-            if not _WINO_AUTO and wcfg == 0:
-                # 64 x 512-output blocks work on one dilation phase each: a short phase (L / d) can leave the last
-                # block mostly empty; the 64 x 256 tile (cfg 4, ~10 % slower per output) then wins
-                lp_ = -(-length // dil)
-                if 1.10 * (-(-lp_ // 256) * 256) < -(-lp_ // 512) * 512:
-                    wcfg = 4
-            d = hip.to_device_struct_array(groups, dev)
-            keep.append(d)
-            if flops is None:
-                flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
-                            for g in groups for i in range(g.nseg))
-            # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
-            executed[0] += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
-                               for g in groups for i in range(g.nseg))
-            if sink is not None:
-                sink.append(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B))
-            else:
-                steps.append(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B), groups)
-
-        parts = []                  # split-K partial outputs, allocated by the first launch that needs them
-
-        ref = dict(L=ref_frames)      # stage length of the whole clip (== L unless this plan is a chunk of a longer clip)
-
-        def res_conv(ents, xs_in, ks, dil, outs, biases, res, c, cpad, wpad, L, tcfg, ck, sink=None, wcfg=0, pm=False,
-                     split=True, defer_sum=False):
-            """One launch of the same conv position in the nk AMP blocks (one group per block).  Returns, per
-            block, the tensors whose sum is the conv's output (more than one: split-K partial outputs that the
-            caller adds, defer_sum)."""
-            nsplit = wino_split_k(ks, c, wpad, ref["L"], dil, wcfg, self.bf) if split and sink is None and all("u" in e for e in ents) else 1
-            if nsplit > 1:
-                # Short clips: a launch of a few dozen blocks is bound by the K loop of ONE block.  The input channels
-                # are cut into nsplit slices, one group each (first slice: bias and residual), and the partial
-                # outputs are added in a fixed order.  Decided from the clip length alone, so a clip gives the same
-                # bits alone and inside a batch; one group per batch item (a slice is not a whole [B, C, L] tensor).
-                if not parts:
-                    parts.append(torch.empty(2 * self.nk, B_ * max_elems, **f32))
-                    keep.append(parts[0])
-                pitch = dil * phase_len(L, dil) if pm else L
-                cs = c // nsplit
-                at = lambda t, b, ch: t.data_ptr() + 4 * (b * c + ch) * pitch
-                groups = []
-                for i, e in enumerate(ents):
-                    for sl in range(nsplit):
-                        dst = outs[i] if sl == 0 else parts[0][2 * i + sl - 1]
-                        for b in range(B_):
-                            seg = make_wino_seg(at(xs_in[i], b, sl * cs), e["u"][sl * cs // 16:], cs, ks[i])
-                            groups.append(make_wino_group([seg], biases[i] if sl == 0 else None,
-                                                          [at(r, b, 0) for r in res[i]] if sl == 0 else [],
-                                                          at(dst, b, 0), c, wpad, L))
-                wino_step(groups, wpad, L, dil, wcfg, None, pm, batch=1,
-                          flops=sum(2.0 * c * c * k * L * B_ for k in ks))
-                pieces = [[outs[i]] + [parts[0][2 * i + sl] for sl in range(nsplit - 1)] for i in range(len(ents))]
-                if not defer_sum:
-                    for i in range(len(ents)):
-                        steps.append(("sum", pieces[i], outs[i], B_ * c * pitch, 1.0),
-                                     key=kk[0][:2] + (kk[0][2] + 1, i))
-                return pieces
-            elif all("u" in e for e in ents):
-                wino_step([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i])], biases[i],
-                                           res[i], outs[i], c, wpad, L) for i in range(len(ents))],
-                          wpad, L, dil, wcfg, sink, pm)
-            else:
-                groups = []
-                for i, e in enumerate(ents):
-                    offs = [(t - (ks[i] - 1) // 2) * dil for t in range(ks[i])]
-                    groups.append(make_conv_group([make_conv_seg(xs_in[i], e["w"], c, offs)], biases[i], res[i],
-                                                  outs[i], c, cpad, L, L, L))
-                conv_step(groups, cpad, L, tcfg, ck, sink)
-            return [[o] for o in outs]
-
-        def act_step(groups, c, length, sink=None, din=1, dout=1):
-            d = hip.to_device_struct_array(groups, dev)
-            keep.append(d)
-            if sink is not None:
-                sink.append(("act", d, len(groups), c, length, din, dout))
-            else:
-                steps.append(("act", d, len(groups), c, length, din, dout), groups)
-
-        mel_in = torch.empty(B, self.num_mels, N, **f32)
-        pre = torch.empty(B, self.c0, N, **f32)
-        keep.append(pre)            # descriptors hold raw pointers: every buffer they name must outlive the plan
-        k7 = [j - 3 for j in range(7)]
-        at(-1, 0, 0, 0)
-        if self.pre_u is not None:
-            wino_step([make_wino_group([make_wino_seg(mel_in, self.pre_u, self.num_mels, 7)], self.pre_b, [], pre,
-                                       self.c0, self.pre_wpad, N)], self.pre_wpad, N, 1, self.pre_wcfg)
-        else:
-            conv_step([make_conv_group([make_conv_seg(mel_in, self.pre_w, self.num_mels, k7)], self.pre_b, [],
-                                        pre, self.c0, self.pre_cpad, N, N, N)], self.pre_cpad, N, self.pre_cfg, self.pre_ck)
-        cur = pre
-        dils = sorted({d for dl in self.dil for d in dl})
-        # (phase-major intermediates of the dilated convs are padded to d * phase_len >= L floats per row)
-        max_elems = max(st["c"] * max(d * phase_len(N * math.prod(self.rates[:i + 1]), d) for d in dils + [1])
-                        for i, st in enumerate(self.stages))
-        nbuf = 2 + 4 * self.nk
-        pool = torch.empty(nbuf, B * max_elems, **f32)
-        keep.append(pool)
-        for i, st in enumerate(self.stages):
-            c, u, cpad, tcfg = st["c"], st["u"], st["cpad"], st["tile_cfg"]
-            lin, L = L, L * u
-            lin_ref, ref["L"] = ref["L"], ref["L"] * u
-            view = lambda idx: pool[idx, :B * c * L].view(B, c, L)
-            X = view(0)
-            S = view(1)
-            at(i, -1, 0, 0)
-            if st["up_wino"] is not None:
-                up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
-                nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"],
-                                          st["wpad"], lin_ref, 1, st["wcfg"], self.bf)
-                if nsplit > 1:              # short clips: input channels in slices, as in res_conv
-                    if not parts:
-                        parts.append(torch.empty(2 * self.nk, B * max_elems, **f32))
-                        keep.append(parts[0])
-                    cs = st["cin"] // nsplit
-                    dsts = [X] + [parts[0][sl] for sl in range(nsplit - 1)]
-                    groups = [make_wino_group([make_wino_seg(cur.data_ptr() + 4 * (b * st["cin"] + sl * cs) * lin,
-                                                             ph["u"][sl * cs // 16:], cs, ph["k"], ph["center"])],
-                                              st["up_b"] if sl == 0 else None, [], dsts[sl].data_ptr() + 4 * b * c * L,
-                                              c, st["wpad"], lin, stride=u, phase=r)
-                              for r, ph in enumerate(st["up_wino"]) for sl in range(nsplit) for b in range(B)]
-                    wino_step(groups, st["wpad"], lin, 1, st["wcfg"], flops=up_flops, batch=1)
-                    steps.append(("sum", dsts, X, B * c * L, 1.0), key=(i, -1, 1, 0))
-                else:
-                    groups = [make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"])], st["up_b"],
-                                              [], X, c, st["wpad"], lin, stride=u, phase=r)
-                              for r, ph in enumerate(st["up_wino"])]
-                    wino_step(groups, st["wpad"], lin, 1, st["wcfg"], flops=up_flops)
-            else:
-                groups = [make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X,
-                                           c, cpad, lin, L, lin, stride=u, phase=r)
-                          for r, ph in enumerate(st["up_phases"])]
-                conv_step(groups, cpad, lin, tcfg, st["up_ck"])
-            # heavy kernel sizes first (dispatch order == launch order of the panels)
-            order = sorted(range(self.nk), key=lambda j: -st["blocks"][j]["k"])
-            T1 = [view(2 + 4 * j) for j in range(self.nk)]
-            T2 = [view(3 + 4 * j) for j in range(self.nk)]
-            Y = [[view(4 + 4 * j), view(5 + 4 * j)] for j in range(self.nk)]
-            xin = [X] * self.nk
-            chains = [[] for _ in range(self.nk)] if self.chain_streams and self.resblock == "1" else None
-            for m in range(self.nm if self.resblock == "2" else 0):
-                # AMPBlock2: one activation + one conv (+ x) per dilation; the last one closes the stage
-                blks = [st["blocks"][j] for j in order]
-                ents = [b_["c1"][m] for b_ in blks]
-                ks = [b_["k"] for b_ in blks]
-                ds = [b_["dil"][m] for b_ in blks]
-                at(i, m, 0, 0)
-                act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][m]) for j in order], c, L)
-                at(i, m, 1, 0)
-                if m < self.nm - 1 or not all("w" in e for e in ents):
-                    outs = [Y[j][m % 2] for j in order]
-                    if all(d == ds[0] for d in ds):
-                        res_conv(ents, [T1[j] for j in order], ks, ds[0], outs, [e["b"] for e in ents],
-                                 [[xin[j]] for j in order], c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
-                    else:               # mixed dilations: direct kernel, per-group tap offsets
-                        conv_step([make_conv_group([make_conv_seg(T1[j], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])],
-                                                   e["b"], [xin[j]], Y[j][m % 2], c, cpad, L, L, L)
-                                   for j, e, k, d in zip(order, ents, ks, ds)], cpad, L, tcfg, st["ck"])
-                    xin = [Y[j][m % 2] for j in range(self.nk)]
-                    if m == self.nm - 1:            # xs / num_kernels, block order = the reference's xs += order
-                        steps.append(("mean", xin[0], xin[1], xin[2] if self.nk == 3 else None, S, B * c * L,
-                                      1.0 / self.nk), key=(i, m, 6, 0))
-                else:                   # direct kernel: the nk closing convs as K segments of one group, / nk in the epilogue
-                    segs = [make_conv_seg(T1[j], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])
-                            for j, e, k, d in zip(order, ents, ks, ds)]
-                    conv_step([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L,
-                                                scale=1.0 / self.nk)], cpad, L, tcfg, st["ck"])
-            for m in range(self.nm if self.resblock == "1" else 0):
-                last = m == self.nm - 1
-                if chains is not None:
-                    # one launch sequence per AMP block, each on its own stream (run()): the three
-                    # chains are independent until the stage-closing conv, so the tail of one chain's
-                    # conv overlaps the others' kernels instead of idling the chip
-                    for j in order:
-                        blk = st["blocks"][j]
-                        k, d = blk["k"], blk["dil"][m]
-                        act_step([make_act_group(xin[j], T1[j], blk["acts"][2 * m])], c, L, chains[j])
-                        res_conv([blk["c1"][m]], [T1[j]], [k], d, [T2[j]], [blk["c1"][m]["b"]], [[]],
-                                 c, cpad, st["wpad"], L, tcfg, st["ck"], chains[j], wcfg=st["wcfg"])
-                        act_step([make_act_group(T2[j], T1[j], blk["acts"][2 * m + 1])], c, L, chains[j])
-                        if not last:
-                            res_conv([blk["c2"][m]], [T1[j]], [k], 1, [Y[j][m % 2]], [blk["c2"][m]["b"]], [[xin[j]]],
-                                     c, cpad, st["wpad"], L, tcfg, st["ck"], chains[j], wcfg=st["wcfg"])
-                    if not last:
-                        xin = [Y[j][m % 2] for j in range(self.nk)]
-                    else:
-                        steps.append(("fork", [chains[j] for j in order]))
-                else:
-                    blks = [st["blocks"][j] for j in order]
-                    d1 = blks[0]["dil"][m]
-                    same_d = all(b_["dil"][m] == d1 for b_ in blks)
-                    # dilated Winograd conv: the activations on both sides write / read phase-major tensors
-                    pm = _WINO_PM and same_d and d1 > 1 and all("u" in b_["c1"][m] for b_ in blks)
-                    dpm = d1 if pm else 1
-                    at(i, m, 0, 0)
-                    act_step([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L,
-                             dout=dpm)
-                    at(i, m, 1, 0)
-                    if same_d:
-                        res_conv([b_["c1"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], d1,
-                                 [T2[j] for j in order], [b_["c1"][m]["b"] for b_ in blks], [[] for _ in blks],
-                                 c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"], pm=pm)
-                    else:               # mixed dilations: one direct launch, per-group tap offsets
-                        groups = []
-                        for j in order:
-                            blk = st["blocks"][j]
-                            k, d = blk["k"], blk["dil"][m]
-                            offs = [(t - (k - 1) // 2) * d for t in range(k)]
-                            groups.append(make_conv_group([make_conv_seg(T1[j], blk["c1"][m]["w"], c, offs)],
-                                                           blk["c1"][m]["b"], [], T2[j], c, cpad, L, L, L))
-                        conv_step(groups, cpad, L, tcfg, st["ck"])
-                    at(i, m, 3, 0)
-                    act_step([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L,
-                             din=dpm)
-                    at(i, m, 4, 0)
-                    if not last:
-                        res_conv([b_["c2"][m] for b_ in blks], [T1[j] for j in order], [b_["k"] for b_ in blks], 1,
-                                 [Y[j][m % 2] for j in order], [b_["c2"][m]["b"] for b_ in blks],
-                                 [[xin[j]] for j in order], c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"])
-                        xin = [Y[j][m % 2] for j in range(self.nk)]
-                if last:
-                    at(i, m, 4, 0)
-                    ents = [st["blocks"][j]["c2"][m] for j in order]
-                    wbm, wbn = (96, 256) if st["wcfg"] & 1 else (64, 512)
-                    fused_blocks = B * (st["wpad"] // wbm) * -(-ref["L"] // wbn)
-                    unfuse = fused_blocks < _WINO_FUSE_MIN_BLOCKS
-                    if _WINO_AUTO and all("u" in e for e in ents):
-                        # one launch of nk groups + the averaging pass (4 streams of B c L floats) against one
-                        # group with nk K segments: whichever the launch model says fills the CUs better
-                        ks = [c // 16 * -(-st["blocks"][j]["k"] // 3) for j in order]
-                        # (for ONE clip, whatever the batch: the two forms round differently, and a clip must give
-                        # the same bits alone and inside a batch)
-                        Lr = ref["L"]
-                        unfuse = (choose_wino_cfg(ks, 1, st["wpad"], Lr, 1, st["wcfg"], self.bf)[1] + 4.0 + c * Lr * 16 / 4.0e6
-                                  < choose_wino_cfg([sum(ks)], 1, st["wpad"], Lr, 1, st["wcfg"], self.bf)[1])
-                    if all("u" in e for e in ents) and unfuse and self.nk in (2, 3):
-                        # one group = too few blocks for 256 CUs: run the nk convs as groups and average after
-                        pieces = res_conv(ents, [T1[j] for j in order], [st["blocks"][j]["k"] for j in order], 1,
-                                          [Y[j][m % 2] for j in order], [e["b"] for e in ents], [[xin[j]] for j in order],
-                                          c, cpad, st["wpad"], L, tcfg, st["ck"], wcfg=st["wcfg"], defer_sum=True)
-                        if len(pieces[0]) > 1:                              # split-K: all partial outputs in one pass
-                            by_block = {j: pieces[n_] for n_, j in enumerate(order)}
-                            steps.append(("sum", [t for j in range(self.nk) for t in by_block[j]], S, B * c * L,
-                                          1.0 / self.nk), key=(i, m, 6, 0))
-                        else:
-                            ys = [Y[j][m % 2] for j in range(self.nk)]      # block order = the reference's xs += order
-                            steps.append(("mean", ys[0], ys[1], ys[2] if self.nk == 3 else None, S, B * c * L,
-                                          1.0 / self.nk), key=(i, m, 6, 0))
-                    elif all("u" in e for e in ents):
-                        segs = [make_wino_seg(T1[j], st["blocks"][j]["c2"][m]["u"], c, st["blocks"][j]["k"]) for j in order]
-                        wino_step([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, st["wpad"], L,
-                                                   scale=1.0 / self.nk)], st["wpad"], L, 1, st["wcfg"])
-                    else:
-                        segs = []
-                        for j in order:
-                            blk = st["blocks"][j]
-                            k = blk["k"]
-                            segs.append(make_conv_seg(T1[j], blk["c2"][m]["w"], c, [t - (k - 1) // 2 for t in range(k)]))
-                        conv_step([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L,
-                                                    scale=1.0 / self.nk)], cpad, L, tcfg, st["ck"])
-            # Slot roles repeat every stage: the next up-conv reads S (slot 1) and writes the new X
-            # (slot 0); slot 1 is rewritten only by that stage's last launch, after its readers.
-            cur = S
-        c_last = self.stages[-1]["c"]
-        post_t = pool[2, :B * c_last * L].view(B, c_last, L)
-        at(99, 0, 0, 0)
-        act_step([make_act_group(cur, post_t, self.post_act)], c_last, L)
-        wav = torch.empty(B, L, **f32)
-        steps.append(("post", post_t, wav, c_last, L), key=(99, 0, 1, 0))
-        # algorithmic HBM bytes of the Activation1d launches: every site reads and writes its [B, C, L] tensor once
-        act_bytes = sum(8.0 * s_[2] * B * s_[3] * s_[4] for s_ in steps if s_[0] == "act")
-        p = dict(steps=list(steps), meta=meta, keep=keep, mel_in=mel_in, wav=wav, B=B, N=N, L=L, conv_executed_flops=executed[0],
-                 conv_direct_flops=direct[0], act_bytes=act_bytes, n_act=sum(s_[0] == "act" for s_ in steps))
+                pb.amp2_stack(i)
+            cur = pb.S                  # slot roles repeat every stage: the next up-conv reads S (slot 1), writes X (slot 0)
+        p = pb.finish(cur)
         self._plans[key] = p
         return p
 
@@ -888,8 +851,6 @@ class Vocoder:
         key = ("ragged",) + frames
         if key in self._ragged:
             return self._ragged[key]
-        if self.chain_streams:
-            raise NotImplementedError("ragged batches with FH_VOCODER_STREAMS=1")
         seen, subs = {}, []
         for n in frames:
             k = seen.get(n, 0)
@@ -931,14 +892,10 @@ class Vocoder:
                     maxlen = max(t[1] for t in allg)
                     default = max(lst, key=lambda t: t[0])[1]               # the longest clip's tile shape
                     wcfg = default
-                    if _WINO_AUTO and default in (0, 1, 4, 5):
+                    if default in (0, 1, 4, 5):
                         # the launch model takes one length: the mean one keeps the block count honest
                         mean_len = max(1, sum(t[1] for t in allg) // len(allg))
                         wcfg, _ = choose_wino_cfg([t[0] for t in allg], 1, wpad, mean_len, dil, default=default, bf=self.bf)
-                    if os.environ.get("FH_RAGGED_WCFG"):            # (A/B experiments)
-                        forced = int(os.environ["FH_RAGGED_WCFG"])
-                        if wpad % _WINO_TILES[forced][0] == 0:
-                            wcfg = forced
                     novl = 0 if (pm or all(t[1] % 4 == 0 for t in allg)) else 2
                     # runs (consecutive tiles of one (group, co tile) panel, dealt to one XCD) that hold real tiles
                     bm, bt = _WINO_TILES[wcfg]
@@ -1180,21 +1137,4 @@ class Vocoder:
 
     def _run_steps(self, steps, B, st):
         for s in steps:
-            if s[0] != "fork":
-                self._launch(s, B, st)
-                continue
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.nk)]
-                self._ev = [torch.cuda.Event() for _ in range(self.nk + 1)]
-            self._ev[0].record(main)
-            for j, chain in enumerate(s[1]):
-                side = self._side[j]
-                side.wait_event(self._ev[0])
-                with torch.cuda.stream(side):
-                    h = side.cuda_stream
-                    for cs in chain:
-                        self._launch(cs, B, h)
-                self._ev[j + 1].record(side)
-            for j in range(len(s[1])):
-                main.wait_event(self._ev[j + 1])
+            self._launch(s, B, st)

@@ -221,7 +221,7 @@ typedef struct {
 int fh_sizeof_act_group(void);
 int fh_act1d_grouped_f32(const fh_act_group* groups, int n_groups, int batch, int channels,
                          int len, void* stream);
-/* Same with phase-major tensors (fh_phase_len below): din / dout = dilation whose phase-major layout x / y
+/* Same with phase-major tensors (fh_phase_len below): din / dout = dilation (1 .. 16) whose phase-major layout x / y
  * use, 1 = plain [B, C, len].  Used on both sides of a dilated Winograd conv. */
 int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups, int batch, int channels, int len,
                             int din, int dout, void* stream);

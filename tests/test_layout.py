@@ -168,7 +168,6 @@ def test_split_k_is_for_short_clips_only(monkeypatch):
     C = 768), none for the 10 s headline shape; off with FH_WINO_SPLITK=0; never more slices than divide C / 16."""
     from flowhigh_amd import vocoder as V
     monkeypatch.delenv("FH_WINO_SPLITK", raising=False)
-    monkeypatch.delenv("FH_WINO_SPLIT_GAIN", raising=False)
     ks = [11, 7, 3]
     assert V.wino_split_k(ks, 768, 768, 250, 1, 0) == 3          # 0.5 s clip, first stage
     assert V.wino_split_k(ks, 768, 768, 500, 1, 0) >= 2          # 1 s

@@ -1020,7 +1020,7 @@ extern "C" int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int
   FH_CHECK_ARG(groups && n_groups > 0 && channels > 0 && total_tiles > 0 && total_tiles < (1ll << 31),
                "fh_act1d_ragged_f32: bad sizes");
   FH_CHECK_ARG(din >= 1 && dout >= 1 && din <= 64 && dout <= 64, "fh_act1d_ragged_f32: bad dilations %d / %d", din, dout);
-  if (din <= 16 && dout <= 16 && !getenv("FH_ACT_NO_STRIP")) {      // (row bytes < 2^31: checked by the host plan)
+  if (din <= 16 && dout <= 16) {      // (row bytes < 2^31: checked by the host plan)
     const long long strips = (total_tiles + ACT_NTILE - 1) / ACT_NTILE;
     const bool vec = all_len_mult4 != 0;
 #define FH_ACT_RLAUNCH(V, PI, PO)                                                                                       \

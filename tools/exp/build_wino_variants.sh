@@ -2,7 +2,7 @@
 # Experiment build of the library with the two rejected Winograd block shapes of round 3 compiled in as tiles 8 / 9:
 #   tools/exp/conv_wino2.hip  4-wave blocks, all six transform points of an output in one wave (A^T in registers)
 #   tools/exp/conv_wino3.hip  persistent 12-wave workgroups of two independent 6-wave teams
-# -> flowhigh_amd/lib/abl/winox.so.  Use: FH_LIB_PATH=flowhigh_amd/lib/abl/winox.so FH_DESC_TAIL=128 python tools/wino2_bench.py
+# -> flowhigh_amd/lib/abl/winox.so.  Use: FH_LIB_PATH=flowhigh_amd/lib/abl/winox.so python tools/wino2_bench.py
 # (both kernels are bit-identical to the product's tiles and slower: profiles/r03_wino_block_shapes.txt)
 set -e
 cd "$(dirname "$0")/../.."

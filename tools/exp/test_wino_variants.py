@@ -1,7 +1,7 @@
 """Bitwise comparison of the experimental Winograd block shapes (tile 8 = tools/exp/conv_wino2.hip, tile 9 =
 tools/exp/conv_wino3.hip) with the product's 64 x 256 tile.  Needs the experiment build:
     tools/exp/build_wino_variants.sh
-    FH_LIB_PATH=flowhigh_amd/lib/abl/winox.so FH_DESC_TAIL=128 python -m pytest tools/exp/test_wino_variants.py -q"""
+    FH_LIB_PATH=flowhigh_amd/lib/abl/winox.so python -m pytest tools/exp/test_wino_variants.py -q"""
 import sys
 from pathlib import Path
 
