@@ -39,4 +39,4 @@ for i, s in enumerate(convs):
         blocks = ng * B * (cpad // bm) * -(-n_len // bn)
     tot_f += fl; tot_t += acc[i]
     print(f"{i:3d} {('W' if s[0] == 'wino' else ' ')}{bm:>3}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
-print(f"total {tot_f/1e9:.1f} GFLOP {tot_t/1e3:.3f} ms {tot_f/tot_t/1e6:.1f} TF/s   (tile shapes changed by the plan-time measurement: {p.get('tuned', 0)})")
+print(f"total {tot_f/1e9:.1f} GFLOP {tot_t/1e3:.3f} ms {tot_f/tot_t/1e6:.1f} TF/s")
