@@ -234,6 +234,7 @@ def pack_wino_weight(w, cout_pad):
 
 
 WINO_BF16X6 = 16          # FH_WINO_BF16X6 of flowhigh_hip.h: tile_cfg flag, three-piece bf16 weights
+WINO_XCD_RANGES = 32      # FH_WINO_XCD_RANGES: tile_cfg flag, blocks -> XCDs by time range instead of by weight panel
 
 
 def use_bf16x6():
@@ -287,6 +288,30 @@ def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg, bf=False):
         if cost < 0.95 * base and cost < best:     # (a slice must be estimated >= 5 % faster)
             best, n = cost, ns
     return n
+
+
+def wino_block_mapping(groups, batch, wpad, length, dil, wcfg):
+    """WINO_XCD_RANGES or 0: which block -> XCD mapping reads less from HBM (tools/traffic_per_launch.py: at batch 1 the
+    launches of the 768 / 384 / 192-channel stages read 2.2-5.6 x their algorithmic bytes).  By weight panel (default):
+    a panel's weights are fetched ~once, but the co tiles of a group sit on up to 8 XCDs and each reads the group's
+    whole input: input x min(co tiles, 8), weights x min(runs per panel, 8).  By time range: the input is read once,
+    every XCD fetches all weights once per rectangle of time tiles: weights x 8 x rectangles.  Same bits either way; transposed-conv phase groups (strided outputs) keep the default."""
+    bm, bt = _WINO_TILES[wcfg]
+    n_tiles = -(-(-(-length // dil)) // bt) * dil
+    # (batch 1 only: with more batch items the by-panel blocks of different items already share a panel's weights through
+    # the L2, and the time-range order measured 4-6 % SLOWER at B = 8 and 32; at B = 1 it is neutral in time)
+    if batch > 1 or n_tiles < 16 or any(g.out_stride > 1 for g in groups):
+        return 0
+    weights = sum(g.seg[i].cin * g.seg[i].ngrp * 6 * wpad * 4.0 for g in groups for i in range(g.nseg))
+    inputs = sum(g.seg[i].cin * length * 4.0 * batch for g in groups for i in range(g.nseg))
+    co_tiles = wpad // bm
+    run_len = -(-n_tiles // -(-n_tiles // _WINO_RUN))
+    runs_per_panel = -(-n_tiles // run_len)             # (a panel's runs are dealt to different XCDs)
+    by_panel = weights * min(runs_per_panel, 8) + inputs * min(co_tiles, 8)
+    tpx = -(-n_tiles // 8)
+    rect = max(1, 32 // co_tiles)                       # time tiles of a rectangle (conv_wino.hip, xcd_ranges branch)
+    by_range = 8.0 * weights * -(-tpx // rect) + inputs
+    return WINO_XCD_RANGES if by_range < 0.9 * by_panel else 0
 
 
 def make_wino_seg(x, u, cin, k, center=None):
@@ -433,6 +458,7 @@ class _PlanBuilder:
         B = self.B if batch is None else batch
         wcfg, _ = choose_wino_cfg([sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg)) for g in groups],
                                   B, wpad, length, dil, default=wcfg, bf=self.v.bf)
+        wcfg |= wino_block_mapping(groups, B, wpad, length, dil, wcfg)
         d = hip.to_device_struct_array(groups, self.v.device, WINO_DESC_TAIL)
         self.keep.append(d)
         if flops is None:
@@ -890,7 +916,7 @@ class Vocoder:
                             for length, _, groups in lst for g in groups]
                     allg.sort(key=lambda t: (-t[0], -t[1]))                 # heavy groups first (dispatch order)
                     maxlen = max(t[1] for t in allg)
-                    default = max(lst, key=lambda t: t[0])[1]               # the longest clip's tile shape
+                    default = max(lst, key=lambda t: t[0])[1] & 15          # the longest clip's tile shape
                     wcfg = default
                     if default in (0, 1, 4, 5):
                         # the launch model takes one length: the mean one keeps the block count honest

@@ -148,6 +148,12 @@ int fh_phase_len(int len, int dilation);
  * products (dropped terms <= 2^-24 |a b|) at 0.375 of the matrix-pipe cycles.  Inputs, outputs and accumulation stay
  * float32; results differ from the fp32-MFMA form by rounding only. */
 #define FH_WINO_BF16X6 16
+/* tile_cfg | FH_WINO_XCD_RANGES: block -> work mapping by TIME instead of by weight panel: XCD x (block id mod 8) works on
+ * the x-th eighth of the time axis of every (group, batch, co tile) panel, the co tiles of the same time tiles next to
+ * each other in dispatch order.  The co tiles of a group then read their common input through one L2 while it is
+ * resident; every XCD fetches every weight panel.  For launches whose transformed weights are
+ * small beside their activations (C <= 384 at batch 1): less HBM traffic, same bits.  Ignored by the ragged entry. */
+#define FH_WINO_XCD_RANGES 32
 int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
                      int dilation, int phase_major, int tile_cfg, void* stream);
 /* Ragged form (clips of different lengths, one group per clip and AMP block, batch 1): the grid is laid out for

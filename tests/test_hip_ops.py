@@ -713,3 +713,27 @@ def test_resample_poly(sr_in):
     got = Resampler(DEV)(torch.from_numpy(x).to(DEV), sr_in)
     assert got.shape == ref.shape
     assert maxdiff(got, torch.from_numpy(ref)) <= 2e-6
+
+
+@pytest.mark.parametrize("wcfg,k,d,pm,L", [(0, 11, 1, False, 9000), (6, 7, 3, True, 9001), (1, 3, 5, True, 7000), (4, 7, 1, False, 4100)])
+def test_conv_wino_xcd_range_mapping_gives_the_same_bits(wcfg, k, d, pm, L):
+    """tile_cfg | FH_WINO_XCD_RANGES: blocks are dealt to the XCDs by eighths of the time axis instead of by weight
+    panel (less HBM traffic where the weights are small beside the activations): a different block -> work mapping
+    only, so the same bits; batch 2, residual, a length that is not a multiple of anything."""
+    c, B = 384, 2
+    x, w, b = rnd(B, c, L, seed=500), rnd(c, c, k, seed=501, scale=1.0 / (c * k) ** 0.5), rnd(c, seed=502)
+    r1 = rnd(B, c, L, seed=503)
+    conv = lambda t: (V.to_phase_major(t, d) if pm else t).to(DEV)
+    xd, rd = conv(x), conv(r1)
+    ud, bd = V.pack_wino_weight(w, c).to(DEV), b.to(DEV)
+    outs = []
+    for flag in (0, V.WINO_XCD_RANGES):
+        out = torch.full_like(xd, float("nan"))
+        g = V.make_wino_group([V.make_wino_seg(xd, ud, c, k)], bd, [rd], out, c, c, L)
+        keep = V.conv_wino([g], B, c, L, d, DEV, wcfg | flag, phase_major=pm)
+        torch.cuda.synchronize()
+        outs.append(V.from_phase_major(out.cpu(), d, L) if pm else out.cpu())
+        del keep
+    assert torch.equal(outs[0], outs[1])
+    ref = (F.conv1d(x.double(), w.double(), b.double(), dilation=d, padding=(k - 1) // 2 * d) + r1.double()).float()
+    assert maxdiff(outs[1], ref) <= 6e-5

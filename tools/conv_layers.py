@@ -1,14 +1,17 @@
 """Per-launch table of the vocoder's conv launches: tile, blocks, algorithmic GFLOP, us, TFLOP/s.
-Run on the GPU box: python tools/conv_layers.py [batch] [frames]"""
+Run on the GPU box: python tools/conv_layers.py [batch] [frames] [bypanel]"""
 import sys, torch
 sys.path.insert(0, '.')
 from flowhigh_amd import synth
+from flowhigh_amd import vocoder as V
 from flowhigh_amd.vocoder import Vocoder
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 TILES = {0: (128, 128), 1: (192, 128), 2: (96, 256), 3: (64, 256), 4: (32, 512), 5: (128, 64), 6: (96, 128)}
 cfg = synth.SYNTH_CFG
+if len(sys.argv) > 3 and sys.argv[3] == 'bypanel':         # A/B: every Winograd launch with the by-weight-panel block mapping
+    V.wino_block_mapping = lambda *a: 0
 voc = Vocoder(cfg, synth.make_state_dict(cfg, 0), 'cuda:0')
 p = voc.plan(B, N)
 mel = torch.randn(B, N, cfg["num_mels"], generator=torch.Generator().manual_seed(0)) * 2.0 - 3.0
@@ -31,12 +34,14 @@ print(f"{'#':>3} {'tile':>8} {'grp':>3} {'cpad':>5} {'n_len':>7} {'blocks':>6} {
 for i, s in enumerate(convs):
     if s[0] == 'wino':
         _, d, ng, cpad, n_len, dil, fl, wcfg, _pm = s[:9]
+        xr, wcfg = wcfg & 32, wcfg & 15
         bm, bn = (128, 256) if wcfg == 6 else (32, 256) if wcfg == 5 else (64, 256) if wcfg == 4 else (96, 256) if wcfg & 1 else (64, 512)
         blocks = ng * s[9] * (cpad // bm) * -(-(-(-n_len // dil)) // bn) * dil
     else:
+        xr = 0
         _, d, ng, cpad, n_len, tcfg, ck, fl = s
         bm, bn = TILES[tcfg]
         blocks = ng * B * (cpad // bm) * -(-n_len // bn)
     tot_f += fl; tot_t += acc[i]
-    print(f"{i:3d} {('W' if s[0] == 'wino' else ' ')}{bm:>3}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
+    print(f"{i:3d} {(('R' if xr else 'W') if s[0] == 'wino' else ' ')}{bm:>3}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
 print(f"total {tot_f/1e9:.1f} GFLOP {tot_t/1e3:.3f} ms {tot_f/tot_t/1e6:.1f} TF/s")
