@@ -34,6 +34,9 @@ WINO_S2 = ('''      if constexpr (VL) {
           if (GC == 1) vl_store(Ss, xbuf ^ 1, sub, 0, 0);''')
 WINO_S3 = ('''      if (has_next && sub == SUBS - 1) {                 // end of a slab: one barrier per SUBS chunks''',
            '''      if (false) {''')
+WINO_E = ('''      if (eact) {
+        const float* er = E + (eth * 6 * 32 + ecol) * W_EP + 4 * erq;''', '''      if (eact && tid == 12345) {                 // ablation: no epilogue reads / arithmetic / stores (the exchange writes stay)
+        const float* er = E + (eth * 6 * 32 + ecol) * W_EP + 4 * erq;''')
 ACT_SIN = ('''        s2[r] = sin_squared2(arg[r]);
         amax = fmaxf(amax, fmaxf(fabsf(arg[r][0]), fabsf(arg[r][1])));     // (NaN falls through, as sinf(NaN))''',
            '''        s2[r] = arg[r];                            // ablation: no sin^2''')
@@ -53,6 +56,9 @@ RECIPES = {
     "wino_notransform": ("conv_wino.hip", [WINO_T]),
     "wino_noweights": ("conv_wino.hip", [WINO_A]),
     "wino_noslab": ("conv_wino.hip", [WINO_S1, WINO_S2, WINO_S3]),
+    "wino_noslab_noweights": ("conv_wino.hip", [WINO_A, WINO_S1, WINO_S2, WINO_S3]),
+    "wino_mfma_lds_only": ("conv_wino.hip", [WINO_T, WINO_A, WINO_S1, WINO_S2, WINO_S3]),
+    "wino_noepilogue": ("conv_wino.hip", [WINO_E]),
     "act_nosin": ("act1d.hip", [ACT_SIN]),
     "act_noup": ("act1d.hip", [ACT_UP]),
     "act_nodown": ("act1d.hip", [ACT_DOWN]),

@@ -8,6 +8,8 @@
 //   B: a block barrier every 16 iterations (one per chunk of 4 tap groups)
 //   H: a 16-byte global load per 8 iterations from a 1 GB buffer, every wave its own stream: ~1.4 TB/s of HBM reads
 //   W: a 16-byte global store per 16 iterations to a 1 GB buffer: ~0.7 TB/s of HBM writes
+//   S: 8 ds_write_b64 per 16 iterations (the slab staging of one chunk of 4 tap groups)
+//   P: the weight loads walk a 64 MB buffer shared by all blocks instead of an L2-resident 4 KB tile (L2 misses to the Infinity Cache)
 //   hipcc -O3 --offload-arch=gfx950 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip && tools/micro/mfma_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,7 +22,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int MASK>
 __global__ __launch_bounds__(768) void mix_loop(const float* __restrict__ in, float* out, unsigned long long* clk, int iters,
                                                  const f32x4* __restrict__ big, f32x4* __restrict__ bigw) {
-  constexpr bool L = MASK & 1, V = MASK & 2, G = MASK & 4, B = MASK & 8, H = MASK & 16, W = MASK & 32;
+  constexpr bool L = MASK & 1, V = MASK & 2, G = MASK & 4, B = MASK & 8, H = MASK & 16, W = MASK & 32, S = MASK & 64, P = MASK & 128;
   __shared__ __attribute__((aligned(16))) float lds[16384];
   const int tid = threadIdx.x, lane = tid & 63;
   for (int i = tid; i < 16384; i += 768) lds[i] = in[i & 8191];
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(768) void mix_loop(const float* __restrict__ in, fl
         asm volatile("" :: "v"(s[2][0]), "v"(s[3][0]), "v"(s[0][1]), "v"(s[2][1]), "v"(s[3][1]), "v"(s[1][0]));
       }
       if (G && u == 1) {
-        const f32x4 w = gp[(i0 & 62) * 8];
+        const f32x4 w = P ? big[((size_t)(i0 >> 1) * 64 + lane) & ((1ull << 22) - 1)] : gp[(i0 & 62) * 8];
         x[0] = w[0]; x[1] = w[1]; x[2] = w[2]; x[3] = w[3];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -76,6 +78,11 @@ __global__ __launch_bounds__(768) void mix_loop(const float* __restrict__ in, fl
         for (int j = 0; j < 4; ++j)
           a[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[(j & 1) * 2 + k2 + 4 * u], bf[j >> 1][k2], a[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (S && (i0 & 15) == 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        *reinterpret_cast<f32x2*>(lds + 8192 + ((tid * 2 + e * 1536) & 8191)) = bf[e & 1];
     }
     if (H && (i0 & 7) == 6) hacc += big[(hbase + (size_t)(i0 >> 3) * (256 * 12 * 64)) & ((1ull << 26) - 1)];
     if (W && (i0 & 15) == 14) bigw[(hbase + (size_t)(i0 >> 4) * (256 * 12 * 64)) & ((1ull << 26) - 1)] = hacc;
@@ -140,6 +147,9 @@ int main() {
   run<16>(in, out, clk, "MFMA + HBM reads", big, bigw);
   run<48>(in, out, clk, "MFMA + HBM reads + writes", big, bigw);
   run<63>(in, out, clk, "all six", big, bigw);
+  run<64>(in, out, clk, "MFMA + LDS slab writes", big, bigw);
+  run<4 + 128>(in, out, clk, "MFMA + weight loads (64 MB)", big, bigw);
+  run<63 + 64 + 128>(in, out, clk, "all eight", big, bigw);
   run<0>(in, out, clk, "MFMA only (again)", big, bigw);
   return 0;
 }
