@@ -9,6 +9,7 @@
 //   H: a 16-byte global load per 8 iterations from a 1 GB buffer, every wave its own stream: ~1.4 TB/s of HBM reads
 //   W: a 16-byte global store per 16 iterations to a 1 GB buffer: ~0.7 TB/s of HBM writes
 //   S: 8 ds_write_b64 per 16 iterations (the slab staging of one chunk of 4 tap groups)
+//   A: 14 scalar ALU instructions per iteration (the real loop's descriptor / address arithmetic: 1.8 SALU per MFMA, PMC)
 //   P: the weight loads walk a 64 MB buffer shared by all blocks instead of an L2-resident 4 KB tile (L2 misses to the Infinity Cache)
 //   hipcc -O3 --offload-arch=gfx950 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip && tools/micro/mfma_mix
 #include <hip/hip_runtime.h>
@@ -22,7 +23,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int MASK>
 __global__ __launch_bounds__(768) void mix_loop(const float* __restrict__ in, float* out, unsigned long long* clk, int iters,
                                                  const f32x4* __restrict__ big, f32x4* __restrict__ bigw) {
-  constexpr bool L = MASK & 1, V = MASK & 2, G = MASK & 4, B = MASK & 8, H = MASK & 16, W = MASK & 32, S = MASK & 64, P = MASK & 128;
+  constexpr bool L = MASK & 1, V = MASK & 2, G = MASK & 4, B = MASK & 8, H = MASK & 16, W = MASK & 32, S = MASK & 64, P = MASK & 128, A = MASK & 256;
   __shared__ __attribute__((aligned(16))) float lds[16384];
   const int tid = threadIdx.x, lane = tid & 63;
   for (int i = tid; i < 16384; i += 768) lds[i] = in[i & 8191];
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(768) void mix_loop(const float* __restrict__ in, fl
   // 1 GB = 2^26 f32x4; every wave walks its own 64-lane-wide stream
   const size_t hbase = ((size_t)blockIdx.x * 12 + (tid >> 6)) * 64 + lane;
   f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+  int sacc = __builtin_amdgcn_readfirstlane(tid);
   const int i_dummy = 0;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int i0 = 0; i0 < iters; i0 += 2) {
@@ -71,6 +73,10 @@ __global__ __launch_bounds__(768) void mix_loop(const float* __restrict__ in, fl
         const f32x4 w = P ? big[((size_t)(i0 >> 1) * 64 + lane) & ((1ull << 22) - 1)] : gp[(i0 & 62) * 8];
         x[0] = w[0]; x[1] = w[1]; x[2] = w[2]; x[3] = w[3];
       }
+      if (A) {
+#pragma unroll
+        for (int e = 0; e < 7; ++e) asm volatile("s_mul_i32 %0, %0, 3\n\ts_add_u32 %0, %0, 1" : "+s"(sacc));
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(768) void mix_loop(const float* __restrict__ in, fl
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  float t = hacc[0] + hacc[1] + hacc[2] + hacc[3];
+  float t = hacc[0] + hacc[1] + hacc[2] + hacc[3] + (float)sacc;
   for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) t += a[j][r];
   if (t == 12345.678f) out[0] = t;
   if (threadIdx.x == 0 && blockIdx.x == 17) {
@@ -150,6 +156,8 @@ int main() {
   run<64>(in, out, clk, "MFMA + LDS slab writes", big, bigw);
   run<4 + 128>(in, out, clk, "MFMA + weight loads (64 MB)", big, bigw);
   run<63 + 64 + 128>(in, out, clk, "all eight", big, bigw);
+  run<256>(in, out, clk, "MFMA + 14 SALU", big, bigw);
+  run<63 + 64 + 128 + 256>(in, out, clk, "all nine", big, bigw);
   run<0>(in, out, clk, "MFMA only (again)", big, bigw);
   return 0;
 }
