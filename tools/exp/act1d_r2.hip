@@ -13,14 +13,10 @@
 //   z[2i]   = snake( 2 * sum_{q=-3..2} x[i+q] f_up[5-2q] )
 //   z[2i+1] = snake( 2 * sum_{q=-2..3} x[i+q] f_up[6-2q] )
 //   y[i]    = sum_{k=0..11} z[2i+k-5] f_dn[k]
-// The kernel works on the (odd, next even) pairs P_i = (z[2i+1], z[2i+2]): both halves of P_i read the SAME six
-// samples x[i-2 .. i+3] (taps (2 f_up[6-2q], 2 f_up[7-2q]), q = -2..3), and y[i] is the sum of both halves of
-// sum_{m=0..5} P_{i-3+m} * (f_dn[2m], f_dn[2m+1]): six packed FMAs per pair and per output (the (even, odd) pairing
-// of rounds 1-2 straddled both filters: seven each).
 //
 // Block = 256 threads; a tile = one (group, batch, channel) row segment of TT = 256 PPT - 8 outputs:
 //   phase 1: x[t0-8 .. t0+TT+7] -> LDS                         (258 float4, clamped indices)
-//   phase 2: thread t makes the 4 consecutive pairs P_i, i = t0 - 4 + 4t .. + 3 -> LDS
+//   phase 2: thread t makes the 4 consecutive (even, odd) pairs 4t .. 4t+3 of z -> LDS
 //   phase 3: thread t makes the 4 consecutive outputs 4t .. 4t+3 and stores them as one 16-byte vector.
 // Every LDS access is a 16-byte vector; the filter and snake arithmetic of phase 2 is on the
 // packed-fp32 VALU (v_pk_fma_f32).  (A persistent, software-prefetching variant measured slower.)
@@ -34,16 +30,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte access at any dword address
 
 // sin^2(a) without libm's sinf, two values at a time.  sin^2 has period pi and is even: Cody-Waite
-// reduction by pi in two fused steps (k = rint(a / pi); a - k fl(pi) is exact in one FMA for |a| < 2^15: its bits lie
-// between 2^-23 and 2^0; then - k (pi - fl(pi))) to |r| <= pi/2, then
+// reduction by pi in three fused steps (exact products for |k| < 2^15) to |r| <= pi/2, then
 // sin^2(r) = w P(w), w = r^2, P = degree-5 near-minimax fit of sin^2(sqrt w) / w on [0, (pi/2)^2]
 // (tools: numpy Chebyshev fit).  No quadrant select.  Absolute error <= 1.6e-7 in fp32 (checked on the
 // host against float64), the same size as squaring a 1-ulp sinf.  |a| >= 32768 is patched by the caller.
 __device__ __forceinline__ f32x2 sin_squared2(f32x2 a) {
-  // k = rint(a / pi) by the 1.5 * 2^23 trick (one packed FMA + one packed add instead of a multiply and two v_rndne)
-  const f32x2 k = __builtin_elementwise_fma(a, (f32x2)(0.31830988618379067154f), (f32x2)(12582912.f)) - 12582912.f;
-  f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-3.14159274101257324f), a);
-  r = __builtin_elementwise_fma(k, (f32x2)(8.742277657347586e-08f), r);
+  const f32x2 t = a * 0.31830988618379067154f;
+  const f32x2 k = {rintf(t[0]), rintf(t[1])};
+  f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-3.140625f), a);
+  r = __builtin_elementwise_fma(k, (f32x2)(-9.67502593994140625e-4f), r);
+  r = __builtin_elementwise_fma(k, (f32x2)(-1.5099579897537296e-7f), r);
   const f32x2 w = r * r;
   f32x2 p = __builtin_elementwise_fma(w, (f32x2)(-3.6304279547e-06f), (f32x2)(1.3934598246e-04f));
   p = __builtin_elementwise_fma(w, p, (f32x2)(-3.1723924913e-03f));
@@ -97,7 +93,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float ys[POUT ? ACT_PAIRS : 4];     // outputs of a tile, natural order
-  // filter taps of the current group as the pairs the packed FMAs take: [0..5] up (x 2), [6..11] down;
+  // filter taps of the current group as the (even, odd) pairs the packed FMAs take: [0..6] up (x 2), [7..13] down;
   // rewritten (other buffer) when a tile belongs to another group.  Read as LDS broadcasts: as scalar loads they
   // cost two s_load round trips, ~10 SGPR moves and 8 packed adds per tile.
   __shared__ __attribute__((aligned(16))) f32x2 taps[2][16];
@@ -124,30 +120,21 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     const fh_act_group* G;
     int t0, c, gi, len;
     float alpha, inv_beta;            // vector loads, requested one tile ahead together with the tile itself
-    f32x2 tap;                        // thread e < 12: tap pair e of the tile's group (loaded only if the group changes)
+    f32x2 tap;                        // thread e < 14: tap pair e of the tile's group (loaded only if the group changes)
   };
-  // byte offsets of this thread's tap pair inside fh_act_group: up pair j = (f_up[10 - 2j], f_up[11 - 2j]) (the taps of
-  // x[i - 2 + j] in z[2i+1] and z[2i+2]), down pair m = (f_dn[2m], f_dn[2m+1])
+  // byte offsets of this thread's tap pair inside fh_act_group (out of range = 0: the unused end taps)
   unsigned tap_off0, tap_off1;
   float tap_scale;
   {
-    const bool up = tid < 6;
-    const int j = up ? tid : tid - 6;
-    const int i0 = up ? 10 - 2 * j : 2 * j, i1 = i0 + 1;
+    const bool up = tid < 7;
+    const int j = up ? tid : tid - 7;
+    const int i0 = up ? 11 - 2 * j : 2 * j - 1, i1 = up ? 12 - 2 * j : 2 * j;
+    const bool v0 = tid < 14 && (up ? j <= 5 : j > 0), v1 = tid < 14 && (up ? j >= 1 : j < 6);
     const unsigned base = up ? (unsigned)offsetof(fh_act_group, up_taps) : (unsigned)offsetof(fh_act_group, down_taps);
-    tap_off0 = tid < 12 ? base + 4u * (unsigned)i0 : 0x80000000u;
-    tap_off1 = tid < 12 ? base + 4u * (unsigned)i1 : 0x80000000u;
+    tap_off0 = v0 ? base + 4u * (unsigned)i0 : 0x80000000u;
+    tap_off1 = v1 ? base + 4u * (unsigned)i1 : 0x80000000u;
     tap_scale = up ? 2.f : 1.f;       // (the 2x of UpSample1d folded in: exact)
   }
-  // per-thread parts of the tile's load / store byte offsets (+ 4 t0 per tile); 0x80000000 = never in range.  Offsets
-  // before the row (t0 = 0) wrap to huge values and offsets past its end exceed the descriptor: both read 0 / drop.
-  unsigned ld_off[2];
-#pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
-    const int f = tid + 256 * rep;
-    ld_off[rep] = f < ACT_XF4 ? (unsigned)((4 * f - 8) * 4) : 0x80000000u;
-  }
-  const unsigned st_off = ACT_PPT * tid < ACT_TT ? (unsigned)(ACT_PPT * tid * 4) : 0x80000000u;
   // position of a flattened tile: (tile in row, channel, batch, group); the first one of the block is found by
   // 32-bit divisions, the following ones by carrying (a 64-bit division per tile cost ~400 scalar instructions)
   struct Pos { int tile, c, bb, gi, tpr; };       // tpr: tiles per row of group gi
@@ -203,7 +190,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
       }
       const int t = T.t0 - 8 + 4 * f;
       if (VEC) {
-        xr[rep] = __builtin_amdgcn_raw_buffer_load_b128(T.rx, (unsigned)(T.t0 * 4) + ld_off[rep], 0, 0);
+        xr[rep] = __builtin_amdgcn_raw_buffer_load_b128(T.rx, f < ACT_XF4 ? (unsigned)(t * 4) : 0x80000000u, 0, 0);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -249,7 +236,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     const fh_act_group& G = *T.G;
     if (T.gi != gi_prev) {            // first tile of the block or of a group (uniform): publish its taps
       tbuf ^= 1;                      // (other buffer: waves may still be in phase 3 of the previous tile)
-      if (tid < 12) taps[tbuf][tid] = T.tap;
+      if (tid < 14) taps[tbuf][tid] = T.tap;
     }
     gi_prev = T.gi;
     const f32x2* tp = taps[tbuf];
@@ -290,9 +277,9 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     }
     // phase 2 (as above)
     {
-      f32x2 fu2[6];
+      f32x2 fu2[7];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) fu2[q] = tp[q];
+      for (int q = 0; q < 7; ++q) fu2[q] = tp[q];
       float xv[ACT_PPT + 8];
 #pragma unroll
       for (int v = 0; v < ACT_PPT / 4 + 2; ++v) {
@@ -307,7 +294,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
       for (int r = 0; r < ACT_PPT; ++r) {
         f32x2 z = {0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 6; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + 2 + q]), fu2[q], z);
+        for (int q = 0; q < 7; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + 1 + q]), fu2[q], z);
         zf[r] = z;
         arg[r] = z * alpha;
       }
@@ -316,7 +303,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
 #pragma unroll
       for (int r = 0; r < ACT_PPT; ++r) {
         s2[r] = sin_squared2(arg[r]);
-        amax = fmaxf(fmaxf(amax, fabsf(arg[r][0])), fabsf(arg[r][1]));     // (v_max3; NaN falls through, as sinf(NaN))
+        amax = fmaxf(amax, fmaxf(fabsf(arg[r][0]), fabsf(arg[r][1])));     // (NaN falls through, as sinf(NaN))
       }
       if (__builtin_expect(amax >= 32768.f, 0)) {
 #pragma unroll 1
@@ -336,27 +323,26 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     __syncthreads();
     // phase 3 (as above); every thread computes, invalid outputs get an out-of-range store offset
     {
-      f32x2 fdp[6];
+      f32x2 fdp[7];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) fdp[j] = tp[6 + j];
+      for (int j = 0; j < 7; ++j) fdp[j] = tp[7 + j];
       const int o0 = ACT_PPT * tid;
       const int i0 = t0 + o0;
-      float zv[2 * ACT_PPT + 12];        // pairs 4t .. 4t + 9 (the first one is not used: 16-byte reads)
+      float zv[2 * ACT_PPT + 16];
 #pragma unroll
-      for (int v = 0; v < ACT_PPT / 2 + 3; ++v) {
+      for (int v = 0; v < ACT_PPT / 2 + 4; ++v) {
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 2 * ACT_PPT * tid + 4 * v);
         zv[4 * v] = t4[0]; zv[4 * v + 1] = t4[1]; zv[4 * v + 2] = t4[2]; zv[4 * v + 3] = t4[3];
       }
       float out[ACT_PPT];
-      const int zbase = 2 * (t0 - 4) + 1;       // zs[m - zbase] = z[m]
+      const int zbase = 2 * (t0 - 4);
 #pragma unroll
       for (int r = 0; r < ACT_PPT; ++r) {       // interior form for every output (reads stay inside zs)
         f32x2 a2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < 7; ++j)
           a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
-        // (one scalar add per output: left to the vectoriser this became 6 moves + 2 packed adds per tile)
-        asm("v_add_f32 %0, %1, %2" : "=v"(out[r]) : "v"(a2[0]), "v"(a2[1]));
+        out[r] = a2[0] + a2[1];
       }
       // outputs whose taps leave [0, 2L-1] exist only in the first and the last tile(s) of a row (uniform test)
       if (t0 == 0 || t0 + ACT_TT + 3 > len) {
@@ -398,7 +384,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
           }
         }
       } else if (VEC) {
-        const unsigned off = (unsigned)(t0 * 4) + st_off;       // (len % 4 == 0: a vector is inside the row or past its end)
+        const unsigned off = (o0 < ACT_TT && i0 < len) ? (unsigned)(i0 * 4) : 0x80000000u;
         const u32x4 ou = {__float_as_uint(out[0]), __float_as_uint(out[1]), __float_as_uint(out[2]), __float_as_uint(out[3])};
         __builtin_amdgcn_raw_buffer_store_b128(ou, T.ry, off, 0, 0);
       } else {

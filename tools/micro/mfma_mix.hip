@@ -11,7 +11,7 @@
 //   S: 8 ds_write_b64 per 16 iterations (the slab staging of one chunk of 4 tap groups)
 //   A: 14 scalar ALU instructions per iteration (the real loop's descriptor / address arithmetic: 1.8 SALU per MFMA, PMC)
 //   P: the weight loads walk a 64 MB buffer shared by all blocks instead of an L2-resident 4 KB tile (L2 misses to the Infinity Cache)
-//   hipcc -O3 --offload-arch=gfx950 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip && tools/micro/mfma_mix
+//   hipcc -O3 --offload-arch=gfx950 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip && tools/micro/mfma_mix [random]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -131,7 +131,29 @@ void run(const float* in, float* out, unsigned long long* clk, const char* name,
          (3.0 * iters * 8 * 64) / (ms * 1e-3 * mhz * 1e6));
 }
 
-int main() {
+// Many short launches back to back (the real conv launches are ~300 us): does the clock / rate of a launch depend on its length?
+template <int MASK>
+void run_short(const float* in, float* out, unsigned long long* clk, const char* name, const f32x4* big, f32x4* bigw, int iters, int launches) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int l = 0; l < 20; ++l) mix_loop<MASK><<<256, 768>>>(in, out, clk, iters, big, bigw);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  for (int l = 0; l < launches; ++l) mix_loop<MASK><<<256, 768>>>(in, out, clk, iters, big, bigw);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long c[2];
+  (void)hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
+  const double flop = 256.0 * 12 * iters * 8 * 2.0 * 32 * 32 * 2 * launches;
+  printf("%-28s %5d launches of %6d iterations (%7.1f us each): %6.1f TFLOP/s over all, clock of the last launch %4.0f MHz\n", name,
+         launches, iters, ms * 1e3 / launches, flop / ms * 1e-9, 100.0 * (double)c[0] / (double)c[1]);
+}
+
+int main(int argc, char** argv) {
+  const bool random_big = argc > 1;       // any argument: the 1 GB weight / stream buffer holds random values instead of zeros
   float *in, *out;
   unsigned long long* clk;
   (void)hipMalloc(&in, 65536 * 4);
@@ -144,6 +166,13 @@ int main() {
   (void)hipMalloc(&big, 1ull << 30);
   (void)hipMalloc(&bigw, 1ull << 30);
   (void)hipMemset(big, 0, 1ull << 30);
+  if (random_big) {                       // (data-dependent power: the same loops on operands whose bits toggle)
+    std::vector<float> hb(1u << 24);
+    for (auto& v : hb) v = (float)rand() / (float)RAND_MAX * 2.f - 1.f;
+    for (size_t off = 0; off < (1ull << 30); off += hb.size() * 4)
+      (void)hipMemcpy(reinterpret_cast<char*>(big) + off, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    printf("weights / streamed operands: random in [-1, 1]\n");
+  }
   run<0>(in, out, clk, "MFMA only", big, bigw);
   run<1>(in, out, clk, "+ LDS reads", big, bigw);
   run<2>(in, out, clk, "+ packed transform", big, bigw);
@@ -159,5 +188,9 @@ int main() {
   run<256>(in, out, clk, "MFMA + 14 SALU", big, bigw);
   run<63 + 64 + 128 + 256>(in, out, clk, "all nine", big, bigw);
   run<0>(in, out, clk, "MFMA only (again)", big, bigw);
+  for (int iters : {100000, 10000, 1000, 460, 100}) {
+    run_short<0>(in, out, clk, "MFMA only", big, bigw, iters, 40000000 / iters > 2000 ? 2000 : 40000000 / iters);
+    run_short<63 + 64 + 128 + 256>(in, out, clk, "all nine", big, bigw, iters, 40000000 / iters > 2000 ? 2000 : 40000000 / iters);
+  }
   return 0;
 }
