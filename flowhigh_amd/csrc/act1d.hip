@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
                                                           long long total_tiles, int din_arg, int dout_arg, int n_groups) {
   const int din = (DIL > 0 && PIN) ? DIL : din_arg, dout = (DIL > 0 && POUT) ? DIL : dout_arg;
   static_assert(ACT_THREADS == 256 && ACT_PPT == 4, "strip kernel is written for 256 threads x 4 outputs");
-  __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
+  __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + (PIN ? 112 : 16)];   // (PIN: the phase chunks overshoot the tile by < 5 din + 8)
   __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
   __shared__ __attribute__((aligned(16))) float ys[POUT ? ACT_PAIRS : 4];     // outputs of a tile, natural order
   // filter taps of the current group as the pairs the packed FMAs take: [0..5] up (x 2), [6..11] down;
@@ -106,7 +106,13 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   auto lp_of = [](int l, int d) { return ((l + d - 1) / d + 3) & ~3; };
   // phase-major input: chunk q = (phase p, 4 consecutive decimated samples); <= 2 chunks per thread
   const int nq_in = PIN ? ((ACT_XS + din - 1) / din + 3) / 4 : 1;
-  const int nq_out = POUT ? ((ACT_TT + dout - 1) / dout + 3) / 4 : 1;
+  // Outputs stored per tile.  Phase-major output (one length per launch): the largest multiple of 4 dout <= ACT_TT, so
+  // that every tile starts on a chunk boundary of every phase: the TT / 4 <= 254 chunks of a tile are whole 16-byte
+  // vectors, one per thread, at offsets that are per-thread constants + one uniform term (ragged launches keep ACT_TT
+  // and the general chunk geometry below: their tile prefix is computed by the host from fh_act_tile_len()).
+  const bool pout_aligned = POUT && !RAGGED;
+  const int TT = pout_aligned ? ACT_TT / (4 * dout) * (4 * dout) : ACT_TT;
+  const int nq_out = POUT ? (pout_aligned ? TT / (4 * dout) : ((ACT_TT + dout - 1) / dout + 3) / 4) : 1;
   // (phase, chunk-in-phase) of this thread's two chunks: constant over the tiles.  All other divisions by the
   // dilation are done once per tile on wave-uniform values: ceil((x - p) / d) = x / d + (x % d > p), 0 <= p < d.
   int pin_p[2], pin_k[2], pout_p[2], pout_k[2];
@@ -118,11 +124,27 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     pout_p[rep] = f / nq_out;
     pout_k[rep] = f - pout_p[rep] * nq_out;
   }
+  // phase-major input, per tile: tb = t0 - 8 = bu din + rt; the chunk (p, k) starts at u = bu + (rt > p) + 4 k, i.e. at
+  // sample t = tb + pin_ct - rt + (rt > p ? din : 0), pin_ct = 4 k din + p (first tile of a row, tb < 0: u = 4 k, t = pin_ct)
+  int pin_ct[2];
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) pin_ct[rep] = 4 * pin_k[rep] * din + pin_p[rep];
+  struct PinTile { int bu, rt, a, b; };               // uniform per tile
+  auto pin_tile = [&](int t0) {
+    const int tb = t0 - 8;
+    PinTile q;
+    if (tb < 0) { q.bu = 0; q.rt = -1; q.a = 8; q.b = 0; }
+    else { q.bu = uni(tb / din); q.rt = tb - q.bu * din; q.a = -q.rt; q.b = din; }
+    return q;
+  };
+  // aligned phase-major output: chunk of thread tid = (phase p, chunk k): ys index p + dout (4 k + e), row offset
+  // p lp_out + t0 / dout + 4 k floats; t0 / dout = tile (TT / dout)
+  const int pout_cy = pout_p[0] < dout ? pout_p[0] + 4 * pout_k[0] * dout : 0x7fffffff;
 
   struct Tile {                       // wave-uniform description of one flattened tile
     __amdgpu_buffer_rsrc_t rx, ry;
     const fh_act_group* G;
-    int t0, c, gi, len;
+    int t0, tile_in_row, c, gi, len;
     float alpha, inv_beta;            // vector loads, requested one tile ahead together with the tile itself
     f32x2 tap;                        // thread e < 12: tap pair e of the tile's group (loaded only if the group changes)
   };
@@ -174,7 +196,8 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     const size_t rowi = (size_t)p.bb * channels + p.c;
     T.rx = make_rsrc(uni(T.G->x) + rowi * (size_t)pitch_in, ok ? (unsigned)pitch_in * 4u : 0u);
     T.ry = make_rsrc(uni((const float*)T.G->y) + rowi * (size_t)pitch_out, ok ? (unsigned)pitch_out * 4u : 0u);
-    T.t0 = p.tile * ACT_TT;
+    T.t0 = p.tile * TT;
+    T.tile_in_row = p.tile;
     // (buffer loads, not flat ones: with a flat load in flight the compiler has to wait with vmcnt(0))
     T.alpha = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
         make_rsrc(uni(T.G->alpha), (unsigned)channels * 4u), (unsigned)T.c * 4u, 0, 0));
@@ -191,11 +214,9 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     for (int rep = 0; rep < 2; ++rep) {
       const int f = tid + 256 * rep;
       if (PIN) {           // 4 consecutive samples of one phase: 16 bytes at a dword-aligned address
-        const int tb8 = uni(T.t0 - 8 + 8 * din);                   // >= 0
-        const int qt = uni(tb8 / din), rt = tb8 - qt * din;
-        const int p = pin_p[rep], k = pin_k[rep];
-        const int ul = qt - 8 + (rt > p ? 1 : 0);                  // ceil((t0 - 8 - p) / din)
-        const int u = (ul > 0 ? ul : 0) + 4 * k;
+        const PinTile q = pin_tile(T.t0);
+        const int p = pin_p[rep];
+        const int u = q.bu + (q.rt > p ? 1 : 0) + 4 * pin_k[rep];  // max(0, ceil((t0 - 8 - p) / din)) + 4 k
         const int lp_in = lp_of(T.len, din);
         // (past the row: reads a neighbour phase or falls out of range; such samples are not used)
         xr[rep] = __builtin_amdgcn_raw_buffer_load_b128(T.rx, p < din ? (unsigned)((p * lp_in + u) * 4) : 0x80000000u, 0, 0);
@@ -257,20 +278,16 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
     const int len = T.len, zlast = 2 * len - 1;              // (shadow the launch value: this tile's row length)
     const int lp_out = POUT ? lp_of(len, dout) : 0;
     if (PIN) {                 // scatter the phase chunks to their natural positions (stride din, odd: conflict free)
-      const int tb = T.t0 - 8;
-      const int tb8 = uni(tb + 8 * din);
-      const int qt = uni(tb8 / din), rt = tb8 - qt * din;
+      // Unconditional: a chunk never starts before the tile (t >= tb), what it brings past the tile lands in the slack
+      // of xs, and samples past the row end are overwritten by the replicate padding below.
+      const PinTile q = pin_tile(T.t0);
 #pragma unroll
       for (int rep = 0; rep < 2; ++rep) {
-        const int p = pin_p[rep], k = pin_k[rep];
-        const int ul = qt - 8 + (rt > p ? 1 : 0);
-        const int u = (ul > 0 ? ul : 0) + 4 * k;
+        const int p = pin_p[rep];
         if (p < din) {
+          float* dst = xs + pin_ct[rep] + q.a + (q.rt > p ? q.b : 0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int t = (u + e) * din + p;
-            if (t >= 0 && t < len && t - tb < ACT_XS) xs[t - tb] = __uint_as_float(cur[rep][e]);
-          }
+          for (int e = 0; e < 4; ++e) dst[e * din] = __uint_as_float(cur[rep][e]);
         }
       }
     } else {
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
         asm("v_add_f32 %0, %1, %2" : "=v"(out[r]) : "v"(a2[0]), "v"(a2[1]));
       }
       // outputs whose taps leave [0, 2L-1] exist only in the first and the last tile(s) of a row (uniform test)
-      if (t0 == 0 || t0 + ACT_TT + 3 > len) {
+      if (t0 == 0 || t0 + TT + 3 > len) {
 #pragma unroll 1
         for (int r = 0; r < ACT_PPT; ++r) {
           const int i = i0 + r;
@@ -375,7 +392,19 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
           }
         }
       }
-      if (POUT) {                // natural order through LDS, then 4 consecutive outputs of one phase per thread
+      if (POUT && pout_aligned) { // natural order through LDS, then 4 consecutive outputs of one phase per thread
+        *reinterpret_cast<f32x4*>(ys + o0) = (f32x4){out[0], out[1], out[2], out[3]};
+        __syncthreads();
+        // a chunk is stored if its first sample is inside the row (then it is inside the phase's lp_out floats; what
+        // it writes past the phase's last sample is padding nobody reads)
+        const bool st = pout_cy < len - t0;
+        const float* src = ys + (pout_p[0] < dout ? pout_cy : 0);
+        u32x4 ou;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ou[e] = __float_as_uint(src[e * dout]);
+        const int u0 = uni(T.tile_in_row * (TT / dout));
+        __builtin_amdgcn_raw_buffer_store_b128(ou, T.ry, st ? (unsigned)((pout_p[0] * lp_out + u0 + 4 * pout_k[0]) * 4) : 0x80000000u, 0, 0);
+      } else if (POUT) {         // (ragged launches) the same with the general chunk geometry
         *reinterpret_cast<f32x4*>(ys + o0) = (f32x4){out[0], out[1], out[2], out[3]};
         __syncthreads();
         const int t_end = (t0 + ACT_TT < len ? t0 + ACT_TT : len) - 1;      // last output of this tile
@@ -422,7 +451,8 @@ extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups,
                                        int channels, int len, int din, int dout, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && channels > 0 && len > 0, "fh_act1d_grouped_f32: bad sizes");
   FH_CHECK_ARG(din >= 1 && dout >= 1, "fh_act1d_grouped_pm_f32: bad dilations %d / %d", din, dout);
-  const int tiles = fh_cdiv(len, ACT_TT);
+  // (phase-major output: a tile stores the largest multiple of 4 dout outputs <= ACT_TT, see the kernel)
+  const int tiles = fh_cdiv(len, dout > 1 && dout <= 16 ? ACT_TT / (4 * dout) * (4 * dout) : ACT_TT);
   const long long blocks = (long long)n_groups * batch * channels * tiles;
   FH_CHECK_ARG(blocks < (1ll << 31), "fh_act1d_grouped_f32: grid too large");
   // chunks of a tile in phase-major form must fit 2 per thread: ceil(ceil(XS / d) / 4) * d <= 512; 32-bit row offsets
