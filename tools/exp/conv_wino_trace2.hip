@@ -151,7 +151,8 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
 template <int MT, int NT, int SUBS, bool VL, bool BF>
 __global__ __attribute__((amdgpu_flat_work_group_size(W_THREADS, W_THREADS), amdgpu_waves_per_eu(3, 3)))
 void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles,
-                      int n_tiles, int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs) {
+                      int n_tiles, int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs,
+                      int xcd_ranges) {
   using Cfg = WCfg<MT, NT, SUBS>;
   constexpr int W_BM = Cfg::BM, W_BT = Cfg::BT, W_P = Cfg::P, W_RP2 = Cfg::RP2, W_XPT = Cfg::XPT, W_SLAB = Cfg::SLAB;
   constexpr int W_SUB = (W_CK / 2) * W_RP2;          // floats of one 16-channel chunk inside a slab buffer
@@ -171,19 +172,41 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const int total_runs = panels * runs_per_panel;
   const int bid = blockIdx.x;
   const int slot = bid >> 3;
-  int run = (slot / run_len) * 8 + (bid & 7);
-  // Ragged launches (groups of different lengths, grid sized for the longest): only the runs that hold real tiles
-  // are launched, listed heavy-first in run_map -- otherwise the empty runs of the short clips, which fall on
-  // the same XCDs for every panel (run r of a panel -> XCD (panel * runs_per_panel + r) % 8), leave the real work
-  // on 2-4 of the 8 XCDs.
-  if (run_map) {
-    if (run >= n_runs) return;
-    run = uni(run_map[run]);
+  int panel, ntile;
+  if (xcd_ranges) {
+    // FH_WINO_XCD_RANGES: XCD x (= block id mod 8) works on the x-th EIGHTH of the time axis of EVERY panel.  Inside
+    // an XCD the blocks of a (group, batch item) are ordered in RECTANGLES of (all its co tiles) x (R consecutive time
+    // tiles), R = 32 / co_tiles: the ~32 blocks that are resident on the XCD's CUs together are the co tiles of the same
+    // R time tiles, so they read their common input through one L2 while it is there, and the R blocks of a co tile
+    // stream that panel's weights in lockstep.  Price: every XCD fetches every weight panel (once per rectangle): the
+    // mapping for launches whose weights are small beside their activations (tools/traffic_per_launch.py), chosen by
+    // the host plan; groups still in launch order (heavy first).
+    const int tpx = (n_tiles + 7) >> 3;
+    const int R = co_tiles < 32 ? 32 / co_tiles : 1;
+    const int nrect = (tpx + R - 1) / R;
+    const int per_gb = co_tiles * nrect * R;
+    const int gbi = uni(slot / per_gb), rem = slot % per_gb;
+    const int rect = rem / (co_tiles * R), w = rem % (co_tiles * R);
+    const int t = rect * R + w % R;
+    if (gbi >= n_groups * batch || t >= tpx) return;
+    panel = uni(gbi * co_tiles + w / R);
+    ntile = uni((bid & 7) * tpx + t);
+    if (ntile >= n_tiles) return;
+  } else {
+    int run = (slot / run_len) * 8 + (bid & 7);
+    // Ragged launches (groups of different lengths, grid sized for the longest): only the runs that hold real tiles
+    // are launched, listed heavy-first in run_map -- otherwise the empty runs of the short clips, which fall on
+    // the same XCDs for every panel (run r of a panel -> XCD (panel * runs_per_panel + r) % 8), leave the real work
+    // on 2-4 of the 8 XCDs.
+    if (run_map) {
+      if (run >= n_runs) return;
+      run = uni(run_map[run]);
+    }
+    if (run >= total_runs) return;
+    panel = uni(run / runs_per_panel);
+    ntile = uni((run % runs_per_panel) * run_len + (slot % run_len));
+    if (ntile >= n_tiles) return;
   }
-  if (run >= total_runs) return;
-  const int panel = uni(run / runs_per_panel);
-  const int ntile = uni((run % runs_per_panel) * run_len + (slot % run_len));
-  if (ntile >= n_tiles) return;
   const int cot = uni(panel % co_tiles);
   const int gb = uni(panel / co_tiles);
   const int b = uni(gb % batch);
@@ -768,7 +791,7 @@ namespace {
 
 template <int MT, int NT, int SUBS, bool VL, bool BF>
 int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
-                int phase_major, hipStream_t stream, const int* run_map = nullptr, int n_runs = 0) {
+                int phase_major, hipStream_t stream, const int* run_map, int n_runs, bool xcd_ranges) {
   using Cfg = WCfg<MT, NT, SUBS>;
   FH_CHECK_ARG(cout_pad > 0 && cout_pad % Cfg::BM == 0, "fh_conv_wino_f32: cout_pad %d not a multiple of %d", cout_pad, Cfg::BM);
   const int co_tiles = cout_pad / Cfg::BM;
@@ -776,7 +799,9 @@ int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cou
   const long long panels = (long long)n_groups * batch * co_tiles;
   const int run_len = fh_cdiv(n_tiles, fh_cdiv(n_tiles, W_RUN));
   const long long runs = run_map ? (long long)n_runs : panels * fh_cdiv(n_tiles, run_len);
-  const long long blocks = (long long)fh_cdiv(runs, 8) * 8 * run_len;
+  const int rect_r = co_tiles < 32 ? 32 / co_tiles : 1, tpx = fh_cdiv(n_tiles, 8);        // (see the kernel's xcd_ranges branch)
+  const long long blocks = xcd_ranges ? 8ll * n_groups * batch * co_tiles * fh_cdiv(tpx, rect_r) * rect_r
+                                      : (long long)fh_cdiv(runs, 8) * 8 * run_len;
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino_f32: grid too large");
   // > 64 KB of dynamic LDS needs the attribute once per DEVICE (a kernel has one function object per device, and
   // a process may hold models on several): one flag per device ordinal and template instance.
@@ -796,7 +821,8 @@ int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cou
     lds_opt_in[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS, VL, BF>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
-                     stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major, run_map, n_runs);
+                     stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major, run_map, n_runs,
+                     xcd_ranges ? 1 : 0);
   FH_CHECK_LAUNCH("fh_conv_wino_f32");
   return FH_OK;
 }
@@ -809,14 +835,15 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
   // not 16-byte aligned; `len` is then only the longest group's length)
   const bool pm = (phase_major & 1) != 0;
   const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2);
-  return vl ? launch_wino_vl<MT, NT, SUBS, true, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs)
-            : launch_wino_vl<MT, NT, SUBS, false, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs);
+  const bool xr = (phase_major & 4) != 0 && !run_map;          // (bit 2, set by wino_dispatch: FH_WINO_XCD_RANGES)
+  return vl ? launch_wino_vl<MT, NT, SUBS, true, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs, xr)
+            : launch_wino_vl<MT, NT, SUBS, false, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs, xr);
 }
 
 }  // namespace
 
 extern "C" int fh_wino_tile_m(int tile_cfg) {
-  tile_cfg &= ~FH_WINO_BF16X6;
+  tile_cfg &= ~(FH_WINO_BF16X6 | FH_WINO_XCD_RANGES);
 #ifdef FH_WINO_EXPERIMENTS
   if (tile_cfg == 8 || tile_cfg == 9) return 64;
 #endif
@@ -828,6 +855,10 @@ extern "C" int fh_phase_len(int len, int dilation) { return ((len + dilation - 1
 namespace {
 int wino_dispatch(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
                   int phase_major, int tile_cfg, hipStream_t st, const int* run_map, int n_runs) {
+  if (tile_cfg & FH_WINO_XCD_RANGES) {
+    tile_cfg &= ~FH_WINO_XCD_RANGES;
+    phase_major |= 4;
+  }
   switch (tile_cfg) {
     case 0: return launch_wino<2, 2, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case 1: return launch_wino<3, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
@@ -874,7 +905,7 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
   return wino_dispatch(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0 ? 1 : 0, tile_cfg, (hipStream_t)stream, nullptr, 0);
 }
 
-extern "C" int fh_wino_tile_n(int tile_cfg) { tile_cfg &= ~FH_WINO_BF16X6; return tile_cfg == 0 ? 512 : (fh_wino_tile_m(tile_cfg) > 0 ? 256 : -1); }
+extern "C" int fh_wino_tile_n(int tile_cfg) { tile_cfg &= ~(FH_WINO_BF16X6 | FH_WINO_XCD_RANGES); return tile_cfg == 0 ? 512 : (fh_wino_tile_m(tile_cfg) > 0 ? 256 : -1); }
 extern "C" int fh_wino_run_len(int n_tiles) { return n_tiles > 0 ? fh_cdiv(n_tiles, fh_cdiv(n_tiles, W_RUN)) : -1; }
 
 extern "C" int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
