@@ -38,16 +38,17 @@ WINO_E = ('''      if (eact) {
         const float* er = E + (eth * 6 * 32 + ecol) * W_EP + 4 * erq;''', '''      if (eact && tid == 12345) {                 // ablation: no epilogue reads / arithmetic / stores (the exchange writes stay)
         const float* er = E + (eth * 6 * 32 + ecol) * W_EP + 4 * erq;''')
 ACT_SIN = ('''        s2[r] = sin_squared2(arg[r]);
-        amax = fmaxf(amax, fmaxf(fabsf(arg[r][0]), fabsf(arg[r][1])));     // (NaN falls through, as sinf(NaN))''',
+        amax = fmaxf(fmaxf(amax, fabsf(arg[r][0])), fabsf(arg[r][1]));     // (v_max3; NaN falls through, as sinf(NaN))''',
            '''        s2[r] = arg[r];                            // ablation: no sin^2''')
 ACT_UP = ('''      for (int r = 0; r < ACT_PPT; ++r) zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2[r], zf[r]);
       f32x4* zw''', '''      for (int r = 0; r < ACT_PPT; ++r) zout[r] = (f32x2){xv[r + 1], xv[r + 2]} * alpha + inv_beta;   // ablation: no up filter / snake
       f32x4* zw''')
 ACT_DOWN = ('''        f32x2 a2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
+        for (int j = 0; j < 6; ++j)
           a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
-        out[r] = a2[0] + a2[1];
+        // (one scalar add per output: left to the vectoriser this became 6 moves + 2 packed adds per tile)
+        asm("v_add_f32 %0, %1, %2" : "=v"(out[r]) : "v"(a2[0]), "v"(a2[1]));
       }
       // outputs whose taps leave''', '''        out[r] = zv[2 * r + 8];                    // ablation: no down filter
       }

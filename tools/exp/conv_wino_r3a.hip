@@ -105,10 +105,7 @@ struct WCfg {
   static constexpr int XPT = (4 * BT + 16 + 47) / 48;   // slab samples per thread (48 threads per row)
   static constexpr int SLAB = SUBS * (W_CK / 2) * RP2;  // floats per slab buffer
   static constexpr int EPI = 12 * 32 * W_EP;            // epilogue exchange, floats
-  // two exchange buffers where a block has more than one 32 x 32 sub-tile per wave (one barrier per sub-tile instead of
-  // two); the 32 x 256 shape keeps one: two of its blocks share a CU
-  static constexpr int EBUFS = MT * NT > 1 ? 2 : 1;
-  static constexpr int LDS_FLOATS = 2 * SLAB > EBUFS * EPI ? 2 * SLAB : EBUFS * EPI;
+  static constexpr int LDS_FLOATS = 2 * SLAB > EPI ? 2 * SLAB : EPI;
   static_assert(RP2 >= 8 * P, "planes overlap");
 };
 
@@ -163,9 +160,6 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   unsigned long long* const trace = g_wino_trace;
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-  unsigned long long* rec2 = nullptr;
-  if (trace) rec2 = trace + 1 + 24 * ((unsigned long long)blockIdx.x * 12ull + (unsigned long long)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
-#define STAMP(k) do { if (rec2 && (threadIdx.x & 63) == 0) rec2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
   // ---- block -> (panel, n block); panels = (group, batch, co tile), heavy groups first ----------
   const int panels = n_groups * batch * co_tiles;
@@ -361,17 +355,13 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   };
 
   // ---- prologue -------------------------------------------------------------------------------
-  STAMP(3);
   WSeg S0 = load_wseg(&G->seg[0]);
-  STAMP(4);
   if constexpr (BF) {
     load_a3(S0, 0, 0, true);
   } else {
     load_a_half(0, S0, 0, 0, true);
     load_a_half(1, S0, 0, 0, true);
   }
-  if (rec2) { __builtin_amdgcn_s_waitcnt(0); }      // diagnosis only: first A tiles have arrived
-  STAMP(16);
   int xbuf = 0;
 #pragma unroll
   for (int sub = 0; sub < SUBS; ++sub) {
@@ -386,9 +376,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       store_x(0, sub);
     }
   }
-  STAMP(17);
   __syncthreads();
-  STAMP(18);
 
   f32x2 c0 = {bc0, bc0}, c1 = {bc1, bc1}, c2 = {bc2, bc2};       // alpha, beta, gamma of this wave's row of B^T
   // The K loop of a chunk is a flat sequence of k-step PAIRS: pair p = 4 g + kp (tap group g,
@@ -569,7 +557,6 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   run_all(std::integral_constant<int, 2>{});
   run_all(std::integral_constant<int, 1>{});
   const unsigned long long t_loop1 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  STAMP(6);
 
   // ---- epilogue: exchange M_xi through LDS, y = A^T M, bias + residuals, scale, store ----------
   const int nres = uni(G->nres);
@@ -594,46 +581,33 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   // (lanes 0-31 of a store: 512 contiguous bytes of one row).  Against the row-major tiles with 4-byte accesses of
   // round 2 (16 writes + 18 reads per thread and tile in 3 passes, ~2 us per tile with the matrix pipes idle:
   // tools/wino_trace2.py) this is a quarter of the LDS instructions and a third of the address arithmetic.
+  float* E = lds;
   const int eth = tid >> 8, erq = (tid >> 5) & 7, ecol = tid & 31;       // reader item (threads 512 .. 767 idle)
   const bool eact = tid < 512;
-  // bias and first residual of a sub-tile's 4 rows are requested one sub-tile ahead (the weight registers are free
-  // now): an HBM round trip is longer than one exchange
-  float bpre[2][4];
-  u32x4 rpre[2][4];
-  auto request = [&](int mt, int nt, float (&bp)[4], u32x4 (&rp)[4]) {
-    const int corow = co0 + mt * 32 + 4 * erq;
-    const int v0 = tb * (4 * W_BT) + (nt * 64 + eth * 32 + ecol) * 4;
-    const bool colok = eact && (v0 + 3) * dil + ph < len;
-    const unsigned coloff = (pm ? (unsigned)(ph * lp) : 0u) + (unsigned)v0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      bp[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-          rbias, (eact && corow + i < cout) ? (unsigned)(corow + i) * 4u : 0x80000000u, 0, 0));
-    if (vec && nres > 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = colok && corow + i < cout;
-        rp[i] = __builtin_amdgcn_raw_buffer_load_b128(
-            rr0, ok ? ((unsigned)(corow + i) * (unsigned)opitch + coloff) * 4u : 0x80000000u, 0, 0);
-      }
-    }
-  };
-  request(0, 0, bpre[0], rpre[0]);
-  __syncthreads();                                   // every wave is out of the K loop: the slab space is free
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      constexpr int kEB = Cfg::EBUFS;
-      const int sub = mt * NT + nt;
-      const int sb_ = sub < 3 ? 7 + 3 * sub : 19;
-      STAMP(sb_);       // (first sub-tile: after the barrier that ends the K loop; later ones: after the previous stores)
-      float* E = lds + (kEB == 2 ? (sub & 1) * Cfg::EPI : 0);
-      if (kEB == 1 && sub > 0) __syncthreads();      // (one buffer: the readers of the previous sub-tile must be done)
+      __syncthreads();
+      // bias and first residual of this thread's 4 rows: requested here so that their latency hides under the exchange
       const int corow = co0 + mt * 32 + 4 * erq;                        // + i
       const int v0 = tb * (4 * W_BT) + (nt * 64 + eth * 32 + ecol) * 4;   // decimated index of y[0]
       const bool colok = eact && (v0 + 3) * dil + ph < len;
-      if (sub + 1 < MT * NT) request((sub + 1) / NT, (sub + 1) % NT, bpre[(sub + 1) & 1], rpre[(sub + 1) & 1]);
+      const unsigned coloff = (pm ? (unsigned)(ph * lp) : 0u) + (unsigned)v0;
+      float bpre[4];
+      u32x4 rpre[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        bpre[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            rbias, (eact && corow + i < cout) ? (unsigned)(corow + i) * 4u : 0x80000000u, 0, 0));
+      if (vec && nres > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = colok && corow + i < cout;
+          rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(
+              rr0, ok ? ((unsigned)(corow + i) * (unsigned)opitch + coloff) * 4u : 0x80000000u, 0, 0);
+        }
+      }
       {
         float* ew = E + ((th * 6 + xi) * 32 + l31) * W_EP + 4 * lh;
 #pragma unroll
@@ -642,7 +616,6 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
               (f32x4){acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
       }
       __syncthreads();
-      STAMP(sb_ + 1);
       if (eact) {
         const float* er = E + (eth * 6 * 32 + ecol) * W_EP + 4 * erq;
         const f32x4 m0 = *reinterpret_cast<const f32x4*>(er), m1 = *reinterpret_cast<const f32x4*>(er + 32 * W_EP),
@@ -658,14 +631,14 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
         for (int i = 0; i < 4; ++i) {
           const int co = corow + i;
           const bool rowok = co < cout;
-          const float bv = bpre[sub & 1][i];
+          const float bv = bpre[i];
           const unsigned rowoff = (unsigned)co * (unsigned)opitch + (pm ? (unsigned)(ph * lp) : 0u);
           const float y[4] = {y0[i], y1[i], y2[i], y3[i]};
           if (vec && colok) {
             const unsigned off = rowok ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
             f32x4 o = {y[0] + bv, y[1] + bv, y[2] + bv, y[3] + bv};
             if (nres > 0) {
-              u32x4 t = rpre[sub & 1][i];
+              u32x4 t = rpre[i];
               f32x4 rs = {__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
               if (nres > 1) {
                 t = __builtin_amdgcn_raw_buffer_load_b128(rr1, off, 0, 0);
@@ -698,18 +671,20 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           }
         }
       }
-      STAMP(sb_ + 2);
     }
   }
   if (pf == 0x7fc12345u && trace) trace[0] = 0;      // keeps pf alive; never true for weights
-  if (rec2 && (tid & 63) == 0) {
+  if (trace && (tid & 63) == 0) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    rec2[0] = (unsigned long long)blockIdx.x | ((unsigned long long)(hw & 0xffffff) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
-    rec2[1] = t_start;
-    rec2[2] = __builtin_amdgcn_s_memrealtime();
-    rec2[23] = (unsigned long long)wave | ((__builtin_amdgcn_s_memtime() - c_start) << 8);
+    const unsigned long long slot = atomicAdd(trace, 1ull);
+    unsigned long long* r = trace + 1 + 5 * slot;
+    r[0] = (unsigned long long)blockIdx.x | ((unsigned long long)(hw & 0xffffff) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
+    r[1] = t_start;
+    r[2] = __builtin_amdgcn_s_memrealtime();
+    r[3] = (unsigned long long)wave | ((t_loop0 - t_start) << 8) | ((t_loop1 - t_start) << 36);
+    r[4] = __builtin_amdgcn_s_memtime() - c_start;       // shader clocks: r[4] / (r[2] - r[1]) x 100 MHz
   }
 }
 

@@ -45,13 +45,11 @@ sub('''  const unsigned long long t_loop1 = trace ? __builtin_amdgcn_s_memrealti
 ''', '''  const unsigned long long t_loop1 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   STAMP(6);
 ''')
-sub('''    for (int nt = 0; nt < NT; ++nt) {
-      __syncthreads();
-      // bias and first residual''', '''    for (int nt = 0; nt < NT; ++nt) {
-      const int sk_ = mt * NT + nt, sb_ = sk_ < 3 ? 7 + 3 * sk_ : 19;
-      __syncthreads();
-      STAMP(sb_);
-      // bias and first residual''')
+sub('''      const int sub = mt * NT + nt;
+''', '''      const int sub = mt * NT + nt;
+      const int sb_ = sub < 3 ? 7 + 3 * sub : 19;
+      STAMP(sb_);       // (first sub-tile: after the barrier that ends the K loop; later ones: after the previous stores)
+''')
 sub('''      }
       __syncthreads();
       if (eact) {''', '''      }
