@@ -105,7 +105,10 @@ struct WCfg {
   static constexpr int XPT = (4 * BT + 16 + 47) / 48;   // slab samples per thread (48 threads per row)
   static constexpr int SLAB = SUBS * (W_CK / 2) * RP2;  // floats per slab buffer
   static constexpr int EPI = 12 * 32 * W_EP;            // epilogue exchange, floats
-  static constexpr int LDS_FLOATS = 2 * SLAB > EPI ? 2 * SLAB : EPI;
+  // two exchange buffers where a block has more than one 32 x 32 sub-tile per wave (one barrier per sub-tile instead of
+  // two); the 32 x 256 shape keeps one: two of its blocks share a CU
+  static constexpr int EBUFS = MT * NT > 1 ? 2 : 1;
+  static constexpr int LDS_FLOATS = 2 * SLAB > EBUFS * EPI ? 2 * SLAB : EBUFS * EPI;
   static_assert(RP2 >= 8 * P, "planes overlap");
 };
 
@@ -581,33 +584,44 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   // (lanes 0-31 of a store: 512 contiguous bytes of one row).  Against the row-major tiles with 4-byte accesses of
   // round 2 (16 writes + 18 reads per thread and tile in 3 passes, ~2 us per tile with the matrix pipes idle:
   // tools/wino_trace2.py) this is a quarter of the LDS instructions and a third of the address arithmetic.
-  float* E = lds;
   const int eth = tid >> 8, erq = (tid >> 5) & 7, ecol = tid & 31;       // reader item (threads 512 .. 767 idle)
   const bool eact = tid < 512;
+  // bias and first residual of a sub-tile's 4 rows are requested one sub-tile ahead (the weight registers are free
+  // now): an HBM round trip is longer than one exchange
+  float bpre[2][4];
+  u32x4 rpre[2][4];
+  auto request = [&](int mt, int nt, float (&bp)[4], u32x4 (&rp)[4]) {
+    const int corow = co0 + mt * 32 + 4 * erq;
+    const int v0 = tb * (4 * W_BT) + (nt * 64 + eth * 32 + ecol) * 4;
+    const bool colok = eact && (v0 + 3) * dil + ph < len;
+    const unsigned coloff = (pm ? (unsigned)(ph * lp) : 0u) + (unsigned)v0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      bp[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+          rbias, (eact && corow + i < cout) ? (unsigned)(corow + i) * 4u : 0x80000000u, 0, 0));
+    if (vec && nres > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = colok && corow + i < cout;
+        rp[i] = __builtin_amdgcn_raw_buffer_load_b128(
+            rr0, ok ? ((unsigned)(corow + i) * (unsigned)opitch + coloff) * 4u : 0x80000000u, 0, 0);
+      }
+    }
+  };
+  request(0, 0, bpre[0], rpre[0]);
+  __syncthreads();                                   // every wave is out of the K loop: the slab space is free
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      __syncthreads();
-      // bias and first residual of this thread's 4 rows: requested here so that their latency hides under the exchange
+      constexpr int kEB = Cfg::EBUFS;
+      const int sub = mt * NT + nt;
+      float* E = lds + (kEB == 2 ? (sub & 1) * Cfg::EPI : 0);
+      if (kEB == 1 && sub > 0) __syncthreads();      // (one buffer: the readers of the previous sub-tile must be done)
       const int corow = co0 + mt * 32 + 4 * erq;                        // + i
       const int v0 = tb * (4 * W_BT) + (nt * 64 + eth * 32 + ecol) * 4;   // decimated index of y[0]
       const bool colok = eact && (v0 + 3) * dil + ph < len;
-      const unsigned coloff = (pm ? (unsigned)(ph * lp) : 0u) + (unsigned)v0;
-      float bpre[4];
-      u32x4 rpre[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        bpre[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            rbias, (eact && corow + i < cout) ? (unsigned)(corow + i) * 4u : 0x80000000u, 0, 0));
-      if (vec && nres > 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool ok = colok && corow + i < cout;
-          rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(
-              rr0, ok ? ((unsigned)(corow + i) * (unsigned)opitch + coloff) * 4u : 0x80000000u, 0, 0);
-        }
-      }
+      if (sub + 1 < MT * NT) request((sub + 1) / NT, (sub + 1) % NT, bpre[(sub + 1) & 1], rpre[(sub + 1) & 1]);
       {
         float* ew = E + ((th * 6 + xi) * 32 + l31) * W_EP + 4 * lh;
 #pragma unroll
@@ -631,14 +645,14 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
         for (int i = 0; i < 4; ++i) {
           const int co = corow + i;
           const bool rowok = co < cout;
-          const float bv = bpre[i];
+          const float bv = bpre[sub & 1][i];
           const unsigned rowoff = (unsigned)co * (unsigned)opitch + (pm ? (unsigned)(ph * lp) : 0u);
           const float y[4] = {y0[i], y1[i], y2[i], y3[i]};
           if (vec && colok) {
             const unsigned off = rowok ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
             f32x4 o = {y[0] + bv, y[1] + bv, y[2] + bv, y[3] + bv};
             if (nres > 0) {
-              u32x4 t = rpre[i];
+              u32x4 t = rpre[sub & 1][i];
               f32x4 rs = {__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
               if (nres > 1) {
                 t = __builtin_amdgcn_raw_buffer_load_b128(rr1, off, 0, 0);
