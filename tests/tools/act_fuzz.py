@@ -1,5 +1,6 @@
 """Randomised check of fh_act1d_grouped_pm_f32 (plain / phase-major in and out, ragged lengths, several groups)
-against the oracle's Activation1d.  python tests/tools/act_fuzz.py [n_cases] [seed]"""
+against the oracle's Activation1d.  python tests/tools/act_fuzz.py [n_cases] [seed] [wide]
+wide: phase-major dilations up to 16 on either side and rows of up to 20 000 samples (several tiles per row at every dilation)."""
 import sys, random, torch
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, synth, vocoder as V
@@ -7,12 +8,17 @@ from oracle import ref_cpu
 DEV = torch.device('cuda:0')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
 filt = synth.kaiser_sinc_filter()
 worst = 0.0
 for case in range(n_cases):
     B, C, G = rng.choice([1, 2, 3]), rng.choice([1, 3, 8]), rng.choice([1, 2, 3])
     L = rng.choice([rng.randint(1, 30), rng.randint(31, 1100), rng.randint(1101, 5000)])
     din, dout = rng.choice([(1, 1), (1, 3), (3, 1), (1, 5), (5, 1), (2, 1), (1, 2), (3, 5)])
+    if WIDE:
+        d = rng.choice([4, 6, 7, 9, 11, 13, 16])
+        din, dout = rng.choice([(1, d), (d, 1), (d, rng.choice([3, 8, 16]))])
+        L = rng.choice([rng.randint(1, 200), rng.randint(900, 2200), rng.randint(2201, 20000)])
     kind = rng.choice(["snakebeta_log", "snake_lin"])
     g = torch.Generator().manual_seed(1000 + case)
     keep, refs, groups, outs = [], [], [], []
