@@ -179,6 +179,7 @@ def main():
     cfg = synth.SYNTH_CFG
     sd = synth.make_state_dict(cfg, 0)
     model = FlowHighSR(FLowHigh(sd, cfg, dev), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
+    act_blocks = model.flowhigh.vocoder.act_blocks
     B = args.batch if args.batch is not None else conf["per_gpu"]
     n_frames = int(SECS * 100)
     n_in, t48 = int(SECS * sr_in), int(SECS * 48000)
@@ -283,6 +284,7 @@ def main():
                        "parallelism": (f"{n_clips} clips on rank 0, RCCL P2P scatter -> generate -> gather, x{world}"
                                        if conf["sharded"] else f"clip-sharded x{world}, no data-path collective"),
                        "rccl_world_size": world if dist is not None else None,
+                       "act_blocks_per_cu": act_blocks,       # 0 = no cap; vocoder.calibrate_act_occupancy (same bits either way)
                        "sharded_check": None},
             "roofline": {"bound": "mfma",
                          "kernel": "conv_wino_kernel + conv_mfma_kernel (all conv launches of BigVGAN: 97 % of the path's FLOPs)",

@@ -443,7 +443,45 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   }
 }
 
+// Occupancy cap (fh_act_set_blocks_per_cu).  At its natural 7 blocks (28 waves) per CU this kernel keeps the vector ALUs, the
+// LDS and HBM busy at once, and on some MI355X boxes the power management answers with a lower shader clock that outlasts the
+// NEXT launch: a Winograd launch that follows an activation launch then runs at 2.11 instead of 2.38 GHz (+14 % time), far more
+// than the activation launch itself costs (tools/clock_dip_probe.py; a device copy of the same bytes does not do it).  With 3-4
+// blocks per CU the activation is as fast on those boxes and the dip mostly gone; on boxes without the dip the cap costs the
+// activation 10-25 %.  So it is a per-device run-time setting that the host calibrates (vocoder.calibrate_act_occupancy): the
+// launchers ask for UNUSED dynamic LDS so that only the wanted number of blocks fits the CU's 160 KB.
+std::atomic<int> g_act_blocks_per_cu[FH_MAX_DEVICES];
+
+unsigned act_pad_lds_bytes() {          // static LDS of the variants: 12.7-17.2 KB; total must lie in (160 KB / (n + 1), 160 KB / n]
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) return 0u;
+  switch (g_act_blocks_per_cu[dev].load(std::memory_order_relaxed)) {
+    case 5: return 15u * 1024u;
+    case 4: return 22u * 1024u;
+    case 3: return 36u * 1024u;
+    case 2: return 44u * 1024u;
+    default: return 0u;
+  }
+}
+
 }  // namespace
+
+extern "C" int fh_act_set_blocks_per_cu(int blocks) {
+  FH_CHECK_ARG(blocks == 0 || (blocks >= 2 && blocks <= 5), "fh_act_set_blocks_per_cu: %d (0 = no cap, or 2..5)", blocks);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) {
+    fh_set_error("fh_act_set_blocks_per_cu: no current HIP device (or ordinal >= %d)", FH_MAX_DEVICES);
+    return FH_E_LAUNCH;
+  }
+  g_act_blocks_per_cu[dev].store(blocks, std::memory_order_relaxed);
+  return FH_OK;
+}
+
+extern "C" int fh_act_get_blocks_per_cu(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) return 0;
+  return g_act_blocks_per_cu[dev].load(std::memory_order_relaxed);
+}
 
 extern "C" int fh_sizeof_act_group(void) { return (int)sizeof(fh_act_group); }
 
@@ -461,11 +499,12 @@ extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups,
   {
     const long long strips = (blocks + ACT_NTILE - 1) / ACT_NTILE;
     const bool vec = (len & 3) == 0;   // rows 16-byte aligned provided the tensors are (checked by the host plan)
+    const unsigned pad = act_pad_lds_bytes();
 #define FH_ACT_LAUNCH(V, PI, PO)                                                                              \
-  hipLaunchKernelGGL((act1d_strip_kernel<V, PI, PO>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
+  hipLaunchKernelGGL((act1d_strip_kernel<V, PI, PO>), dim3((unsigned)strips), dim3(256), pad, (hipStream_t)stream, \
                      groups, batch, channels, len, tiles, blocks, din, dout, n_groups)
 #define FH_ACT_LAUNCH_D(PI, PO, D)                                                                            \
-  hipLaunchKernelGGL((act1d_strip_kernel<true, PI, PO, D>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
+  hipLaunchKernelGGL((act1d_strip_kernel<true, PI, PO, D>), dim3((unsigned)strips), dim3(256), pad, (hipStream_t)stream, \
                      groups, batch, channels, len, tiles, blocks, din, dout, n_groups)
     if (din > 1 && dout > 1) FH_ACT_LAUNCH(false, true, true);
     else if (din > 1) {
@@ -496,8 +535,9 @@ extern "C" int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int
   {                                                                  // (row bytes < 2^31: checked by the host plan)
     const long long strips = (total_tiles + ACT_NTILE - 1) / ACT_NTILE;
     const bool vec = all_len_mult4 != 0;
+    const unsigned pad = act_pad_lds_bytes();
 #define FH_ACT_RLAUNCH(V, PI, PO)                                                                                       \
-  hipLaunchKernelGGL((act1d_strip_kernel<V, PI, PO, 0, true>), dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, \
+  hipLaunchKernelGGL((act1d_strip_kernel<V, PI, PO, 0, true>), dim3((unsigned)strips), dim3(256), pad, (hipStream_t)stream, \
                      groups, 1, channels, 0, 1, total_tiles, din, dout, n_groups)
     if (din > 1 && dout > 1) FH_ACT_RLAUNCH(false, true, true);
     else if (din > 1) { if (vec) FH_ACT_RLAUNCH(true, true, false); else FH_ACT_RLAUNCH(false, true, false); }

@@ -83,6 +83,8 @@ _SIGS = {
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_pm_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
     "fh_act_tile_len": [],
+    "fh_act_set_blocks_per_cu": [_I],
+    "fh_act_get_blocks_per_cu": [],
     "fh_act1d_ragged_f32": [_P, _I, _I, _I, _I, C.c_longlong, _I, _P],
     "fh_sizeof_sum_job": [],
     "fh_sum_multi_f32": [_P, _I, C.c_longlong, _P],

@@ -399,6 +399,91 @@ def act1d_grouped(groups, batch, channels, length, device, din=1, dout=1):
     return d
 
 
+# ---- occupancy of the activation launches (fh_act_set_blocks_per_cu) --------------------------------------------------
+# On some MI355X boxes an uncapped activation launch (7 blocks = 28 waves per CU: vector ALUs, LDS and HBM busy at once)
+# makes the power management drop the shader clock for the duration of the NEXT launch: a Winograd launch that follows
+# one runs at 2.11 instead of 2.38 GHz (tools/clock_dip_probe.py, tools/box_probe.sh; a device copy of the same bytes does
+# not do it).  With 3-4 blocks per CU the dip is mostly gone at no cost to the activation on those boxes; on boxes
+# without the dip the cap costs the activation 10-25 %.  So the setting is measured once per device and process.
+# (3 blocks removes a little more of the dip on a synthetic pair but costs the activation launches of a real step 20 %: the
+# step is as fast with 4: tools/exp/occ_ab.sh)
+ACT_BLOCKS_CHOICES = (0, 4)             # 0 = no cap
+_act_blocks = {}                        # device ordinal -> setting in force
+
+
+def pick_act_blocks(pair_us, slack=0.98):
+    """The decision rule: no cap unless a capped setting makes the (activation + conv) pair at least 2 % faster."""
+    best = min(pair_us, key=pair_us.get)
+    return best if best != 0 and pair_us[best] < slack * pair_us[0] else 0
+
+
+def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100):
+    """Average us of one (activation launch, Winograd launch) pair of a mid-network stage's size with the activation capped
+    at `blocks` per CU (synthetic tensors; the launches are the model's: 3 groups, k = 11 / 7 / 3)."""
+    dev = hip.norm_device(device)
+    with hip.device_guard(dev):
+        g = torch.Generator().manual_seed(0)
+        ks = (11, 7, 3)
+        xs = [torch.randn(1, c, length, generator=g).to(dev) for _ in ks]
+        ys = [torch.empty(1, c, length, device=dev) for _ in ks]
+        outs = [torch.empty(1, c, length, device=dev) for _ in ks]
+        bias = torch.zeros(c, device=dev)
+        wcfg, wpad = pick_wino_tile(c)
+        us = [pack_wino_weight(torch.randn(c, c, k, generator=g) * 0.02, wpad).to(dev) for k in ks]
+        gw = hip.to_device_struct_array([make_wino_group([make_wino_seg(ys[i], us[i], c, k)], bias, [], outs[i], c, wpad, length)
+                                         for i, k in enumerate(ks)], dev, hip.WINO3_WS_BYTES)
+        filt = [0.0] * 5 + [0.5, 0.5] + [0.0] * 5
+        p = dict(alpha=torch.ones(c, device=dev), inv_beta=torch.ones(c, device=dev), up=filt, down=filt)
+        ga = hip.to_device_struct_array([make_act_group(xs[i], ys[i], p) for i in range(len(ks))], dev)
+        lib, st = hip.lib(), hip.stream()
+        before = lib.fh_act_get_blocks_per_cu()
+        hip.check(lib.fh_act_set_blocks_per_cu(blocks), "fh_act_set_blocks_per_cu")
+        try:
+            def pair():
+                hip.check(lib.fh_act1d_grouped_pm_f32(ga.data_ptr(), len(ks), 1, c, length, 1, 1, st), "fh_act1d_grouped_pm_f32")
+                hip.check(lib.fh_conv_wino_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg, st), "fh_conv_wino_f32")
+            for _ in range(warm):
+                pair()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                pair()
+            e1.record()
+            torch.cuda.synchronize(dev)
+        finally:
+            hip.check(lib.fh_act_set_blocks_per_cu(before), "fh_act_set_blocks_per_cu")
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def calibrate_act_occupancy(device, force=False):
+    """Choose and set the activation launches' blocks per CU on `device` (once per device and process; FH_ACT_BLOCKS =
+    auto | 0 | 2..5 overrides the measurement).  Returns the setting.  Results do not depend on it, only launch times."""
+    dev = hip.norm_device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        return 0
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _act_blocks and not force:
+        return _act_blocks[idx]
+    env = os.environ.get("FH_ACT_BLOCKS", "auto")
+    if env != "auto":
+        choice = int(env)
+    else:
+        pair_us = {}
+        for round_ in range(2):                      # two alternating passes: the chip's state drifts over the first 100 ms
+            for b in ACT_BLOCKS_CHOICES:
+                t = measure_act_conv_pair(dev, b)
+                pair_us[b] = min(pair_us.get(b, t), t)
+        choice = pick_act_blocks(pair_us)
+        calibrate_act_occupancy.last_measurement = dict(pair_us)
+    with hip.device_guard(dev):
+        hip.check(hip.lib().fh_act_set_blocks_per_cu(choice), "fh_act_set_blocks_per_cu")
+    _act_blocks[idx] = choice
+    return choice
+
+
+calibrate_act_occupancy.last_measurement = None
+
+
 class _PlanBuilder:
     """Builds the launch plan of one [batch, num_mels, n_frames] shape (Vocoder.plan): workspace pool, descriptor
     arrays and the ordered list of launch steps.
@@ -826,6 +911,8 @@ class Vocoder:
         self._ragged = hip.ShapeCache()
         self.conv_timing = None
         self.act_timing = None
+        # blocks per CU of the activation launches on this device (measured once per device and process: see above)
+        self.act_blocks = calibrate_act_occupancy(self.device)
 
     def conv_flops_per_frame(self):
         """Algorithmic FLOPs of the MFMA conv launches per mel frame (SURVEY.md 8d formula:

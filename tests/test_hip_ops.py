@@ -327,6 +327,57 @@ def test_act1d_phase_major(L, din, dout):
 
 
 @pytest.mark.parametrize("din,dout", [(1, 1), (3, 1), (1, 5)])
+def test_act1d_occupancy_cap_gives_the_same_bits(din, dout):
+    """fh_act_set_blocks_per_cu is a launch-time knob (unused dynamic LDS limits the resident blocks): every setting
+    writes the same bits; values outside 0, 2..5 are refused."""
+    B, C, L = 2, 16, 5003
+    filt = synth.kaiser_sinc_filter()
+    x = rnd(B, C, L, seed=180, scale=1.5)
+    p = dict(alpha=(rnd(C, seed=181).abs() + 0.5).to(DEV), inv_beta=(rnd(C, seed=182).abs() + 0.5).to(DEV),
+             up=filt.flatten().tolist(), down=filt.flatten().tolist())
+    xd = (V.to_phase_major(x, din) if din > 1 else x).to(DEV)
+    lib = hip.lib()
+    before = lib.fh_act_get_blocks_per_cu()
+    outs = []
+    try:
+        for blocks in (0, 5, 4, 3, 2):
+            hip.check(lib.fh_act_set_blocks_per_cu(blocks))
+            assert lib.fh_act_get_blocks_per_cu() == blocks
+            yd = torch.full((B, C, dout * V.phase_len(L, dout) if dout > 1 else L), float("nan"), device=DEV)
+            keep = V.act1d_grouped([V.make_act_group(xd, yd, p)], B, C, L, DEV, din, dout)
+            torch.cuda.synchronize()
+            outs.append(V.from_phase_major(yd.cpu(), dout, L) if dout > 1 else yd.cpu())
+            del keep
+        assert lib.fh_act_set_blocks_per_cu(7) != 0 and lib.fh_act_set_blocks_per_cu(1) != 0
+        assert lib.fh_act_get_blocks_per_cu() == 2
+    finally:
+        hip.check(lib.fh_act_set_blocks_per_cu(before))
+    assert bool(torch.isfinite(outs[0]).all())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_act_occupancy_calibration_measures_and_sets_a_cap(monkeypatch):
+    """vocoder.calibrate_act_occupancy: three (activation, conv) pair timings, the rule's choice in force on the device."""
+    monkeypatch.delenv("FH_ACT_BLOCKS", raising=False)
+    lib = hip.lib()
+    before = lib.fh_act_get_blocks_per_cu()
+    try:
+        choice = V.calibrate_act_occupancy(DEV, force=True)
+        m = V.calibrate_act_occupancy.last_measurement
+        assert set(m) == set(V.ACT_BLOCKS_CHOICES) and all(100.0 < t < 5000.0 for t in m.values()), m
+        assert choice == V.pick_act_blocks(m) and lib.fh_act_get_blocks_per_cu() == choice
+        monkeypatch.setenv("FH_ACT_BLOCKS", "3")
+        assert V.calibrate_act_occupancy(DEV, force=True) == 3 and lib.fh_act_get_blocks_per_cu() == 3
+        assert V.calibrate_act_occupancy(DEV) == 3                          # cached per device
+    finally:
+        monkeypatch.delenv("FH_ACT_BLOCKS", raising=False)
+        V._act_blocks.pop(DEV.index if DEV.index is not None else 0, None)
+        hip.check(lib.fh_act_set_blocks_per_cu(before))
+        V._act_blocks[DEV.index if DEV.index is not None else 0] = before
+
+
+@pytest.mark.parametrize("din,dout", [(1, 1), (3, 1), (1, 5)])
 def test_act1d_huge_arguments_take_the_accurate_sine(din, dout):
     """|x alpha| >= 32768 leaves the range of the kernel's Cody-Waite reduction: those pairs are recomputed
     with sinf (one test per tile).  A few such samples among ordinary ones, all layouts, vs the oracle

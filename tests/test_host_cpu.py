@@ -201,6 +201,15 @@ def test_on_device_runs_methods_under_the_models_device(monkeypatch):
             assert hasattr(getattr(cls, n), "__wrapped__"), f"{cls.__name__}.{n} is not under hip.on_device"
 
 
+def test_act_occupancy_rule_keeps_the_default_unless_a_cap_pays():
+    from flowhigh_amd import vocoder as V
+    assert V.pick_act_blocks({0: 615.0, 4: 590.0}) == 4                  # a box with the clock dip
+    assert V.pick_act_blocks({0: 615.0, 4: 590.0, 3: 562.0}) == 3
+    assert V.pick_act_blocks({0: 540.0, 4: 548.0}) == 0                  # a box without it
+    assert V.pick_act_blocks({0: 600.0, 4: 592.0}) == 0                  # within 2 %: keep the default
+    assert V.calibrate_act_occupancy(torch.device("cpu")) == 0            # nothing to set without a GPU
+
+
 def test_norm_device_pins_the_ordinal():
     from flowhigh_amd import hip
     assert hip.norm_device("cuda:2") == torch.device("cuda", 2)

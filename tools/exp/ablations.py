@@ -53,6 +53,10 @@ ACT_DOWN = ('''        f32x2 a2 = {0.f, 0.f};
       // outputs whose taps leave''', '''        out[r] = zv[2 * r + 8];                    // ablation: no down filter
       }
       // outputs whose taps leave''')
+def act_occ(dyn_bytes):      # unused dynamic LDS per block: limits the resident blocks per CU (12.7 KB static + this, of 160 KB)
+    return ("dim3(256), 0, (hipStream_t)stream", f"dim3(256), {dyn_bytes}, (hipStream_t)stream")
+
+
 RECIPES = {
     "wino_notransform": ("conv_wino.hip", [WINO_T]),
     "wino_noweights": ("conv_wino.hip", [WINO_A]),
@@ -64,6 +68,10 @@ RECIPES = {
     "act_noup": ("act1d.hip", [ACT_UP]),
     "act_nodown": ("act1d.hip", [ACT_DOWN]),
     "act_dataonly": ("act1d.hip", [ACT_UP, ACT_DOWN]),
+    "act_occ5": ("act1d.hip", [act_occ(18 * 1024)]),     # 5 blocks (20 waves) per CU instead of 7
+    "act_occ4": ("act1d.hip", [act_occ(26 * 1024)]),
+    "act_occ3": ("act1d.hip", [act_occ(38 * 1024)]),
+    "act_occ2": ("act1d.hip", [act_occ(50 * 1024)]),
 }
 
 

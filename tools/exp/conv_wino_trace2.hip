@@ -596,19 +596,23 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   // tools/wino_trace2.py) this is a quarter of the LDS instructions and a third of the address arithmetic.
   const int eth = tid >> 8, erq = (tid >> 5) & 7, ecol = tid & 31;       // reader item (threads 512 .. 767 idle)
   const bool eact = tid < 512;
-  // bias and first residual of a sub-tile's 4 rows are requested one sub-tile ahead (the weight registers are free
-  // now): an HBM round trip is longer than one exchange
-  float bpre[2][4];
-  u32x4 rpre[2][4];
-  auto request = [&](int mt, int nt, float (&bp)[4], u32x4 (&rp)[4]) {
+  // The bias of a thread's rows (all of them now) and the first residual of a sub-tile's 4 rows TWO sub-tiles ahead
+  // (the weight registers are free): under load an HBM round trip takes 1.5-2 us, an exchange 1.2 (tools/wino_trace2.py)
+  constexpr int kRB = MT * NT < 3 ? MT * NT : MT == 4 ? 2 : 3;      // residual buffers (128-row tile: 2, registers); requests run kRB - 1 ahead
+  float bpre[MT][4];
+  u32x4 rpre[kRB][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = co0 + mt * 32 + 4 * erq + i;
+      bpre[mt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, (eact && co < cout) ? (unsigned)co * 4u : 0x80000000u, 0, 0));
+    }
+  auto request = [&](int mt, int nt, u32x4 (&rp)[4]) {
     const int corow = co0 + mt * 32 + 4 * erq;
     const int v0 = tb * (4 * W_BT) + (nt * 64 + eth * 32 + ecol) * 4;
     const bool colok = eact && (v0 + 3) * dil + ph < len;
     const unsigned coloff = (pm ? (unsigned)(ph * lp) : 0u) + (unsigned)v0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      bp[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-          rbias, (eact && corow + i < cout) ? (unsigned)(corow + i) * 4u : 0x80000000u, 0, 0));
     if (vec && nres > 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -618,7 +622,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       }
     }
   };
-  request(0, 0, bpre[0], rpre[0]);
+  request(0, 0, rpre[0]);
+  if (kRB > 2) request(1 / NT, 1 % NT, rpre[1]);
   __syncthreads();                                   // every wave is out of the K loop: the slab space is free
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -633,7 +638,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       const int corow = co0 + mt * 32 + 4 * erq;                        // + i
       const int v0 = tb * (4 * W_BT) + (nt * 64 + eth * 32 + ecol) * 4;   // decimated index of y[0]
       const bool colok = eact && (v0 + 3) * dil + ph < len;
-      if (sub + 1 < MT * NT) request((sub + 1) / NT, (sub + 1) % NT, bpre[(sub + 1) & 1], rpre[(sub + 1) & 1]);
+      if (kRB > 1 && sub + kRB - 1 < MT * NT) request((sub + kRB - 1) / NT, (sub + kRB - 1) % NT, rpre[(sub + kRB - 1) % kRB]);
       {
         float* ew = E + ((th * 6 + xi) * 32 + l31) * W_EP + 4 * lh;
 #pragma unroll
@@ -658,14 +663,14 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
         for (int i = 0; i < 4; ++i) {
           const int co = corow + i;
           const bool rowok = co < cout;
-          const float bv = bpre[sub & 1][i];
+          const float bv = bpre[mt][i];
           const unsigned rowoff = (unsigned)co * (unsigned)opitch + (pm ? (unsigned)(ph * lp) : 0u);
           const float y[4] = {y0[i], y1[i], y2[i], y3[i]};
           if (vec && colok) {
             const unsigned off = rowok ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
             f32x4 o = {y[0] + bv, y[1] + bv, y[2] + bv, y[3] + bv};
             if (nres > 0) {
-              u32x4 t = rpre[sub & 1][i];
+              u32x4 t = rpre[sub % kRB][i];
               f32x4 rs = {__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
               if (nres > 1) {
                 t = __builtin_amdgcn_raw_buffer_load_b128(rr1, off, 0, 0);

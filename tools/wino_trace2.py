@@ -31,6 +31,18 @@ buf = torch.zeros(1 + NW * 200000, dtype=torch.int64, device=DEV)
 # sustained clock (tools/wino_sustained.py); WARM=20 (12 ms, then a sync) is what the round-3 tables were taken with
 import os
 warm = int(os.environ.get("WARM", "20"))
+# ALT=1: every warm-up conv launch is preceded by an activation launch of the same tensors (the model's alternation), and so is
+# the traced one: on some boxes of the pool a conv launch that follows an activation launch is 14 % slower (tools/box_probe.sh)
+if os.environ.get("ALT", "0") == "1":
+    from flowhigh_amd import synth
+    filt = synth.kaiser_sinc_filter().flatten().tolist()
+    pa = dict(alpha=torch.rand(c, device=DEV) + 0.5, inv_beta=torch.rand(c, device=DEV) + 0.5, up=filt, down=filt)
+    ya = [torch.empty(B, c, L, device=DEV) for _ in KS]
+    ga = hip.to_device_struct_array([V.make_act_group(res[i], ya[i], pa) for i in range(3)], DEV)
+    conv_only = run
+    def run():
+        hip.check(lib.fh_act1d_grouped_pm_f32(ga.data_ptr(), 3, B, c, L, 1, 1, st))
+        conv_only()
 for _ in range(warm): run()
 if warm <= 20: torch.cuda.synchronize()
 hip.check(lib.fh_debug_set_wino_trace(buf.data_ptr()))
