@@ -3,6 +3,13 @@
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
+# the activation occupancy cap is measured once here and fixed for the profiled runs (otherwise the ~640 calibration
+# launches of every process would sit in the kernel statistics)
+export FH_ACT_BLOCKS=$(python3 -c "
+import sys; sys.path.insert(0, '.')
+from flowhigh_amd import vocoder as V
+print(V.calibrate_act_occupancy('cuda:0'))" 2>/dev/null | tail -1)
+echo "FH_ACT_BLOCKS=$FH_ACT_BLOCKS"
 out=gpurun_out/pmc_$tag; rm -rf $out; mkdir -p $out
 i=0
 for set in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \

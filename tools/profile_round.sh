@@ -4,6 +4,13 @@
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
+# the activation occupancy cap is measured once here and fixed for the profiled runs (otherwise the ~640 calibration
+# launches of every process would sit in the kernel statistics)
+export FH_ACT_BLOCKS=$(python3 -c "
+import sys; sys.path.insert(0, '.')
+from flowhigh_amd import vocoder as V
+print(V.calibrate_act_occupancy('cuda:0'))" 2>/dev/null | tail -1)
+echo "FH_ACT_BLOCKS=$FH_ACT_BLOCKS"
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-alt > $out/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt > $out/pmc_fetch.log 2>&1
