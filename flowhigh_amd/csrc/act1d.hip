@@ -446,9 +446,9 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
 // Occupancy cap (fh_act_set_blocks_per_cu).  At its natural 7 blocks (28 waves) per CU this kernel keeps the vector ALUs, the
 // LDS and HBM busy at once, and on some MI355X boxes the power management answers with a lower shader clock that outlasts the
 // NEXT launch: a Winograd launch that follows an activation launch then runs at 2.11 instead of 2.38 GHz (+14 % time), far more
-// than the activation launch itself costs (tools/clock_dip_probe.py; a device copy of the same bytes does not do it).  With 3-4
-// blocks per CU the activation is as fast on those boxes and the dip mostly gone; on boxes without the dip the cap costs the
-// activation 10-25 %.  So it is a per-device run-time setting that the host calibrates (vocoder.calibrate_act_occupancy): the
+// than the activation launch itself costs (tools/clock_dip_probe.py; a device copy of the same bytes does not do it).  With 3
+// blocks per CU most of the dip is gone (a step is 5-7 % faster on such a box); on boxes without the dip the cap costs the
+// activation 25 %.  So it is a per-device run-time setting that the host calibrates (vocoder.calibrate_act_occupancy): the
 // launchers ask for UNUSED dynamic LDS so that only the wanted number of blocks fits the CU's 160 KB.
 std::atomic<int> g_act_blocks_per_cu[FH_MAX_DEVICES];
 

@@ -403,11 +403,12 @@ def act1d_grouped(groups, batch, channels, length, device, din=1, dout=1):
 # On some MI355X boxes an uncapped activation launch (7 blocks = 28 waves per CU: vector ALUs, LDS and HBM busy at once)
 # makes the power management drop the shader clock for the duration of the NEXT launch: a Winograd launch that follows
 # one runs at 2.11 instead of 2.38 GHz (tools/clock_dip_probe.py, tools/box_probe.sh; a device copy of the same bytes does
-# not do it).  With 3-4 blocks per CU the dip is mostly gone at no cost to the activation on those boxes; on boxes
-# without the dip the cap costs the activation 10-25 %.  So the setting is measured once per device and process.
-# (3 blocks removes a little more of the dip on a synthetic pair but costs the activation launches of a real step 20 %: the
-# step is as fast with 4: tools/exp/occ_ab.sh)
-ACT_BLOCKS_CHOICES = (0, 4)             # 0 = no cap
+# not do it).  With 3 blocks per CU the dip is mostly gone (on such a box the capped activation is 10-15 % slower, the convs
+# 10 % faster); on boxes without the dip the cap would only cost the activation 25 %.  So the setting is measured once per device and process.
+# (tools/exp/occ_ab.sh on both kinds of affected boxes: 4 blocks help on one kind only (bench 500 -> 527) and do nothing on the
+# other (the clock is clamped as before); 3 blocks help on both (488 -> 522, 500 -> 524); 2 blocks: the activation itself
+# is too slow then (512))
+ACT_BLOCKS_CHOICES = (0, 3)             # 0 = no cap
 _act_blocks = {}                        # device ordinal -> setting in force
 
 

@@ -241,7 +241,7 @@ int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, 
 /* Occupancy cap of the activation launches on the CURRENT device: at most `blocks` (2 .. 5) 4-wave blocks per CU, 0 = no cap
  * (7, the default).  A tuning knob, not a semantic one (results are the same bits): on some MI355X boxes the uncapped launch
  * draws enough power that the shader clock drops for the duration of the NEXT launch (a Winograd conv then takes 14 % longer);
- * 3-4 blocks per CU avoid that at no cost to the activation there, and cost it 10-25 % on boxes without the effect.  No
+ * 3 blocks per CU avoid most of that (the step is 5-7 % faster there) and cost the activation 25 % on boxes without the effect.  No
  * reference counterpart; the host calibrates it once per device (flowhigh_amd/vocoder.py: calibrate_act_occupancy,
  * FH_ACT_BLOCKS). */
 int fh_act_set_blocks_per_cu(int blocks);
