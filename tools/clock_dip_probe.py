@@ -67,3 +67,22 @@ for name, fn in cases:
     torch.cuda.synchronize()
     t = sorted(a.elapsed_time(b) * 1e3 for a, b in ce)
     print(f"{name:44s} ({dur:6.1f} us each): conv launch median {t[len(t) // 2]:6.1f} us, p10 {t[30]:6.1f}, p90 {t[270]:6.1f}")
+
+# how long does the lower clock last?  one activation launch, then four conv launches back to back
+if not os.environ.get("ONLY_ACT"):
+    time.sleep(0.3)
+    for _ in range(60):
+        act()
+        for _ in range(4): conv()
+    rows = []
+    for _ in range(100):
+        act()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        for k in range(4):
+            conv(); ev[k + 1].record()
+        rows.append(ev)
+    torch.cuda.synchronize()
+    med = lambda v: sorted(v)[len(v) // 2]
+    print("one activation launch, then four conv launches: median us of the 1st .. 4th:",
+          " ".join(f"{med([r[k].elapsed_time(r[k + 1]) * 1e3 for r in rows]):6.1f}" for k in range(4)))
