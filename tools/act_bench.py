@@ -3,6 +3,9 @@ import sys, torch
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, synth, vocoder as V
 DEV = torch.device('cuda:0')
+import os
+if os.environ.get('FH_ACT_BLOCKS', 'auto') != 'auto':          # (no Vocoder here: force the occupancy cap by hand)
+    hip.check(hip.lib().fh_act_set_blocks_per_cu(int(os.environ['FH_ACT_BLOCKS'])))
 filt = synth.kaiser_sinc_filter().flatten().tolist()
 def bench(fn, reps=20):
     for _ in range(3): fn()
