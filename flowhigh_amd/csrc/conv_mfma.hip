@@ -31,10 +31,6 @@ namespace {
 
 constexpr int NT_RUN = 8;       // n-tiles of a panel that run together on one XCD
 
-// Debug hook (fh_debug_set_conv_trace): when set, every block appends {blockIdx | hw_id << 32,
-// start, end (100 MHz s_memrealtime ticks), K steps} to this buffer: [0] = record counter.
-__device__ unsigned long long* g_conv_trace = nullptr;
-
 template <int MT, int NT, int WM, int WN, int CK>
 struct ConvCfg {
   static constexpr int BM = 32 * MT * WM;
@@ -74,9 +70,6 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   float* ws = lds;
   float* xs = lds + 2 * BM * WP;
   int* toff = reinterpret_cast<int*>(lds + Cfg::LDS_FLOATS);   // [seg][tap] column shift of each tap
-
-  unsigned long long* const trace = g_conv_trace;
-  const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // ---- block -> (panel, n tile); panels = (group, batch, co tile), heavy groups first ----
   const int panels = n_groups * batch * co_tiles;
@@ -343,18 +336,6 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q][nt] * scale), ro, off[q][nt], 0, 0);
     }
   }
-  if (trace && tid == 0) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned long long slot = atomicAdd(trace, 1ull);
-    unsigned long long* r = trace + 1 + 4 * slot;
-    r[0] = (unsigned long long)blockIdx.x | ((unsigned long long)(hw & 0xffffff) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
-    r[1] = t_start;
-    r[2] = __builtin_amdgcn_s_memrealtime();
-    r[3] = (unsigned long long)nsteps;
-  }
 }
 
 template <int MT, int NT, int WM, int WN, int CK>
@@ -439,16 +420,6 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 }  // namespace
 
 extern "C" int fh_sizeof_conv_group(void) { return (int)sizeof(fh_conv_group); }
-
-extern "C" int fh_debug_set_conv_trace(void* buf) {
-  unsigned long long* p = (unsigned long long*)buf;
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_conv_trace), &p, sizeof(p));
-  if (e != hipSuccess) {
-    fh_set_error("fh_debug_set_conv_trace: %s", hipGetErrorString(e));
-    return FH_E_LAUNCH;
-  }
-  return FH_OK;
-}
 
 extern "C" int fh_conv_tile_m(int cfg) { return (cfg >= 0 && cfg < kNumTiles) ? kTiles[cfg].bm : -1; }
 extern "C" int fh_conv_tile_n(int cfg) { return (cfg >= 0 && cfg < kNumTiles) ? kTiles[cfg].bn : -1; }

@@ -40,10 +40,6 @@
 
 #include <type_traits>
 
-#ifdef FH_WINO_EXPERIMENTS          // tools/exp/build_wino_variants.sh: tiles 8 / 9 (tools/exp/conv_wino2.hip, conv_wino3.hip)
-#include "conv_wino_int.h"
-#endif
-
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -112,9 +108,8 @@ struct WCfg {
   static_assert(RP2 >= 8 * P, "planes overlap");
 };
 
-// Rows of B^T, canonical arithmetic shared by every Winograd kernel of this library (conv_wino2.hip computes all six
-// rows in one wave with the common sub-expressions p, q shared between rows 1/2 and 3/4; both forms round alike, so
-// a conv gives the same bits whatever kernel / tile shape the launch plan picks):
+// Rows of B^T, canonical arithmetic shared by every tile shape of this kernel (rows 1/2 and 3/4 share the
+// sub-expressions p, q; a conv gives the same bits whatever tile shape the launch plan picks):
 //     p = fma(alpha, x[i], x[j]);  q = fma(beta, x[k], x[l]);  v = fma(gamma, q, p)
 //   row 0:  4 x0 - 5 x2 + x4 = fma(4, x0, fma(-5, x2, x4))            (q = x0: beta = 0)
 //   row 1: -4 x1 - 4 x2 + x3 + x4 = (x4 - 4 x2) + (x3 - 4 x1)
@@ -127,13 +122,10 @@ __device__ const int kBtOff[6][4] = {{2, 4, 0, 0}, {2, 4, 1, 3}, {2, 4, 1, 3}, {
 __device__ const float kBtCoef[6][3] = {{-5.f, 0.f, 4.f}, {-4.f, -4.f, 1.f}, {-4.f, -4.f, -1.f},
                                         {-1.f, -1.f, 2.f}, {-1.f, -1.f, -2.f}, {-5.f, 0.f, 4.f}};
 
-// Debug hook (fh_debug_set_wino_trace): as fh_debug_set_conv_trace, per wave of every block.
-__device__ unsigned long long* g_wino_trace = nullptr;
-
 struct WSeg {
   const float* x;
   const float* u;
-  int cin, ngrp, center;
+  int cin, ngrp, center, xlen;
 };
 __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
   WSeg w;
@@ -142,6 +134,7 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
   w.cin = uni(S->cin);
   w.ngrp = uni(S->ngrp);
   w.center = uni(S->center);
+  w.xlen = uni(S->xlen);
   return w;
 }
 
@@ -160,9 +153,6 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   constexpr int W_BM = Cfg::BM, W_BT = Cfg::BT, W_P = Cfg::P, W_RP2 = Cfg::RP2, W_XPT = Cfg::XPT, W_SLAB = Cfg::SLAB;
   constexpr int W_SUB = (W_CK / 2) * W_RP2;          // floats of one 16-channel chunk inside a slab buffer
   extern __shared__ __attribute__((aligned(16))) float lds[];      // Cfg::LDS_FLOATS
-  unsigned long long* const trace = g_wino_trace;
-  const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
   // ---- block -> (panel, n block); panels = (group, batch, co tile), heavy groups first ----------
   const int panels = n_groups * batch * co_tiles;
@@ -250,15 +240,18 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const int lrow = tid / 48, ltt = tid % 48;
   const int lds_st = (lrow >> 1) * W_RP2 + ((ltt & 3) * W_P + (ltt >> 2)) * 2 + (lrow & 1);   // + 24 i
   unsigned xreg[W_XPT];
+  // (S.xlen > 0: the segment's rows are xlen samples long, not len -- a transposed-conv phase whose output has one
+  // sample more than u * its input, plain layout only)
   auto load_x = [&](const WSeg& S, int chunk, bool valid) {
+    const int xl = S.xlen > 0 ? S.xlen : len, xp = S.xlen > 0 ? S.xlen : pitch;
     const __amdgpu_buffer_rsrc_t r =
-        make_rsrc(uni(S.x + (size_t)b * S.cin * pitch), valid ? (unsigned)(S.cin * pitch) * 4u : 0u);
+        make_rsrc(uni(S.x + (size_t)b * S.cin * xp), valid ? (unsigned)(S.cin * xp) * 4u : 0u);
     const int ub = tb * (4 * W_BT) - S.center;                           // first staged decimated index (uniform)
     const int posb = ub * dil + ph;                                      // ... and its position in the clip
-    const int rowoff = (chunk * W_CK + lrow) * pitch;
+    const int rowoff = (chunk * W_CK + lrow) * xp;
     const int estride = pm ? 1 : dil;                                    // element stride of consecutive u
     const int eoff0 = rowoff + (pm ? ph * lp + ub + ltt : posb + ltt * dil);
-    if (posb >= 0 && posb + (48 * W_XPT - 1) * dil < len) {               // block interior: no per-sample checks
+    if (posb >= 0 && posb + (48 * W_XPT - 1) * dil < xl) {                // block interior: no per-sample checks
 #pragma unroll
       for (int i = 0; i < W_XPT; ++i)
         xreg[i] = __builtin_amdgcn_raw_buffer_load_b32(r, (unsigned)(eoff0 + 48 * i * estride) * 4u, 0, 0);
@@ -266,7 +259,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #pragma unroll
       for (int i = 0; i < W_XPT; ++i) {
         const int pos = posb + (ltt + 48 * i) * dil;     // outside the clip: out-of-range offset -> 0
-        const unsigned off = (unsigned)pos < (unsigned)len ? (unsigned)(eoff0 + 48 * i * estride) * 4u : 0x80000000u;
+        const unsigned off = (unsigned)pos < (unsigned)xl ? (unsigned)(eoff0 + 48 * i * estride) * 4u : 0x80000000u;
         xreg[i] = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
       }
     }
@@ -285,22 +278,23 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const int vp = tid / 96, vt = tid % 96;
   u32x4 xq[2][2];                                      // [item slot][channel of the pair]
   auto vl_load = [&](const WSeg& S, int chunk, bool valid, int item, int slot) {
+    const int xl = S.xlen > 0 ? S.xlen : len, xp = S.xlen > 0 ? S.xlen : pitch;      // (xlen % 4 == 0 here: host)
     const __amdgpu_buffer_rsrc_t r =
-        make_rsrc(uni(S.x + (size_t)b * S.cin * pitch), valid ? (unsigned)(S.cin * pitch) * 4u : 0u);
+        make_rsrc(uni(S.x + (size_t)b * S.cin * xp), valid ? (unsigned)(S.cin * xp) * 4u : 0u);
     const int ub = tb * (4 * W_BT) - S.center;                           // first decimated index needed (>= -5)
     const int q0 = (ub - (ub & 3)) >> 2;                                 // floor(ub / 4)
-    const int rowlen = pm ? lp : len;
+    const int rowlen = pm ? lp : xl;
     const int q = vt + 96 * item, qa = q0 + q;
     const bool ok = q < W_XQ && qa >= 0 && 4 * qa < rowlen;              // (outside the row: zero padding)
-    const int e0 = (chunk * W_CK + 2 * vp) * pitch + (pm ? ph * lp : 0) + 4 * qa;
+    const int e0 = (chunk * W_CK + 2 * vp) * xp + (pm ? ph * lp : 0) + 4 * qa;
     xq[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)e0 * 4u : 0x80000000u, 0, 0);
-    xq[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(e0 + pitch) * 4u : 0x80000000u, 0, 0);
+    xq[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(e0 + xp) * 4u : 0x80000000u, 0, 0);
   };
   auto vl_store = [&](const WSeg& S, int buf, int sub, int item, int slot) {
     const int ub = tb * (4 * W_BT) - S.center;
     const int ua = ub - (ub & 3);                                        // decimated index of slab sample 0
     const int q = vt + 96 * item;
-    const int nvalid = pm ? (len - ph + dil - 1) / dil : len;            // samples of this phase / row
+    const int nvalid = pm ? (len - ph + dil - 1) / dil : (S.xlen > 0 ? S.xlen : len);   // samples of this phase / row
     if (ua + 4 * W_XQ > nvalid) {                                        // last block of the row: zero past the end
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -554,12 +548,10 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       ++sg;
     }
   };
-  const unsigned long long t_loop0 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   run_all(std::integral_constant<int, 4>{});
   run_all(std::integral_constant<int, 3>{});
   run_all(std::integral_constant<int, 2>{});
   run_all(std::integral_constant<int, 1>{});
-  const unsigned long long t_loop1 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // ---- epilogue: exchange M_xi through LDS, y = A^T M, bias + residuals, scale, store ----------
   const int nres = uni(G->nres);
@@ -568,7 +560,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const float* __restrict__ bias = uni(G->bias);
   const int ostride = uni(G->out_stride) > 1 ? uni(G->out_stride) : 1;      // transposed-conv phase: out row = ostride * len
   const int ophase = uni(G->out_phase);
-  const int opitch = pitch * ostride;
+  // out_len > 0: row pitch of out (and res); a transposed conv with an odd (k - u) returns u * len_in + 1 samples per row
+  const int opitch = uni(G->out_len) > 0 ? uni(G->out_len) : pitch * ostride;
   const size_t slab = (size_t)b * cout * opitch;
   const unsigned slab_bytes = (unsigned)cout * (unsigned)opitch * 4u;
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(uni((const float*)G->out) + slab, slab_bytes);
@@ -676,8 +669,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int n = ph + dil * (v0 + q);
-              const unsigned off = (rowok && n < len) ? (rowoff + (unsigned)(pm ? v0 + q : n * ostride + ophase)) * 4u
-                                                      : 0x80000000u;
+              const unsigned off = (rowok && n < len && (ostride == 1 || n * ostride + ophase < opitch))
+                                       ? (rowoff + (unsigned)(pm ? v0 + q : n * ostride + ophase)) * 4u : 0x80000000u;
               float o = y[q] + bv;
               if (nres > 0) {
                 float rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));
@@ -692,19 +685,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       }
     }
   }
-  if (pf == 0x7fc12345u && trace) trace[0] = 0;      // keeps pf alive; never true for weights
-  if (trace && (tid & 63) == 0) {
-    unsigned hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned long long slot = atomicAdd(trace, 1ull);
-    unsigned long long* r = trace + 1 + 5 * slot;
-    r[0] = (unsigned long long)blockIdx.x | ((unsigned long long)(hw & 0xffffff) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
-    r[1] = t_start;
-    r[2] = __builtin_amdgcn_s_memrealtime();
-    r[3] = (unsigned long long)wave | ((t_loop0 - t_start) << 8) | ((t_loop1 - t_start) << 36);
-    r[4] = __builtin_amdgcn_s_memtime() - c_start;       // shader clocks: r[4] / (r[2] - r[1]) x 100 MHz
-  }
+  // (keeps pf alive: the prefetch loads above are never read; never true for finite weights)
+  if (pf == 0x7fc12345u) __builtin_amdgcn_s_sleep(1);
 }
 
 // out = ((a + b) + c) * scale, 4 elements per thread (the reference's xs += ...; xs / n order)
@@ -783,16 +765,6 @@ extern "C" int fh_sum_multi_f32(const fh_sum_job* jobs, int n_jobs, long long ma
   return FH_OK;
 }
 
-extern "C" int fh_debug_set_wino_trace(void* buf) {
-  unsigned long long* p = (unsigned long long*)buf;
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &p, sizeof(p));
-  if (e != hipSuccess) {
-    fh_set_error("fh_debug_set_wino_trace: %s", hipGetErrorString(e));
-    return FH_E_LAUNCH;
-  }
-  return FH_OK;
-}
-
 extern "C" int fh_sizeof_wino_group(void) { return (int)sizeof(fh_wino_group); }
 
 namespace {
@@ -842,7 +814,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
   // (phase_major bit 1: the caller rules the vector loader out -- ragged launches in which some group's rows are
   // not 16-byte aligned; `len` is then only the longest group's length)
   const bool pm = (phase_major & 1) != 0;
-  const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2);
+  const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2);       // (bit 1 also from FH_WINO_NOVL)
   const bool xr = (phase_major & 4) != 0 && !run_map;          // (bit 2, set by wino_dispatch: FH_WINO_XCD_RANGES)
   return vl ? launch_wino_vl<MT, NT, SUBS, true, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs, xr)
             : launch_wino_vl<MT, NT, SUBS, false, BF>(groups, n_groups, batch, cout_pad, len, dilation, pm, stream, run_map, n_runs, xr);
@@ -851,10 +823,7 @@ int launch_wino(const fh_wino_group* groups, int n_groups, int batch, int cout_p
 }  // namespace
 
 extern "C" int fh_wino_tile_m(int tile_cfg) {
-  tile_cfg &= ~(FH_WINO_BF16X6 | FH_WINO_XCD_RANGES);
-#ifdef FH_WINO_EXPERIMENTS
-  if (tile_cfg == 8 || tile_cfg == 9) return 64;
-#endif
+  tile_cfg &= ~(FH_WINO_BF16X6 | FH_WINO_XCD_RANGES | FH_WINO_NOVL);
   return tile_cfg == 6 ? 128 : tile_cfg == 5 ? 32 : tile_cfg == 4 ? 64 : tile_cfg == 1 ? 96 : tile_cfg == 0 ? 64 : -1;
 }
 
@@ -867,31 +836,16 @@ int wino_dispatch(const fh_wino_group* groups, int n_groups, int batch, int cout
     tile_cfg &= ~FH_WINO_XCD_RANGES;
     phase_major |= 4;
   }
+  if (tile_cfg & FH_WINO_NOVL) {
+    tile_cfg &= ~FH_WINO_NOVL;
+    phase_major |= 2;
+  }
   switch (tile_cfg) {
     case 0: return launch_wino<2, 2, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case 1: return launch_wino<3, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case 4: return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case 5: return launch_wino<1, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case 6: return launch_wino<4, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-#ifdef FH_WINO_EXPERIMENTS
-    case 8: {
-      // 64 x 256 tile in 4-wave blocks, six transform points per wave (conv_wino2.hip): vector loads only; launches
-      // that cannot use them run the 12-wave 64 x 256 tile (same block -> work mapping, same bits)
-      const bool pm = (phase_major & 1) != 0;
-      if ((pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2))
-        return fh_wino2_launch(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
-      return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-    }
-    case 9: {
-      // persistent workgroups of two independent 6-wave teams (conv_wino3.hip), 64 x 256 per team tile; same fallback
-      const bool pm = (phase_major & 1) != 0;
-      if ((pm || (dilation == 1 && len % 4 == 0)) && !(phase_major & 2))
-        return fh_wino3_launch(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
-      return launch_wino<2, 1, 1, false>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-    }
-    case FH_WINO_BF16X6 + 9: return launch_wino<2, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-    case FH_WINO_BF16X6 + 8: return launch_wino<2, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
-#endif
     // + FH_WINO_BF16X6: the groups' weights are three-piece bf16 (pack_wino_weight_bf3), six bf16 MFMAs per k-block
     case FH_WINO_BF16X6 + 0: return launch_wino<2, 2, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
     case FH_WINO_BF16X6 + 1: return launch_wino<3, 1, 1, true>(groups, n_groups, batch, cout_pad, len, dilation, phase_major, st, run_map, n_runs);
@@ -913,7 +867,7 @@ extern "C" int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int b
   return wino_dispatch(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0 ? 1 : 0, tile_cfg, (hipStream_t)stream, nullptr, 0);
 }
 
-extern "C" int fh_wino_tile_n(int tile_cfg) { tile_cfg &= ~(FH_WINO_BF16X6 | FH_WINO_XCD_RANGES); return tile_cfg == 0 ? 512 : (fh_wino_tile_m(tile_cfg) > 0 ? 256 : -1); }
+extern "C" int fh_wino_tile_n(int tile_cfg) { tile_cfg &= ~(FH_WINO_BF16X6 | FH_WINO_XCD_RANGES | FH_WINO_NOVL); return tile_cfg == 0 ? 512 : (fh_wino_tile_m(tile_cfg) > 0 ? 256 : -1); }
 extern "C" int fh_wino_run_len(int n_tiles) { return n_tiles > 0 ? fh_cdiv(n_tiles, fh_cdiv(n_tiles, W_RUN)) : -1; }
 
 extern "C" int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,

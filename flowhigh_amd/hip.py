@@ -20,6 +20,7 @@ CONV_MAX_TAPS = 16
 CONV_MAX_SEG = 3
 CONV_MAX_HALO = 64
 
+ABI_VERSION = 2            # FH_ABI_VERSION of include/flowhigh_hip.h
 EPI_LINEAR, EPI_GEGLU, EPI_MAG, EPI_LOGCLAMP = 0, 1, 2, 3
 
 
@@ -37,14 +38,14 @@ class ConvGroup(C.Structure):
 
 class WinoSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("u", C.c_void_p), ("cin", C.c_int32), ("ngrp", C.c_int32),
-                ("center", C.c_int32), ("pad_", C.c_int32)]
+                ("center", C.c_int32), ("xlen", C.c_int32)]
 
 
 class WinoGroup(C.Structure):
     _fields_ = [("seg", WinoSeg * CONV_MAX_SEG), ("bias", C.c_void_p), ("res", C.c_void_p * CONV_MAX_SEG),
                 ("out", C.c_void_p), ("nseg", C.c_int32), ("nres", C.c_int32), ("cout", C.c_int32),
                 ("cout_pad", C.c_int32), ("len", C.c_int32), ("scale", C.c_float), ("out_stride", C.c_int32),
-                ("out_phase", C.c_int32)]
+                ("out_phase", C.c_int32), ("out_len", C.c_int32), ("pad_", C.c_int32)]
 
 
 class ActGroup(C.Structure):
@@ -77,8 +78,6 @@ _SIGS = {
     "fh_conv_wino_ragged_f32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "fh_mean_f32": [_P, _P, _P, _P, C.c_longlong, _F, _P],
     "fh_sum_f32": [_P, C.c_int, _P, C.c_longlong, _F, _P],
-    "fh_debug_set_conv_trace": [_P],
-    "fh_debug_set_wino_trace": [_P],
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_pm_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
@@ -134,7 +133,7 @@ def lib():
         fn.restype = C.c_int
     L.fh_last_error.argtypes = []
     L.fh_last_error.restype = C.c_char_p
-    if L.fh_abi_version() != 1:
+    if L.fh_abi_version() != ABI_VERSION:
         raise HipError("libflowhigh_hip.so ABI version mismatch")
     if L.fh_sizeof_conv_group() != C.sizeof(ConvGroup) or L.fh_sizeof_act_group() != C.sizeof(ActGroup) \
             or L.fh_sizeof_wino_group() != C.sizeof(WinoGroup) or L.fh_sizeof_sum_job() != C.sizeof(SumJob):
@@ -258,9 +257,6 @@ def on_device(fn):
 
 def ptr(t):
     return 0 if t is None else t.data_ptr()
-
-
-WINO3_WS_BYTES = 128          # experiment builds only (tools/exp/conv_wino3.hip): zeroed bytes behind a descriptor array
 
 
 def to_device_struct_array(structs, device, tail_bytes=0):

@@ -50,6 +50,24 @@ ALT2_CFG = dict(SYNTH_CFG, resblock="2", upsample_rates=[8, 6, 5, 2], upsample_k
 ALT3_CFG = dict(ALT2_CFG, resblock_kernel_sizes=[3, 5, 7],
                 resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]])
 
+# The upstream BigVGAN convention k = 2 u on the ODD rates a hop of 480 = 2^5 * 3 * 5 forces: k - u is odd for the
+# u = 5 and u = 3 stages, ConvTranspose1d(k, u, padding (k - u) // 2) then returns u L + 1 samples (models.py:141-146),
+# the waveform has 480 N + 98 samples and PostProcessing trims it (postprocessing.py:30-39).  Channel counts
+# 384 / 192 / 96 / 48 / 24 cover the Winograd upsampler, every Winograd tile and the direct kernel at those lengths.
+ODD_CFG = dict(SYNTH_CFG, upsample_rates=[5, 4, 4, 3, 2], upsample_kernel_sizes=[10, 8, 8, 6, 4],
+               upsample_initial_channel=768)
+# four kernel sizes (models.py:130,182-187 take any count): the stage-closing conv cannot be one 3-segment group
+NK4_CFG = dict(SYNTH_CFG, upsample_rates=[8, 6, 5, 2], upsample_kernel_sizes=[16, 12, 11, 4],
+               upsample_initial_channel=384, resblock_kernel_sizes=[3, 5, 7, 11],
+               resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5], [1, 3, 5]])
+# ... and as AMPBlock2 with five
+NK5_AMP2_CFG = dict(NK4_CFG, resblock="2", resblock_kernel_sizes=[3, 5, 7, 9, 11],
+                    resblock_dilation_sizes=[[1, 3]] * 5)
+# channel counts that are not multiples of 8 (200 -> 100 / 50 / 25 / 12), an odd k - u, one kernel size,
+# a 13-tap kernel (longer than the Winograd form's 4 tap groups)
+PAD_CFG = dict(SYNTH_CFG, upsample_rates=[8, 6, 5, 2], upsample_kernel_sizes=[16, 13, 11, 4],
+               upsample_initial_channel=200, resblock_kernel_sizes=[13], resblock_dilation_sizes=[[1, 2, 5]])
+
 VOC = "flowhigh.audio_enc_dec.vocoder."
 FH = "flowhigh."
 

@@ -33,7 +33,6 @@ WINO_NARROW = (96, 48)
 # transposed convs run as Winograd phase groups from this many INPUT channels on (366 -> 207 us for 1536 -> 768
 # channels at B = 1, a wash at 768 -> 384, slower below: one-tap-group blocks pay the per-chunk slab cost every step)
 WINO_UPS_MIN_CIN = 768
-WINO_DESC_TAIL = 128          # zeroed bytes behind every Winograd descriptor array (work-list cursors of tools/exp builds)
 
 
 def use_wino(c, d):
@@ -42,6 +41,11 @@ def use_wino(c, d):
     on phase-major tensors written / read by the neighbouring activation launches: contiguous runs instead of stride-d
     access).  FH_WINO=0 switches the path off (direct kernel everywhere: parity debugging)."""
     return os.environ.get("FH_WINO", "1") != "0" and c % 16 == 0 and (c >= WINO_MIN_C or c in WINO_NARROW)
+
+
+def wino_conv_ok(c, d, k):
+    """use_wino for a k-tap conv: kernels longer than 4 tap groups run on the direct kernel."""
+    return use_wino(c, d) and k <= WINO_MAX_K
 
 
 def pick_tile_cfg(cout):
@@ -86,14 +90,24 @@ def pack_conv_weight(w, cout_pad, ck=8):
 
 
 def transposed_conv_phases(k, u):
-    """ConvTranspose1d(k, stride u, padding (k-u)//2) as u output phases (SURVEY.md 8a):
-    out[co, u*n + r] = sum over taps j with (r + p - j) % u == 0 of x[ci, n + (r + p - j)//u] w[ci, co, j]."""
+    """ConvTranspose1d(k, stride u, padding (k-u)//2) as u output phases (SURVEY.md 8a; models.py:141-146 builds it for
+    ANY (u, k)):
+    out[co, u*n + r] = sum over taps j with (r + p - j) % u == 0 of x[ci, n + (r + p - j)//u] w[ci, co, j].
+    With k - u odd the output has u * L + 1 samples (transposed_conv_extra): phase 0 then has L + 1 positions, the
+    others L; the tap lists are the same formula."""
     p = (k - u) // 2
     phases = []
     for r in range(u):
         taps = [(j, (r + p - j) // u) for j in range(k) if (r + p - j) % u == 0]
         phases.append(taps)
     return phases
+
+
+def transposed_conv_extra(k, u):
+    """Samples a ConvTranspose1d(k, u, padding (k - u) // 2) returns beyond u * L: (L - 1) u - 2 ((k - u) // 2) + k - u L."""
+    if k < u:
+        raise NotImplementedError(f"upsample kernel {k} shorter than its stride {u}")
+    return (k - u) % 2
 
 
 def make_conv_seg(x, w, cin, offs):
@@ -235,6 +249,8 @@ def pack_wino_weight(w, cout_pad):
 
 WINO_BF16X6 = 16          # FH_WINO_BF16X6 of flowhigh_hip.h: tile_cfg flag, three-piece bf16 weights
 WINO_XCD_RANGES = 32      # FH_WINO_XCD_RANGES: tile_cfg flag, blocks -> XCDs by time range instead of by weight panel
+WINO_NOVL = 64            # FH_WINO_NOVL: tile_cfg flag, some row of the launch is not 16-byte aligned although len % 4 == 0
+WINO_MAX_K = 12           # the kernel instantiates 1..4 tap groups of 3
 
 
 def use_bf16x6():
@@ -314,14 +330,15 @@ def wino_block_mapping(groups, batch, wpad, length, dil, wcfg):
     return WINO_XCD_RANGES if by_range < 0.9 * by_panel else 0
 
 
-def make_wino_seg(x, u, cin, k, center=None):
+def make_wino_seg(x, u, cin, k, center=None, xlen=0):
     s = hip.WinoSeg()
     s.x, s.u, s.cin, s.ngrp = _addr(x), _addr(u), cin, -(-k // 3)
     s.center = (k - 1) // 2 if center is None else center
+    s.xlen = xlen
     return s
 
 
-def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0, stride=1, phase=0):
+def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0, stride=1, phase=0, out_len=0):
     g = hip.WinoGroup()
     # the kernel walks the segments in one pass per tap-group count, largest first
     for i, s in enumerate(sorted(segs, key=lambda s: -s.ngrp)):
@@ -334,7 +351,7 @@ def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0, stride=
     if max(cout * stride, max(s.cin for s in segs)) * length * 4 >= 2 ** 31:
         raise NotImplementedError("per-clip tensor exceeds the 2 GiB range of a buffer descriptor")
     g.cout, g.cout_pad, g.len, g.scale = cout, cpad, length, scale
-    g.out_stride, g.out_phase = stride, phase
+    g.out_stride, g.out_phase, g.out_len = stride, phase, out_len
     return g
 
 
@@ -378,7 +395,7 @@ def from_phase_major(xp, d, length):
 
 def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0, phase_major=False):
     """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
-    d = hip.to_device_struct_array(groups, device, WINO_DESC_TAIL)
+    d = hip.to_device_struct_array(groups, device)
     hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
                                          int(phase_major), tile_cfg, hip.stream()), "fh_conv_wino_f32")
     return d
@@ -432,7 +449,7 @@ def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100
         wcfg, wpad = pick_wino_tile(c)
         us = [pack_wino_weight(torch.randn(c, c, k, generator=g) * 0.02, wpad).to(dev) for k in ks]
         gw = hip.to_device_struct_array([make_wino_group([make_wino_seg(ys[i], us[i], c, k)], bias, [], outs[i], c, wpad, length)
-                                         for i, k in enumerate(ks)], dev, hip.WINO3_WS_BYTES)
+                                         for i, k in enumerate(ks)], dev)
         filt = [0.0] * 5 + [0.5, 0.5] + [0.0] * 5
         p = dict(alpha=torch.ones(c, device=dev), inv_beta=torch.ones(c, device=dev), up=filt, down=filt)
         ga = hip.to_device_struct_array([make_act_group(xs[i], ys[i], p) for i in range(len(ks))], dev)
@@ -505,9 +522,10 @@ class _PlanBuilder:
         v = voc
         dils = sorted({d for dl in v.dil for d in dl})
         # (phase-major intermediates of the dilated convs are padded to d * phase_len >= L floats per row)
-        self.max_elems = max(st["c"] * max(d * phase_len(n_frames * math.prod(v.rates[:i + 1]), d) for d in dils + [1])
-                             for i, st in enumerate(v.stages))
-        self.mel_in = torch.empty(batch, v.num_mels, n_frames, **self.f32)
+        lens = v.stage_lengths(n_frames)
+        self.max_elems = max(st["c"] * max(d * phase_len(lens[i], d) for d in dils + [1]) for i, st in enumerate(v.stages))
+        # (rows past the checkpoint's num_mels -- channel padding to a multiple of 8 -- stay zero)
+        self.mel_in = torch.zeros(batch, v.num_mels, n_frames, **self.f32)
         self.pool = torch.empty(2 + 4 * v.nk, batch * self.max_elems, **self.f32)
         self.keep.append(self.pool)
 
@@ -538,14 +556,17 @@ class _PlanBuilder:
         self.direct += flops
         self.add(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops), groups)
 
-    def wino(self, groups, wpad, length, dil, wcfg, pm=False, flops=None, batch=None):
+    def wino(self, groups, wpad, length, dil, wcfg, pm=False, flops=None, batch=None, novl=False):
         """Winograd launch; the tile shape is the launch model's (choose_wino_cfg).  batch: launches whose groups are
-        per batch item (input-channel slices) pass 1."""
+        per batch item (input-channel slices) pass 1.  novl: some row of the launch is not 16-byte aligned although
+        `length` may be a multiple of 4 (segments with xlen)."""
         B = self.B if batch is None else batch
         wcfg, _ = choose_wino_cfg([sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg)) for g in groups],
                                   B, wpad, length, dil, default=wcfg, bf=self.v.bf)
         wcfg |= wino_block_mapping(groups, B, wpad, length, dil, wcfg)
-        d = hip.to_device_struct_array(groups, self.v.device, WINO_DESC_TAIL)
+        if novl:
+            wcfg |= WINO_NOVL
+        d = hip.to_device_struct_array(groups, self.v.device)
         self.keep.append(d)
         if flops is None:
             flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
@@ -626,12 +647,23 @@ class _PlanBuilder:
                                        v.pre_cpad, N, N, N)], v.pre_cpad, N, v.pre_cfg, v.pre_ck)
         return pre
 
+    def average(self, ys, out, n, scale, key):
+        """out = scale * (((ys[0] + ys[1]) + ys[2]) + ...): the `xs += resblock(x)` / `xs / num_kernels` of
+        models.py:181-187 in the reference's block order, for stages whose closing conv is not fused."""
+        if len(ys) in (2, 3):
+            self.add(("mean", ys[0], ys[1], ys[2] if len(ys) == 3 else None, out, n, scale), key=key)
+        elif len(ys) <= 12:
+            self.add(("sum", list(ys), out, n, scale), key=key)
+        else:
+            raise NotImplementedError("more than 12 resblock kernel sizes")
+
     def enter_stage(self, i):
         """Stage i: lengths and the views of the workspace pool (slot 0 = X: upsampled input, 1 = S: stage output,
         then per AMP block j: 2 + 4 j = T1, 3 + 4 j = T2, 4 / 5 + 4 j = Y ping-pong)."""
         v, st = self.v, self.v.stages[i]
-        self.lin, self.L = self.L, self.L * st["u"]
-        self.lin_ref, self.Lref = self.Lref, self.Lref * st["u"]
+        # (ConvTranspose1d with an odd k - u returns u * L + 1 samples: models.py:141-146)
+        self.lin, self.L = self.L, self.L * st["u"] + st["extra"]
+        self.lin_ref, self.Lref = self.Lref, self.Lref * st["u"] + st["extra"]
         c, B, L = st["c"], self.B, self.L
         view = lambda idx: self.pool[idx, :B * c * L].view(B, c, L)
         self.X, self.S = view(0), view(1)
@@ -646,29 +678,35 @@ class _PlanBuilder:
         wide stages, direct-kernel groups otherwise."""
         v, st, B = self.v, self.v.stages[i], self.B
         c, u, lin, L, X = st["c"], st["u"], self.lin, self.L, self.X
+        # k - u odd: L = u * lin + 1; phase 0 has lin + 1 output positions, the other phases lin
+        extra = st["extra"]
+        npos = lin + extra
         self.at(i, -1, 0, 0)
         if st["up_wino"] is None:
             self.conv([make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X, c,
-                                       st["cpad"], lin, L, lin, stride=u, phase=r)
-                       for r, ph in enumerate(st["up_phases"])], st["cpad"], lin, st["tile_cfg"], st["up_ck"])
+                                       st["cpad"], lin, L, npos if r == 0 else lin, stride=u, phase=r)
+                       for r, ph in enumerate(st["up_phases"])], st["cpad"], npos, st["tile_cfg"], st["up_ck"])
             return
+        # (Winograd phase groups: all have `npos` positions, writes at u * n + r >= L are masked: fh_wino_group.out_len)
+        xlen, olen = (lin, L) if extra else (0, 0)
         up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
         nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"], st["wpad"],
-                                  self.lin_ref, 1, st["wcfg"], v.bf)
+                                  self.lin_ref + extra, 1, st["wcfg"], v.bf)
         if nsplit == 1:
-            self.wino([make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"])], st["up_b"], [], X,
-                                       c, st["wpad"], lin, stride=u, phase=r) for r, ph in enumerate(st["up_wino"])],
-                      st["wpad"], lin, 1, st["wcfg"], flops=up_flops)
+            self.wino([make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"], xlen=xlen)], st["up_b"],
+                                       [], X, c, st["wpad"], npos, stride=u, phase=r, out_len=olen)
+                       for r, ph in enumerate(st["up_wino"])],
+                      st["wpad"], npos, 1, st["wcfg"], flops=up_flops, novl=bool(extra))
             return
         parts = self.parts_buffer()             # short clips: input channels in slices, as in res_conv
         cs = st["cin"] // nsplit
         dsts = [X] + [parts[sl] for sl in range(nsplit - 1)]
         groups = [make_wino_group([make_wino_seg(cur.data_ptr() + 4 * (b * st["cin"] + sl * cs) * lin,
-                                                 ph["u"][sl * cs // 16:], cs, ph["k"], ph["center"])],
+                                                 ph["u"][sl * cs // 16:], cs, ph["k"], ph["center"], xlen=xlen)],
                                   st["up_b"] if sl == 0 else None, [], dsts[sl].data_ptr() + 4 * b * c * L,
-                                  c, st["wpad"], lin, stride=u, phase=r)
+                                  c, st["wpad"], npos, stride=u, phase=r, out_len=olen)
                   for r, ph in enumerate(st["up_wino"]) for sl in range(nsplit) for b in range(B)]
-        self.wino(groups, st["wpad"], lin, 1, st["wcfg"], flops=up_flops, batch=1)
+        self.wino(groups, st["wpad"], npos, 1, st["wcfg"], flops=up_flops, batch=1, novl=bool(extra))
         self.add(("sum", dsts, X, B * c * L, 1.0), key=(i, -1, 1, 0))
 
     def amp1_stack(self, i):
@@ -731,8 +769,7 @@ class _PlanBuilder:
                 self.mixed_dilation_conv(st, order, ents, ks, ds, [T1[j] for j in order], outs, [[xin[j]] for j in order])
             xin = [Y[j][m % 2] for j in range(v.nk)]
             if m == v.nm - 1:            # xs / num_kernels, block order = the reference's xs += order
-                self.add(("mean", xin[0], xin[1], xin[2] if v.nk == 3 else None, self.S, self.B * c * L, 1.0 / v.nk),
-                         key=(i, m, 6, 0))
+                self.average(xin, self.S, self.B * c * L, 1.0 / v.nk, key=(i, m, 6, 0))
 
     def closing_conv(self, i, m, ents, ks, ds, xin):
         """The stage-closing conv position: xs = sum over blocks of (conv(T1_j) + x_j); S = xs / num_kernels
@@ -744,24 +781,33 @@ class _PlanBuilder:
         c, cpad, wpad, L, B, order = st["c"], st["cpad"], st["wpad"], self.L, self.B, self.order
         T1, Y, S = self.T1, self.Y, self.S
         scale = 1.0 / v.nk
+        fusable = v.nk <= hip.CONV_MAX_SEG          # (K segments of one group; more blocks: one group each + one averaging pass)
         if all("u" in e for e in ents):
             ksteps = [c // 16 * -(-k // 3) for k in ks]
             Lr = self.Lref
-            unfuse = v.nk in (2, 3) and (choose_wino_cfg(ksteps, 1, wpad, Lr, 1, st["wcfg"], v.bf)[1] + 4.0 + c * Lr * 16 / 4.0e6
-                                         < choose_wino_cfg([sum(ksteps)], 1, wpad, Lr, 1, st["wcfg"], v.bf)[1])
+            unfuse = not fusable or (v.nk in (2, 3) and (choose_wino_cfg(ksteps, 1, wpad, Lr, 1, st["wcfg"], v.bf)[1] + 4.0 + c * Lr * 16 / 4.0e6
+                                                         < choose_wino_cfg([sum(ksteps)], 1, wpad, Lr, 1, st["wcfg"], v.bf)[1]))
             if not unfuse:
                 segs = [make_wino_seg(T1[j], e["u"], c, k) for j, e, k in zip(order, ents, ks)]
                 self.wino([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, wpad, L, scale=scale)],
                           wpad, L, 1, st["wcfg"])
                 return
+            one_pass = 3 * v.nk <= 12                           # (a sum pass takes 12 sources: up to 3 slices per block)
             pieces = self.res_conv(st, ents, [T1[j] for j in order], ks, 1, [Y[j][m % 2] for j in order],
-                                   [[xin[j]] for j in order], defer_sum=True)
-            if len(pieces[0]) > 1:                              # input-channel slices: all partial outputs in one pass
+                                   [[xin[j]] for j in order], defer_sum=one_pass)
+            if len(pieces[0]) > 1 and one_pass:                 # input-channel slices: all partial outputs in one pass
                 by_block = {j: pieces[n_] for n_, j in enumerate(order)}
                 self.add(("sum", [t for j in range(v.nk) for t in by_block[j]], S, B * c * L, scale), key=(i, m, 6, 0))
             else:
-                ys = [Y[j][m % 2] for j in range(v.nk)]         # block order = the reference's xs += order
-                self.add(("mean", ys[0], ys[1], ys[2] if v.nk == 3 else None, S, B * c * L, scale), key=(i, m, 6, 0))
+                self.average([Y[j][m % 2] for j in range(v.nk)], S, B * c * L, scale, key=(i, m, 6, 0))
+            return
+        if not fusable:
+            outs, res = [Y[j][m % 2] for j in order], [[xin[j]] for j in order]
+            if all(d == ds[0] for d in ds):
+                self.res_conv(st, ents, [T1[j] for j in order], ks, ds[0], outs, res)
+            else:
+                self.mixed_dilation_conv(st, order, ents, ks, ds, [T1[j] for j in order], outs, res)
+            self.average([Y[j][m % 2] for j in range(v.nk)], S, B * c * L, scale, key=(i, m, 6, 0))
             return
         segs = [make_conv_seg(T1[j], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])
                 for j, e, k, d in zip(order, ents, ks, ds)]
@@ -803,27 +849,65 @@ class Vocoder:
         self.rates = list(cfg["upsample_rates"])
         self.up_k = list(cfg["upsample_kernel_sizes"])
         self.c0 = int(cfg["upsample_initial_channel"])
-        self.num_mels = int(cfg["num_mels"])
         self.ks = list(cfg["resblock_kernel_sizes"])
         self.dil = [list(d) for d in cfg["resblock_dilation_sizes"]]
         self.nk = len(self.ks)
-        if self.nk > hip.CONV_MAX_SEG:
-            raise NotImplementedError("more than 3 resblock kernel sizes")
+        if not 1 <= self.nk <= 12:
+            raise NotImplementedError("1 .. 12 resblock kernel sizes")
         self.nm = len(self.dil[0])
         if any(len(d) != self.nm for d in self.dil):
+            # (the reference zips convs with dilations per block, models.py:44-58: blocks of different depth would need
+            # per-block launch positions)
             raise NotImplementedError("ragged dilation lists")
-        if self.resblock == "2" and self.nk not in (2, 3):
-            raise NotImplementedError("AMPBlock2 with other than 2 or 3 kernel sizes")
+        if any(k % 2 == 0 for k in self.ks):
+            # (get_padding(k, d) = (k d - d) / 2 is "same" padding for odd k only; an even k changes the length inside
+            # the residual `+ x` and the reference itself fails there)
+            raise NotImplementedError("even resblock kernel sizes")
         self.hop = math.prod(self.rates)
-        self.chans = [self.c0 // (2 ** (i + 1)) for i in range(len(self.rates))]
-        for c in [self.num_mels, self.c0] + self.chans:
-            if c % 8:
-                raise NotImplementedError(f"channel count {c} is not a multiple of 8")
-        for u, k in zip(self.rates, self.up_k):
-            if (k - u) % 2:
-                raise NotImplementedError("upsample kernel - stride must be even")
-        g = lambda name: sd[prefix + name].detach().float().cpu()
+        # Channel counts as the checkpoint has them (models.py:141-146,152: c0 // 2^(i+1)) and as the kernels run them:
+        # rounded up to a multiple of 8 (the direct kernel's smallest channel chunk).  The extra channels have zero
+        # weights, zero bias and zero conv_post taps, so they carry exact zeros through the network (snake(0) = 0).
+        self.true_mels, self.true_c0 = int(cfg["num_mels"]), int(cfg["upsample_initial_channel"])
+        self.true_chans = [self.true_c0 // (2 ** (i + 1)) for i in range(len(self.rates))]
+        if min(self.true_chans) < 1:
+            raise ValueError("upsample_initial_channel is too small for the number of upsampling stages")
+        up8 = lambda c: -(-c // 8) * 8
+        self.num_mels, self.c0 = up8(self.true_mels), up8(self.true_c0)
+        self.chans = [up8(c) for c in self.true_chans]
+        # ConvTranspose1d(k, u, padding (k - u) // 2) for any (u, k) (models.py:141-146): k - u odd adds one sample per stage
+        self.extra = [transposed_conv_extra(k, u) for u, k in zip(self.rates, self.up_k)]
         dev = self.device
+
+        def g(name):
+            """Checkpoint tensor, channel dimensions zero-padded to the counts above."""
+            t = sd[prefix + name].detach().float().cpu()
+            parts = name.split(".")
+            if parts[0] == "conv_pre" and parts[-1] == "weight":
+                want = (self.c0, self.num_mels, t.shape[2])
+            elif parts[0] == "conv_pre":
+                want = (self.c0,)
+            elif parts[0] == "ups" and parts[-1] == "weight":
+                i = int(parts[1])
+                want = (self.c0 if i == 0 else self.chans[i - 1], self.chans[i], t.shape[2])
+            elif parts[0] == "ups":
+                want = (self.chans[int(parts[1])],)
+            elif parts[0] == "resblocks" and parts[-1] in ("weight", "bias", "alpha", "beta"):
+                c = self.chans[int(parts[1]) // self.nk]
+                want = (c, c, t.shape[2]) if parts[-1] == "weight" else (c,)
+            elif parts[0] == "activation_post" and parts[-1] in ("alpha", "beta"):
+                want = (self.chans[-1],)
+            elif parts[0] == "conv_post" and parts[-1] == "weight":
+                want = (t.shape[0], self.chans[-1], t.shape[2])
+            else:
+                return t
+            if tuple(t.shape) == want:
+                return t
+            out = torch.zeros(want, dtype=torch.float32)
+            if parts[-1] in ("alpha", "beta") and not bool(cfg.get("snake_logscale", False)):
+                out.fill_(1.0)            # (linear-scale snake parameters: any finite non-zero value; the channel is 0)
+            out[tuple(slice(0, n) for n in t.shape)] = t
+            return out
+
         is_beta = cfg["activation"] == "snakebeta"
         logscale = bool(cfg.get("snake_logscale", False))
 
@@ -843,6 +927,8 @@ class Vocoder:
         self.pre_w = pack_conv_weight(g("conv_pre.weight"), self.pre_cpad, self.pre_ck).to(dev)
         self.pre_b = g("conv_pre.bias").to(dev)
         # conv_pre (num_mels -> c0, 7 taps) in Winograd form as well when the shapes fit
+        if g("conv_pre.weight").shape[-1] != 7:
+            raise NotImplementedError("conv_pre kernel size other than 7")            # (models.py:134 fixes 7)
         self.pre_u = None
         if use_wino(self.c0, 1) and self.num_mels % 16 == 0 and self.c0 % 64 == 0:
             self.pre_wcfg, self.pre_wpad = pick_wino_tile(self.c0)
@@ -850,9 +936,16 @@ class Vocoder:
         self.stages = []
         for i, (u, k) in enumerate(zip(self.rates, self.up_k)):
             c = self.chans[i]
+            cin = self.c0 if i == 0 else self.chans[i - 1]
             tcfg, bm, cpad = pick_tile_cfg(c)
-            st = dict(c=c, cin=self.c0 // (2 ** i), u=u, k=k, tile_cfg=tcfg, cpad=cpad,
-                      ck=pick_ck(c), up_ck=pick_ck(self.c0 // (2 ** i)))
+            st = dict(c=c, cin=cin, u=u, k=k, extra=self.extra[i], tile_cfg=tcfg, cpad=cpad,
+                      ck=pick_ck(c), up_ck=pick_ck(cin))
+            # Winograd residual stack only if every block's kernel fits its 4 tap groups (one launch per position)
+            wino_k = max(self.ks) <= WINO_MAX_K
+            for kk, dl in zip(self.ks, self.dil):
+                if not (wino_k and use_wino(c, 1)) and (kk > hip.CONV_MAX_TAPS or (kk - 1) * max(dl) > hip.CONV_MAX_HALO):
+                    raise NotImplementedError(f"resblock kernel {kk} x dilation {max(dl)} exceeds the direct kernel's "
+                                              f"{hip.CONV_MAX_TAPS} taps / {hip.CONV_MAX_HALO} samples of reach")
             st["wcfg"], st["wpad"] = pick_wino_tile(c)
             wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
             st["up_b"] = g(f"ups.{i}.0.bias").to(dev)
@@ -877,7 +970,7 @@ class Vocoder:
                         d = self.dil[j][m]
                         ent = dict(b=g(f"resblocks.{r}.convs.{m}.bias").to(dev))
                         w = g(f"resblocks.{r}.convs.{m}.weight")
-                        if use_wino(c, d) and all(self.dil[jj][m] == d for jj in range(self.nk)):
+                        if wino_k and use_wino(c, d) and all(self.dil[jj][m] == d for jj in range(self.nk)):
                             ent["u"] = pack_wino_weight_any(w, st["wpad"], self.bf).to(dev)
                         else:
                             ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
@@ -891,7 +984,7 @@ class Vocoder:
                         ent = dict(b=g(f"resblocks.{r}.{tag}.{m}.bias").to(dev))
                         # convs1[m] of the nk blocks share one launch: Winograd only if they share the dilation
                         same_d = tag == "convs2" or all(self.dil[jj][m] == d for jj in range(self.nk))
-                        if use_wino(c, d) and same_d:
+                        if wino_k and use_wino(c, d) and same_d:
                             ent["u"] = pack_wino_weight_any(w, st["wpad"], self.bf).to(dev)
                         else:
                             ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
@@ -915,15 +1008,30 @@ class Vocoder:
         # blocks per CU of the activation launches on this device (measured once per device and process: see above)
         self.act_blocks = calibrate_act_occupancy(self.device)
 
+    def stage_lengths(self, n_frames):
+        """Samples per row after every upsampling stage: L_i = u_i L_(i-1) + (k_i - u_i) % 2 (models.py:141-146,179)."""
+        out, n = [], int(n_frames)
+        for st in self.stages:
+            n = n * st["u"] + st["extra"]
+            out.append(n)
+        return out
+
+    def out_len(self, n_frames):
+        """Waveform samples for n_frames mel frames: hop * n_frames when every k - u is even, a few more otherwise
+        (PostProcessing trims to the input's length: postprocessing.py:30-39)."""
+        return self.stage_lengths(n_frames)[-1]
+
     def conv_flops_per_frame(self):
         """Algorithmic FLOPs of the MFMA conv launches per mel frame (SURVEY.md 8d formula:
         2 * Cout * Cin * k per output sample; conv_post and the activations are not included)."""
-        f = 2.0 * self.c0 * self.num_mels * 7
-        length = 1
-        for i, st in enumerate(self.stages):
-            f += 2.0 * st["cin"] * st["c"] * st["k"] * length          # transposed conv: per INPUT sample
+        f = 2.0 * self.true_c0 * self.true_mels * 7
+        length, cin = 1, self.true_c0
+        per_dil = 2 if self.resblock == "1" else 1                      # AMPBlock1: convs1 + convs2 per dilation
+        for st, c in zip(self.stages, self.true_chans):
+            f += 2.0 * cin * c * st["k"] * length                       # transposed conv: per INPUT sample
             length *= st["u"]
-            f += length * st["c"] ** 2 * 2.0 * 2 * self.nm * sum(self.ks)
+            f += length * c ** 2 * 2.0 * per_dil * self.nm * sum(self.ks)
+            cin = c
         return f
 
     @hip.on_device
@@ -1011,6 +1119,8 @@ class Vocoder:
                         mean_len = max(1, sum(t[1] for t in allg) // len(allg))
                         wcfg, _ = choose_wino_cfg([t[0] for t in allg], 1, wpad, mean_len, dil, default=default, bf=self.bf)
                     novl = 0 if (pm or all(t[1] % 4 == 0 for t in allg)) else 2
+                    if any(w & WINO_NOVL for _, w, _ in lst):               # (segments with xlen: odd-(k - u) upsamplers)
+                        novl = 2
                     # runs (consecutive tiles of one (group, co tile) panel, dealt to one XCD) that hold real tiles
                     bm, bt = _WINO_TILES[wcfg]
                     cot = wpad // bm
@@ -1115,7 +1225,7 @@ class Vocoder:
         buffers), every one bit-identical to forward() on that clip alone."""
         rp = self.plan_ragged([m.shape[0] for m in mels])
         for sp, m in zip(rp["subs"], mels):
-            sp["mel_in"].copy_(m.view(1, m.shape[0], -1).transpose(1, 2))
+            sp["mel_in"][:, :self.true_mels].copy_(m.view(1, m.shape[0], -1).transpose(1, 2))
         self.run_ragged(rp)
         return [sp["wav"] for sp in rp["subs"]]
 
@@ -1172,16 +1282,17 @@ class Vocoder:
             e = min(N, s + step)
             a, b = max(0, s - halo), min(N, e + halo)
             p = self.plan(B, b - a, ref_frames=N)
-            p["mel_in"].copy_(mel_bnd[:, a:b].transpose(1, 2))
+            p["mel_in"][:, :self.true_mels].copy_(mel_bnd[:, a:b].transpose(1, 2))
             self.run(p)
-            yield s * self.hop, p["wav"][:, (s - a) * self.hop:(e - a) * self.hop]
+            # (the last chunk also carries the samples past hop * N of a vocoder with odd k - u: out_len)
+            yield s * self.hop, p["wav"][:, (s - a) * self.hop:((e - a) * self.hop if e < N else p["wav"].shape[1])]
             s = e
 
     @hip.on_device
     def forward_chunked(self, mel_bnd, chunk_frames, out=None):
         """forward() in time chunks of `chunk_frames` mel frames: same bits, bounded workspace."""
         B, N, D = mel_bnd.shape
-        wav = out if out is not None else torch.empty(B, N * self.hop, dtype=torch.float32, device=self.device)
+        wav = out if out is not None else torch.empty(B, self.out_len(N), dtype=torch.float32, device=self.device)
         for first, w in self.forward_chunks(mel_bnd, chunk_frames):
             wav[:, first:first + w.shape[1]].copy_(w)
         return wav
@@ -1196,7 +1307,7 @@ class Vocoder:
         if limit > 0 and N > limit + 2 * self.chunk_geometry()[0]:
             return self.forward_chunked(mel_bnd, limit)
         p = self.plan(B, N)
-        p["mel_in"].copy_(mel_bnd.transpose(1, 2))       # 'b n d -> b d n' (melvoco.py:115); layout only
+        p["mel_in"][:, :self.true_mels].copy_(mel_bnd.transpose(1, 2))       # 'b n d -> b d n' (melvoco.py:115); layout only
         self.run(p)
         return p["wav"]
 

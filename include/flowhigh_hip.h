@@ -27,7 +27,7 @@ extern "C" {
 #define FH_E_ARG (-1)     /* bad argument / unsupported shape */
 #define FH_E_LAUNCH (-2)  /* HIP launch error */
 
-#define FH_ABI_VERSION 1
+#define FH_ABI_VERSION 2
 
 int fh_abi_version(void);
 const char* fh_last_error(void);
@@ -111,7 +111,9 @@ typedef struct {
   int32_t cin;
   int32_t ngrp;        /* ceil(k / 3) */
   int32_t center;      /* (k - 1) / 2 */
-  int32_t pad_;
+  int32_t xlen;        /* 0: x rows are `len` samples long (the group's len).  > 0: x is [B, cin, xlen] and reads past
+                          xlen are zero -- a transposed-conv phase whose rows are shorter than its output count, below
+                          (plain layout, dilation 1; rows not 16-byte aligned need FH_WINO_NOVL) */
 } fh_wino_seg;
 
 typedef struct {
@@ -127,6 +129,11 @@ typedef struct {
   float scale;
   int32_t out_stride;   /* 0 or 1: out[b, co, n]; u > 1: one output phase of a transposed conv (models.py:179),   */
   int32_t out_phase;    /*   out [B, cout, u * len] written at u * n + out_phase (dilation 1, plain layout, no res)  */
+  int32_t out_len;      /* 0, or the row length of out when it is not out_stride * len: ConvTranspose1d(k, u, padding
+                           (k - u) / 2) with k - u ODD returns u * L + 1 samples (models.py:141-146): its phase groups have
+                           len = L + 1 output positions, seg.xlen = L, out_len = u * L + 1; positions u * n + out_phase >=
+                           out_len are not written */
+  int32_t pad_;
 } fh_wino_group;
 
 int fh_sizeof_wino_group(void);
@@ -154,6 +161,9 @@ int fh_phase_len(int len, int dilation);
  * resident; every XCD fetches every weight panel.  For launches whose transformed weights are
  * small beside their activations (C <= 384 at batch 1): less HBM traffic, same bits.  Ignored by the ragged entry. */
 #define FH_WINO_XCD_RANGES 32
+/* tile_cfg | FH_WINO_NOVL: some tensor row of the launch is not 16-byte aligned although `len` % 4 == 0 (a segment with
+ * xlen % 4 != 0): the slab loader must not use 16-byte loads.  Same bits. */
+#define FH_WINO_NOVL 64
 int fh_conv_wino_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
                      int dilation, int phase_major, int tile_cfg, void* stream);
 /* Ragged form (clips of different lengths, one group per clip and AMP block, batch 1): the grid is laid out for
@@ -189,13 +199,6 @@ typedef struct {
 } fh_sum_job;
 int fh_sizeof_sum_job(void);
 int fh_sum_multi_f32(const fh_sum_job* jobs, int n_jobs, long long max_n, void* stream);
-
-/* Debug: per-block timeline of the conv kernel.  buf = device array of uint64, buf[0] = record
- * counter (zero it), then 4 words per block {blockIdx | hw_id << 32 | xcc << 56, start, end
- * (100 MHz ticks), K steps}; NULL switches tracing off.  Synchronous (hipMemcpyToSymbol). */
-int fh_debug_set_conv_trace(void* buf);
-/* Same for the Winograd kernel: one record per WAVE, word 3 = wave index in the block. */
-int fh_debug_set_wino_trace(void* buf);
 
 /* conv_post + tanh (models/bigvgan/models.py:190-192): x [B, cin, L], w [cin, ksz], bias[1]
  * -> out [B, L] = tanh(bias + sum_ci sum_j w[ci,j] * x[b, ci, t + j - ksz/2]).  ksz odd <= 15. */

@@ -34,6 +34,10 @@ CASES = {
     "tiny_mix": (synth.TINY_CFG, 4, 0.18, 12000, "euler", 1, "independent_cfm_mix", 0.05, False),
     "amp2_euler": (synth.ALT2_CFG, 5, 0.2, 12000, "euler", 1, "basic_cfm", 0.0, False),
     "amp2_three_blocks": (synth.ALT3_CFG, 6, 0.16, 16000, "midpoint", 1, "basic_cfm", 0.0, False),
+    # ConvTranspose1d with k - u odd (k = 2 u on the rates 5 and 3): the vocoder returns 480 N + 98 samples
+    "odd_euler": (synth.ODD_CFG, 7, 0.2, 12000, "euler", 1, "basic_cfm", 0.0, False),
+    # four resblock kernel sizes
+    "nk4_midpoint": (synth.NK4_CFG, 8, 0.15, 16000, "midpoint", 1, "basic_cfm", 0.0, False),
 }
 
 

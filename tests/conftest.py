@@ -39,4 +39,6 @@ def load_golden(name):
 
 
 E2E_CASES = ["tiny_euler", "alt_midpoint", "tiny_adaptive_i16", "tiny_ragged_16k", "tiny_mix",
-             "amp2_euler", "amp2_three_blocks"]         # AMPBlock2 vocoders (resblock "2")
+             "amp2_euler", "amp2_three_blocks",         # AMPBlock2 vocoders (resblock "2")
+             "odd_euler",                               # upsamplers with k - u odd (u L + 1 samples per stage)
+             "nk4_midpoint"]                            # four resblock kernel sizes

@@ -62,6 +62,28 @@ def test_generate_synth_cfg_vs_oracle(sr_in, method, steps, secs):
     assert (out.cpu() - ref).abs().max().item() <= TOL_WAVEFORM
 
 
+@pytest.mark.parametrize("sr_in,method,secs,B", [(12000, "euler", 1.0, 1), (16000, "midpoint", 0.45, 2)])
+def test_generate_odd_upsamplers_full_width_vs_oracle(sr_in, method, secs, B):
+    """Full-width vocoder (1536 channels) in the upstream BigVGAN convention k = 2 u on the odd rates of hop 480
+    (rates [5, 4, 4, 3, 2], kernels [10, 8, 8, 6, 4]): every u = 5 / u = 3 stage returns u L + 1 samples
+    (/root/reference/src/flowhigh/models/bigvgan/models.py:141-146), the vocoder 480 N + 98, and PostProcessing trims to
+    the input's length (postprocessing.py:30-39).  Batch rows equal single-clip runs bit for bit."""
+    cfg = dict(synth.ODD_CFG, upsample_initial_channel=1536)
+    m, sd = model_for(cfg, 0, method)
+    clips = [synth.lowres_clip(40 + b, secs, sr_in) for b in range(B)]
+    n = int(round(secs * sr_in)) * (48000 // sr_in) // 480
+    noise = torch.cat([synth.prior_noise(40 + b, n) for b in range(B)], 0)
+    out, got = m.generate_batch(clips, sr_in, 48000, 1, noise=noise, return_stages=True)
+    assert tuple(got["wav"].shape) == (B, 480 * n + 98) and tuple(out.shape) == (B, int(round(secs * sr_in)) * (48000 // sr_in))
+    for b in range(B):
+        ref, st = ref_cpu.generate(sd, cfg, clips[b], sr_in, noise[b:b + 1], 1, method, return_stages=True)
+        assert int(got["cr"][b].item()) == st["cr"]
+        assert (got["wav"][b:b + 1].cpu() - st["wav"]).abs().max().item() <= TOL_WAVEFORM
+        assert (out[b:b + 1].cpu() - ref).abs().max().item() <= TOL_WAVEFORM
+        if B > 1:
+            assert torch.equal(m.generate(clips[b], sr_in, 48000, 1, noise=noise[b:b + 1]), out[b:b + 1])
+
+
 def test_device_resampler_path_vs_oracle():
     cfg = synth.TINY_CFG
     m, sd = model_for(cfg, 0, "euler", upsampling="hip")
@@ -405,7 +427,8 @@ def test_two_minute_clip_runs_through_the_chunked_vocoder(monkeypatch):
 
 @pytest.mark.parametrize("cfgname,method,cfm", [("TINY_CFG", "euler", "basic_cfm"), ("SYNTH_CFG", "midpoint", "basic_cfm"),
                                                 ("TINY_CFG", "midpoint", "independent_cfm_adaptive"),
-                                                ("TINY_CFG", "euler", "independent_cfm_mix")])
+                                                ("TINY_CFG", "euler", "independent_cfm_mix"),
+                                                ("ODD_CFG", "euler", "basic_cfm")])         # vocoder returns 480 N + 98 samples
 def test_generate_many_ragged_batch_equals_single_calls_bitwise(cfgname, method, cfm):
     """Masked / ragged batches (reference mask paths transformer.py:35-44, attend.py:127-128): clips of
     different lengths -- odd sample counts, an int16 clip, two of equal length, sub-2-s clips whose wide stages run as

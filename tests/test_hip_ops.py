@@ -71,22 +71,27 @@ def test_conv_no_bias():
     assert maxdiff(run_conv(x, w, None, 1, 4), F.conv1d(x, w, None, padding=1)) <= 1e-5
 
 
-@pytest.mark.parametrize("u,k", [(5, 11), (4, 8), (3, 7), (2, 4), (8, 16), (6, 12)])
+@pytest.mark.parametrize("u,k", [(5, 11), (4, 8), (3, 7), (2, 4), (8, 16), (6, 12),
+                                 (5, 10), (3, 6), (6, 13), (2, 3), (4, 4), (3, 3), (5, 16)])      # k - u odd, k == u, k > 3 u
 def test_conv_transpose_as_phase_groups(u, k):
+    """ConvTranspose1d(k, u, padding (k - u) // 2) for any (u, k) (models.py:141-146) as u phase groups; with k - u
+    odd the output has u L + 1 samples: phase 0 carries one position more."""
     cin, cout, L, B = 32, 16, 157, 2
     x, wt, b = rnd(B, cin, L, seed=11), rnd(cin, cout, k, seed=12, scale=0.2), rnd(cout, seed=13)
     ref = F.conv_transpose1d(x, wt, b, stride=u, padding=(k - u) // 2)
-    assert ref.shape[-1] == u * L
+    extra = V.transposed_conv_extra(k, u)
+    lout = u * L + extra
+    assert ref.shape[-1] == lout
     tile_cfg, _, cpad = V.pick_tile_cfg(cout)
-    xd, out, bd = x.to(DEV), torch.full((B, cout, u * L), float("nan"), device=DEV), b.to(DEV)
+    xd, out, bd = x.to(DEV), torch.full((B, cout, lout), float("nan"), device=DEV), b.to(DEV)
     groups, keep = [], []
     for r, taps in enumerate(V.transposed_conv_phases(k, u)):
         wsel = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1).permute(1, 0, 2)
         wp = V.pack_conv_weight(wsel, cpad, 16).to(DEV)
         keep.append(wp)
         groups.append(V.make_conv_group([V.make_conv_seg(xd, wp, cin, [o for _, o in taps])], bd, [], out,
-                                        cout, cpad, L, u * L, L, stride=u, phase=r))
-    keep.append(V.conv_grouped(groups, B, cpad, L, tile_cfg, DEV, 16))
+                                        cout, cpad, L, lout, L + (extra if r == 0 else 0), stride=u, phase=r))
+    keep.append(V.conv_grouped(groups, B, cpad, L + extra, tile_cfg, DEV, 16))
     torch.cuda.synchronize()
     assert maxdiff(out, ref) <= 1e-5
 
@@ -191,22 +196,30 @@ def test_conv_wino_phase_major(c, k, d, L, B):
 
 
 @pytest.mark.parametrize("u,k,cin,cout,L,B", [(5, 11, 64, 32, 157, 2), (4, 8, 32, 64, 1000, 1), (3, 7, 48, 96, 333, 2),
-                                              (2, 4, 96, 48, 2049, 1), (8, 16, 16, 64, 50, 1)])
+                                              (2, 4, 96, 48, 2049, 1), (8, 16, 16, 64, 50, 1),
+                                              # k - u odd: u L + 1 samples (xlen / out_len of the descriptors); L % 4 == 3 makes
+                                              # the launch length a multiple of 4 over rows that are not 16-byte aligned
+                                              (5, 10, 64, 32, 157, 2), (3, 6, 48, 96, 1003, 2), (5, 10, 32, 64, 1000, 1),
+                                              (6, 13, 16, 64, 203, 3), (2, 3, 32, 32, 31, 1)])
 def test_conv_transpose_as_wino_phase_groups(u, k, cin, cout, L, B):
-    """ConvTranspose1d as u Winograd groups with strided output (one per output phase)."""
+    """ConvTranspose1d as u Winograd groups with strided output (one per output phase), any (u, k)."""
     x, wt, b = rnd(B, cin, L, seed=190), rnd(cin, cout, k, seed=191, scale=0.2), rnd(cout, seed=192)
     ref = F.conv_transpose1d(x.double(), wt.double(), b.double(), stride=u, padding=(k - u) // 2).float()
+    extra = V.transposed_conv_extra(k, u)
+    lout, npos = u * L + extra, L + extra
+    assert ref.shape[-1] == lout
     wcfg, cpad = V.pick_wino_tile(cout)
-    xd, out, bd = x.to(DEV), torch.full((B, cout, u * L), float("nan"), device=DEV), b.to(DEV)
+    xd, out, bd = x.to(DEV), torch.full((B, cout, lout), float("nan"), device=DEV), b.to(DEV)
     groups, keep = [], []
     for r, taps in enumerate(V.transposed_conv_phases(k, u)):
         w, center = V.wino_phase_weight(wt, taps)
         ud = V.pack_wino_weight(w, cpad).to(DEV)
         keep.append(ud)
-        groups.append(V.make_wino_group([V.make_wino_seg(xd, ud, cin, w.shape[-1], center)], bd, [], out, cout, cpad, L,
-                                        stride=u, phase=r))
-    keep.append(V.conv_wino(groups, B, cpad, L, 1, DEV, wcfg))
+        groups.append(V.make_wino_group([V.make_wino_seg(xd, ud, cin, w.shape[-1], center, xlen=L if extra else 0)], bd, [],
+                                        out, cout, cpad, npos, stride=u, phase=r, out_len=lout if extra else 0))
+    keep.append(V.conv_wino(groups, B, cpad, npos, 1, DEV, wcfg | (V.WINO_NOVL if extra else 0)))
     torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
     assert maxdiff(out, ref) <= 2e-5
 
 
@@ -661,11 +674,16 @@ def test_flow_forward(B, n, t):
 # ------------------------------------------------------------------------------------------
 # vocoder, post-processing, resampler
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfgname,B,N", [("TINY_CFG", 2, 25), ("ALT_CFG", 1, 20), ("SYNTH_CFG", 1, 12)])
+@pytest.mark.parametrize("cfgname,B,N", [("TINY_CFG", 2, 25), ("ALT_CFG", 1, 20), ("SYNTH_CFG", 1, 12),
+                                         # configurations the reference accepts beyond the survey's SYNTH-CFG family
+                                         # (models.py:130,141-146,182-187): k - u odd (u L + 1 samples per stage), four /
+                                         # five kernel sizes, channel counts that are not multiples of 8, a 13-tap kernel
+                                         ("ODD_CFG", 2, 23), ("ODD_CFG", 1, 150), ("NK4_CFG", 2, 21), ("NK5_AMP2_CFG", 1, 30),
+                                         ("PAD_CFG", 2, 17), ("PAD100_CFG", 1, 40)])
 def test_vocoder_forward(cfgname, B, N):
-    cfg = getattr(synth, cfgname)
+    cfg = dict(synth.PAD_CFG, num_mels=100) if cfgname == "PAD100_CFG" else getattr(synth, cfgname)
     sd = synth.make_vocoder_state_dict(cfg, seed=1)
-    mel = rnd(B, N, 256, seed=170, scale=2.0) - 3.0
+    mel = rnd(B, N, cfg["num_mels"], seed=170, scale=2.0) - 3.0
     ref = ref_cpu.bigvgan_forward(sd, cfg, mel.transpose(1, 2)).squeeze(1)
     voc = V.Vocoder(cfg, sd, DEV)
     wav = voc.forward(mel.to(DEV))
@@ -674,7 +692,9 @@ def test_vocoder_forward(cfgname, B, N):
 
 
 @pytest.mark.parametrize("cfgname,B,N,chunk", [("SYNTH_CFG", 1, 150, 48), ("SYNTH_CFG", 2, 100, 24), ("TINY_CFG", 1, 333, 96),
-                                                 ("TINY_CFG", 3, 77, 12), ("ALT_CFG", 1, 260, 60), ("ALT3_CFG", 1, 130, 36)])
+                                                 ("TINY_CFG", 3, 77, 12), ("ALT_CFG", 1, 260, 60), ("ALT3_CFG", 1, 130, 36),
+                                                 ("ODD_CFG", 1, 170, 48), ("ODD_CFG", 2, 131, 24), ("NK4_CFG", 1, 140, 60),
+                                                 ("PAD_CFG", 1, 150, 40)])
 def test_vocoder_chunked_equals_unchunked_bitwise(cfgname, B, N, chunk):
     """Time-chunked vocoder (BigVGAN is purely local, bigvgan/models.py:172-194): chunks with fixed
     halos, aligned so that every sample keeps its Winograd tile position and dilation phase, reproduce the whole-clip
@@ -694,14 +714,16 @@ def test_vocoder_chunked_equals_unchunked_bitwise(cfgname, B, N, chunk):
     for first, w in voc.forward_chunks(mel, chunk):
         assert first == pos and torch.equal(w, whole[:, first:first + w.shape[1]])
         pos += w.shape[1]
-    assert pos == N * voc.hop
+    assert pos == voc.out_len(N) and whole.shape[1] == pos            # (hop N, + 98 for ODD_CFG)
     # every chunk plan is smaller than the whole-clip plan
     chunk_plans = [k for k in dict.keys(voc._plans) if len(k) == 3]
     assert chunk_plans and all(k[1] <= chunk + 2 * halo for k in chunk_plans)
 
 
 @pytest.mark.parametrize("cfgname,frames", [("SYNTH_CFG", [50, 333, 50, 77, 201, 3]), ("TINY_CFG", [25, 7, 160, 25, 91]),
-                                            ("ALT_CFG", [20, 33, 9]), ("ALT2_CFG", [30, 12, 45]), ("ALT3_CFG", [16, 40])])
+                                            ("ALT_CFG", [20, 33, 9]), ("ALT2_CFG", [30, 12, 45]), ("ALT3_CFG", [16, 40]),
+                                            ("ODD_CFG", [50, 211, 50, 7, 103]), ("NK4_CFG", [31, 9, 60]),
+                                            ("NK5_AMP2_CFG", [22, 40]), ("PAD_CFG", [19, 64, 5])])
 def test_vocoder_ragged_equals_per_clip_runs_bitwise(cfgname, frames):
     """Vocoder.forward_ragged: clips of different lengths in ONE launch sequence (one group per clip in every conv /
     activation launch, per-group lengths).  Every clip -- including the short ones whose wide stages run as

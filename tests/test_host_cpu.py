@@ -6,7 +6,8 @@ from flowhigh_amd import synth
 from flowhigh_amd.flowhighsr import _load_checkpoint, check_state_dict_keys, expected_state_keys
 
 
-@pytest.mark.parametrize("cfgname", ["SYNTH_CFG", "TINY_CFG", "ALT_CFG", "ALT2_CFG", "ALT3_CFG"])
+@pytest.mark.parametrize("cfgname", ["SYNTH_CFG", "TINY_CFG", "ALT_CFG", "ALT2_CFG", "ALT3_CFG", "ODD_CFG", "NK4_CFG",
+                                     "NK5_AMP2_CFG", "PAD_CFG"])
 def test_expected_keys_are_the_reference_state_dict_keys(cfgname):
     """synth.make_state_dict is loaded into the REAL reference modules with strict=True by oracle/make_golden.py
     and tests/test_reference_pin.py, so its key set is the reference's; expected_state_keys must reproduce it."""
@@ -52,7 +53,8 @@ def _cpu_vocoder(cfgname):
     return Vocoder(cfg, synth.make_vocoder_state_dict(cfg, 1), "cpu")
 
 
-@pytest.mark.parametrize("cfgname", ["SYNTH_CFG", "ALT_CFG", "ALT2_CFG", "ALT3_CFG"])
+@pytest.mark.parametrize("cfgname", ["SYNTH_CFG", "ALT_CFG", "ALT2_CFG", "ALT3_CFG", "ODD_CFG", "NK4_CFG", "NK5_AMP2_CFG",
+                                     "PAD_CFG"])
 def test_plan_steps_have_unique_sorted_position_keys(cfgname):
     """Every launch of a plan is tagged (stage, sub-block, slot, index); plan_ragged merges the plans of different
     clips by that key, so within one plan the keys must be unique and already in launch order."""
@@ -65,6 +67,51 @@ def test_plan_steps_have_unique_sorted_position_keys(cfgname):
             assert (structs is not None) == (step[0] in ("conv", "wino", "act"))
             if structs is not None:
                 assert len(structs) == step[2]
+
+
+def test_odd_upsamplers_carry_the_reference_lengths():
+    """ConvTranspose1d(k, u, padding (k - u) // 2) with k - u odd returns u L + 1 samples
+    (/root/reference/src/flowhigh/models/bigvgan/models.py:141-146): the plan's stage lengths, the phase groups of the
+    upsampler launches (phase 0 has one position more; Winograd groups mask by out_len and read rows of xlen) and the
+    waveform length follow torch's ConvTranspose1d."""
+    from flowhigh_amd import vocoder as V
+    voc = _cpu_vocoder("ODD_CFG")
+    cfg = synth.ODD_CFG
+    for n in (7, 20, 25):
+        want, L = [], n
+        for u, k in zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"]):
+            L = torch.nn.ConvTranspose1d(1, 1, k, u, padding=(k - u) // 2)(torch.zeros(1, 1, L)).shape[-1]
+            want.append(L)
+        assert voc.stage_lengths(n) == want and voc.out_len(n) == 480 * n + 98
+        p = voc.plan(2, n)
+        assert tuple(p["wav"].shape) == (2, want[-1])
+        ups = [(st, m[1]) for st, m in zip(p["steps"], p["meta"]) if m[0][1] == -1 and st[0] in ("conv", "wino")]
+        assert len(ups) == 5
+        lin = n
+        for i, (st, groups) in enumerate(ups):
+            u, extra = cfg["upsample_rates"][i], (cfg["upsample_kernel_sizes"][i] - cfg["upsample_rates"][i]) % 2
+            if st[0] == "wino":
+                assert st[4] == lin + extra and bool(st[7] & V.WINO_NOVL) == bool(extra)
+                for g in groups:
+                    assert g.len == lin + extra and g.out_stride == u
+                    assert (g.out_len, g.seg[0].xlen) == ((want[i], lin) if extra else (0, 0))
+            else:
+                assert st[4] == lin + extra
+                for r, g in enumerate(groups):
+                    assert (g.lin, g.lout, g.out_stride, g.out_phase) == (lin, want[i], u, r)
+                    assert g.n_len == lin + (extra if r == 0 else 0)
+            lin = want[i]
+    voc = _cpu_vocoder("SYNTH_CFG")
+    assert voc.stage_lengths(10) == [50, 200, 600, 1200, 2400, 4800]
+
+
+def test_channel_counts_are_padded_to_multiples_of_eight_with_zero_weights():
+    """200 -> 100 / 50 / 25 / 12 channels run as 104 / 56 / 32 / 16 with zero rows / columns: exact zeros flow through."""
+    voc = _cpu_vocoder("PAD_CFG")
+    assert (voc.true_c0, voc.c0) == (200, 200) and voc.true_chans == [100, 50, 25, 12] and voc.chans == [104, 56, 32, 16]
+    assert voc.post_w.shape == (16, 7) and float(voc.post_w[12:].abs().max()) == 0.0
+    assert voc.stages[1]["extra"] == 1 and voc.stages[0]["extra"] == 0
+    assert float(voc.stages[0]["up_b"][100:].abs().max()) == 0.0
 
 
 def test_plan_ragged_merges_launch_by_launch():
@@ -122,7 +169,7 @@ def test_chunk_geometry_covers_the_receptive_field():
     """halo >= the receptive field of a waveform sample in mel frames (counted layer by layer here), and chunk starts
     keep every stage's Winograd tile position and dilation phase."""
     import math
-    for cfgname in ("SYNTH_CFG", "ALT_CFG", "ALT2_CFG", "ALT3_CFG"):
+    for cfgname in ("SYNTH_CFG", "ALT_CFG", "ALT2_CFG", "ALT3_CFG", "ODD_CFG", "NK4_CFG"):
         voc = _cpu_vocoder(cfgname)
         halo, align = voc.chunk_geometry()
         cfg = getattr(synth, cfgname)

@@ -1,5 +1,6 @@
-"""Writes tools/exp/conv_wino_trace2.hip = flowhigh_amd/csrc/conv_wino.hip + fine-grained stamps (diagnosis build for
-tools/wino_trace2.py; never part of the product library):
+"""Writes tools/exp/conv_wino_trace2.hip (generated, git-ignored) = flowhigh_amd/csrc/conv_wino.hip + a trace pointer,
+its setter and fine-grained stamps (diagnosis build for tools/wino_trace2.py; never part of the product library, which
+carries no debug state):
   python tools/exp/make_trace2.py && tools/build_variant.sh trace2 tools/exp/conv_wino_trace2.hip=conv_wino.hip
 Record per wave (24 words, slot = block * 12 + wave, no atomics: 3072 waves hitting one counter at launch cost ~20 us
 themselves): 0 id, 1 start, 2 end, 3 before / 4 after the segment descriptor fetch, 16 first A tiles arrived,
@@ -18,8 +19,15 @@ def sub(old, new, count=1):
     s = s.replace(old, new, count)
 
 
-sub('''  const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-''', '''  const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+# the product kernel carries no debug state: the trace pointer, its setter and every stamp are added here
+sub('''struct WSeg {''', '''__device__ unsigned long long* g_wino_trace = nullptr;
+
+struct WSeg {''')
+sub('''  extern __shared__ __attribute__((aligned(16))) float lds[];      // Cfg::LDS_FLOATS
+''', '''  extern __shared__ __attribute__((aligned(16))) float lds[];      // Cfg::LDS_FLOATS
+  unsigned long long* const trace = g_wino_trace;
+  const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long* rec2 = nullptr;
   if (trace) rec2 = trace + 1 + 24 * ((unsigned long long)blockIdx.x * 12ull + (unsigned long long)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 #define STAMP(k) do { if (rec2 && (threadIdx.x & 63) == 0) rec2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -41,8 +49,8 @@ sub('''  __syncthreads();
   STAMP(18);
 
   f32x2 c0 = {bc0, bc0}''')
-sub('''  const unsigned long long t_loop1 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-''', '''  const unsigned long long t_loop1 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+sub('''  run_all(std::integral_constant<int, 1>{});
+''', '''  run_all(std::integral_constant<int, 1>{});
   STAMP(6);
 ''')
 sub('''      const int sub = mt * NT + nt;
@@ -61,16 +69,17 @@ sub('''          }
       }
     }
   }
-  if (pf == 0x7fc12345u && trace) trace[0] = 0;''', '''          }
+  // (keeps pf alive''', '''          }
         }
       }
       STAMP(sb_ + 2);
     }
   }
-  if (pf == 0x7fc12345u && trace) trace[0] = 0;''')
-a = s.index('  if (trace && (tid & 63) == 0) {\n    unsigned hw, xcc;')
-b = s.index('// out = ((a + b) + c) * scale, 4 elements per thread')
-s = s[:a] + '''  if (rec2 && (tid & 63) == 0) {
+  // (keeps pf alive''')
+sub('''  if (pf == 0x7fc12345u) __builtin_amdgcn_s_sleep(1);
+}
+''', '''  if (pf == 0x7fc12345u) __builtin_amdgcn_s_sleep(1);
+  if (rec2 && (tid & 63) == 0) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -80,7 +89,12 @@ s = s[:a] + '''  if (rec2 && (tid & 63) == 0) {
     rec2[23] = (unsigned long long)wave | ((__builtin_amdgcn_s_memtime() - c_start) << 8);
   }
 }
+''')
+sub('''extern "C" int fh_sizeof_wino_group(void)''', '''extern "C" int fh_debug_set_wino_trace(void* buf) {       // (this build only; tools/wino_trace2.py binds it itself)
+  unsigned long long* p = (unsigned long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &p, sizeof(p)) == hipSuccess ? FH_OK : FH_E_LAUNCH;
+}
 
-''' + s[b:]
+extern "C" int fh_sizeof_wino_group(void)''')
 (root / "tools/exp/conv_wino_trace2.hip").write_text(s)
 print("tools/exp/conv_wino_trace2.hip")
