@@ -1,0 +1,516 @@
+// Winograd F(5,4) form of the wide residual-stack Conv1d sites of BigVGAN on the fp32 matrix cores.
+//
+// Replaces the AMPBlock convs (/root/reference/src/flowhigh/models/bigvgan/models.py:36-72: kernel 3 / 7 / 11,
+// dilation 1 / 3 / 5, "same" padding) of the stages with >= 192 channels, where the K loop is what a launch takes.
+//
+// Minimal filtering F(5,4): 5 outputs of a 4-tap correlation from 8 inputs with 8 multiplies (points 0, +-1, +-2,
+// +-1/2, inf), y = A^T [ (G g) .* (B^T d) ].  The k taps are walked in ceil(k/4) groups of 4, so a conv executes
+// 1.6 ceil(k/4) multiply-adds per output and channel pair: 1.6 / 3.2 / 4.8 for k = 3 / 7 / 11 against 1.5 / 4.5 / 6.0 of
+// the F(4,3) kernel (conv_wino.hip): 20 % fewer matrix instructions over the stack.  fp32 error against float64: the
+// same as F(4,3) per conv and end to end (tests/tools/winograd_numerics.py, profiles/r04_winograd_numerics.txt).
+//
+// Eight transform points = eight waves: block = 8 waves = 2 per SIMD with up to 256 registers each, wave xi owns
+// M_xi for (32 MT) output channels x 64 tiles (2 columns of 32) = 320 outputs.  With MT = 4 one B fragment feeds
+// 8 MFMAs (4 in the 12-wave F(4,3) shapes): per MFMA 0.31 packed vector + 0.375 LDS instructions against 0.75 + 0.5.
+// On this chip every instruction a SIMD issues beside v_mfma_f32_32x32x2_f32 costs matrix-pipe time wherever it is
+// placed (profiles/r04_wino_kloop_handsched.txt), so the instruction count per MFMA is what sets the K loop's rate.
+//   * A (transformed weights [cin/16][tap group][8][cout_pad][16]) goes global -> registers in fragment layout as in
+//     conv_wino.hip;
+//   * B: the raw 16-channel slab is staged in LDS once per chunk (double buffered, one barrier per chunk), wave w
+//     stages channel pair w.  Samples are de-interleaved into 5 planes (local sample v -> plane v % 5, index v / 5),
+//     channel pairs interleaved, so that lane `tile` reading sample 5 tile + c is a stride-1, conflict-free
+//     ds_read2_b64 (both tile columns in one instruction) with immediate offsets for the channel pair; the slab's
+//     alignment slack is absorbed by the WRITER, so the reader's offsets are per-block constants;
+//   * every row of B^T (points +-1, +-2, +-1/2: six samples, unit coefficient on the last; 0 and inf: four) is one
+//     chain v = x5; v = fma(c_j, x_j, v): five packed FMAs over a k-step pair;
+//   * epilogue: the eight M_xi of a 32 x 32 tile meet through LDS, a thread applies A^T for 4 rows x 1 tile (5 outputs
+//     each), the 5-sample tiles are re-laid row-major in LDS and leave as aligned 16-byte vectors with bias, residuals
+//     and scale applied.
+#include "fh_common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int V_CK = 16;             // input channels per chunk
+constexpr int V_THREADS = 512;       // 8 waves = 8 transform points
+constexpr int V_BT = 64;             // F(5,4) tiles per block (2 columns of 32)
+constexpr int V_OUT = 5 * V_BT;      // outputs per block and row
+constexpr int V_P = 72;              // samples per (plane, channel pair) row: >= V_BT + (4 * 3 + 7) / 5 + 1
+constexpr int V_PAIR = 2 * V_P;      // floats of one channel pair inside a plane
+constexpr int V_PP = 8 * V_PAIR;     // plane pitch, floats
+constexpr int V_SLAB = 5 * V_PP;     // floats per slab buffer (one 16-channel chunk)
+constexpr int V_XQ = (5 * (V_BT - 1) + 4 * 3 + 7 + 3) / 4 + 1;      // aligned quads a slab can touch (85)
+constexpr int V_EP = 36;             // column pitch (floats) of the exchange tiles: conflict-free b128 (conv_wino.hip)
+constexpr int V_YP = 168;            // row pitch (floats) of the output staging: 16-byte aligned, 4 * 168 % 64 == 32
+constexpr int V_EPI = 2 * 8 * 32 * V_EP;        // exchange tiles of two 32 x 32 sub-tiles (both columns of one mt)
+constexpr int V_Y = 2 * 32 * V_YP;
+constexpr int V_LDS_FLOATS = 2 * V_SLAB > V_EPI + V_Y ? 2 * V_SLAB : V_EPI + V_Y;
+constexpr int V_RUN = 8;             // n-blocks of a panel that run together on one XCD (conv_wino.hip: W_RUN)
+
+// Rows of B^T for the points 0, 1, -1, 2, -2, 1/2, -1/2, inf (tests/tools/winograd_numerics.py: toom_cook(5, 4, ...)):
+//   v = x[off[5]];  v = fma(coef[j], x[off[j]], v)  for j = 0 .. 4        (coef 0: the slot repeats a real sample)
+__device__ const int kB8Off[8][6] = {{2, 4, 0, 0, 0, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6},
+                                     {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 3, 5, 1, 1, 7}};
+__device__ const float kB8Coef[8][5] = {{5.25f, -5.25f, -1.f, 0.f, 0.f},      {1.f, 1.f, -4.25f, -4.25f, 1.f},
+                                        {-1.f, 1.f, 4.25f, -4.25f, -1.f},     {0.5f, 0.25f, -2.5f, -1.25f, 2.f},
+                                        {-0.5f, 0.25f, 2.5f, -1.25f, -2.f},   {2.f, 4.f, -2.5f, -5.f, 0.5f},
+                                        {-2.f, 4.f, 2.5f, -5.f, -0.5f},       {-1.f, 5.25f, -5.25f, 0.f, 0.f}};
+
+struct VSeg {
+  const float* x;
+  const float* u;
+  int cin, ngrp, center;
+};
+__device__ __forceinline__ VSeg load_vseg(const fh_wino_seg* S) {
+  VSeg w;
+  w.x = uni(S->x);
+  w.u = uni(S->u);
+  w.cin = uni(S->cin);
+  w.ngrp = uni(S->ngrp);
+  w.center = uni(S->center);
+  return w;
+}
+
+// VL: rows are contiguous and 16-byte aligned (phase-major tensors, or dilation 1 and len % 4 == 0): the slab is fetched
+// with 16-byte loads and the outputs leave as 16-byte vectors; else 4-byte accesses (any length, any dilation in the
+// plain layout).  Same arithmetic either way.
+template <int MT, bool VL>
+__global__ __attribute__((amdgpu_flat_work_group_size(V_THREADS, V_THREADS), amdgpu_waves_per_eu(2, 2)))
+void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles, int n_tiles,
+                        int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs) {
+  constexpr int BM = 32 * MT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // V_LDS_FLOATS
+
+  // ---- block -> (panel, n block): panels = (group, batch, co tile), heavy groups first (conv_wino.hip) ----------
+  const int panels = n_groups * batch * co_tiles;
+  const int runs_per_panel = (n_tiles + run_len - 1) / run_len;
+  const int total_runs = panels * runs_per_panel;
+  const int bid = blockIdx.x;
+  const int slot = bid >> 3;
+  int run = (slot / run_len) * 8 + (bid & 7);
+  if (run_map) {
+    if (run >= n_runs) return;
+    run = uni(run_map[run]);
+  }
+  if (run >= total_runs) return;
+  const int panel = uni(run / runs_per_panel);
+  const int ntile = uni((run % runs_per_panel) * run_len + (slot % run_len));
+  if (ntile >= n_tiles) return;
+  const int cot = uni(panel % co_tiles);
+  const int gb = uni(panel / co_tiles);
+  const int b = uni(gb % batch);
+  const fh_wino_group* __restrict__ G = groups + uni(gb / batch);
+  const int ph = uni(ntile % dil);            // phase of the decimated sequence
+  const int tb = uni(ntile / dil);            // 320-output block within the phase
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);       // transform point of this wave (= channel pair it stages)
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int co0 = cot * BM;
+  const int len = uni(G->len), cout_pad = uni(G->cout_pad), nseg = uni(G->nseg);
+  if (tb * V_OUT * dil + ph >= len) return;
+
+  // phase-major tensors (pm): row = dil phases of lp samples, x[p + dil u] at p * lp + u; else dil == 1 (host)
+  const int lp = ((len + dil - 1) / dil + 3) & ~3;
+  const int pitch = pm ? dil * lp : len;             // floats per (batch, channel) row, inputs and outputs
+  const int rowlen = pm ? lp : len;                  // addressable samples of this block's (phase) row
+  const int nvalid = (len - ph + dil - 1) / dil;                 // ... of which real (decimated samples of this phase)
+  const int rowbase = pm ? ph * lp : 0;
+
+  // this wave's row of B^T: sample slots and coefficients, wave-uniform
+  int boff[6];
+  f32x2 bco[5];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) boff[j] = uni(kB8Off[xi][j]);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float c = __uint_as_float(uni((int)__float_as_uint(kB8Coef[xi][j])));
+    bco[j] = (f32x2){c, c};
+  }
+  // LDS float offsets of the 6 samples of tap group g relative to the lane's base: sample c = 4 g + off -> plane c % 5,
+  // index tile + c / 5
+  int toff[4][6];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int c = 4 * g + boff[j];
+      toff[g][j] = (c % 5) * V_PP + (c / 5) * 2;
+    }
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- slab staging: wave w stages channel pair w; lane handles aligned quads lane and 64 + lane of the pair's two
+  // rows (two 16-byte loads each), then 4 ds_write_b64 (channel pair) per quad into the planes.  Local sample
+  // v = 4 q + e lands at position w = v - sh (sh = the 0-3 samples between the quad boundary and the first sample
+  // needed), plane w % 5, index w / 5: the readers' offsets do not depend on the block's alignment.
+  constexpr int NXS = VL ? 8 : 6;                      // samples per lane and channel: 2 quads, or lane + 64 i, i < 6
+  int wofs[NXS];                                       // LDS float offsets of this lane's samples, -1 = not stored
+  int ua = 0;                                          // decimated index of local sample 0 (VL: a multiple of 4)
+  auto setup_seg = [&](const VSeg& S) {
+    const int ub = tb * V_OUT - S.center;
+    const int sh = VL ? (ub & 3) : 0;
+    ua = ub - sh;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const int v = VL ? 4 * (lane + 64 * (i >> 2)) + (i & 3) : lane + 64 * i;
+      const int w = v - sh;
+      wofs[i] = (v < 4 * V_XQ && w >= 0) ? (w % 5) * V_PP + xi * V_PAIR + (w / 5) * 2 : -1;
+    }
+  };
+  unsigned xq[2][NXS];                                 // [channel of the pair][sample]
+  auto load_x = [&](const VSeg& S, int chunk, bool valid) {
+    const __amdgpu_buffer_rsrc_t r =
+        make_rsrc(uni(S.x + (size_t)b * S.cin * pitch), valid ? (unsigned)(S.cin * pitch) * 4u : 0u);
+    const int row0 = (chunk * V_CK + 2 * xi) * pitch;
+    if constexpr (VL) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = lane + 64 * i, qa = (ua >> 2) + q;
+        const bool ok = q < V_XQ && qa >= 0 && 4 * qa < rowlen;               // (outside the row: zero padding)
+        const int e0 = row0 + rowbase + 4 * qa;
+        const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)e0 * 4u : 0x80000000u, 0, 0);
+        const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(e0 + pitch) * 4u : 0x80000000u, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xq[0][4 * i + e] = t0[e];
+          xq[1][4 * i + e] = t1[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        const int u = ua + lane + 64 * i;                                     // decimated index
+        const int pos = u * dil + ph;                                         // position in the clip
+        const bool ok = lane + 64 * i < 4 * V_XQ && (unsigned)pos < (unsigned)len;
+        const int e0 = row0 + (pm ? rowbase + u : pos);
+        xq[0][i] = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)e0 * 4u : 0x80000000u, 0, 0);
+        xq[1][i] = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)(e0 + pitch) * 4u : 0x80000000u, 0, 0);
+      }
+    }
+  };
+  auto store_x = [&](int buf) {
+    float* dst = lds + buf * V_SLAB;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const int v = VL ? 4 * (lane + 64 * (i >> 2)) + (i & 3) : lane + 64 * i;
+      const bool real = !VL || ua + v < nvalid;                               // (VL, last block of the row: zero past the end)
+      const f32x2 val = {real ? __uint_as_float(xq[0][i]) : 0.f, real ? __uint_as_float(xq[1][i]) : 0.f};
+      if (wofs[i] >= 0) *reinterpret_cast<f32x2*>(dst + wofs[i]) = val;
+    }
+  };
+
+  // A fragments of one step, [mt][half]: half h holds k-steps 4h .. 4h+3 (conv_wino.hip)
+  u32x4 areg[MT][2];
+  const int a_lane = (l31 * V_CK + lh * 8) * 4;
+  auto load_a_half = [&](int h, const VSeg& S, int chunk, int g, bool valid) {
+    const float* up = uni(S.u + ((size_t)((chunk * S.ngrp + g) * 8 + xi) * cout_pad + co0) * V_CK);
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? BM * V_CK * 4 : 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      areg[mt][h] = __builtin_amdgcn_raw_buffer_load_b128(r, a_lane + mt * 32 * V_CK * 4 + 16 * h, 0, 0);
+  };
+  // L2 warm-up of the A tiles of the NEXT chunk (all its tap groups, this wave's xi), as in conv_wino.hip
+  unsigned pf = 0;
+  auto prefetch_a = [&](const VSeg& S, int chunk, bool valid) {
+    const float* up = uni(S.u + ((size_t)(chunk * S.ngrp * 8 + xi) * cout_pad + co0) * V_CK);
+    const unsigned gstride = 8u * (unsigned)cout_pad * V_CK * 4u;          // bytes between tap groups
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? (unsigned)(S.ngrp - 1) * gstride + BM * V_CK * 4 : 0u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned off = l31 < BM * V_CK / 32 ? (unsigned)(2 * j + lh) * gstride + (unsigned)l31 * 128u : 0x80000000u;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pf) : "v"(off), "s"(r) : "memory");
+    }
+  };
+
+  // ---- K loop -----------------------------------------------------------------------------------------------------
+  // A chunk is a flat sequence of k-step PAIRS p = 4 g + kp (tap group g, channel pair kp of the lane's half): 6
+  // ds_read2_b64 (one sample for both columns each), 10 packed FMAs, 4 MT MFMAs.  The samples of pair p + 1 are
+  // requested behind the transform of pair p, in the same registers.
+  int xbuf = 0;
+  const int lane_base = lh * 4 * V_PAIR + l31 * 2;
+  auto run_segment = [&](auto gc, const VSeg& S) {
+    constexpr int GC = decltype(gc)::value;
+    const int nch = S.cin / V_CK;
+    setup_seg(S);
+    load_a_half(0, S, 0, 0, true);
+    load_a_half(1, S, 0, 0, true);
+    load_x(S, 0, true);
+    store_x(xbuf);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      const bool has_next = c + 1 < nch;
+      const float* xsb = lds + xbuf * V_SLAB + lane_base;
+      f32x2 xr[6][2];                                   // [sample slot][column] = (k-step 2 kp, 2 kp + 1)
+      auto fetch = [&](int p) {
+        const int g = p >> 2, kp = p & 3;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float* q = xsb + toff[g][j] + kp * V_PAIR;
+          xr[j][0] = *reinterpret_cast<const f32x2*>(q);
+          xr[j][1] = *reinterpret_cast<const f32x2*>(q + 64);
+        }
+      };
+      fetch(0);
+#pragma unroll
+      for (int p = 0; p < 4 * GC; ++p) {
+        const int g = p >> 2, kp = p & 3, h = kp >> 1;
+        if (p == 0) {
+          load_x(S, c + 1, has_next);                  // stored at the end of this chunk
+          prefetch_a(S, c + 1, has_next);
+        }
+        f32x2 bf[2];                                   // [column] = B values of k-steps 2 kp, 2 kp + 1
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          // (inline asm: packed FMAs, and kept out of the MFMA groups below; VALU result -> MFMA operand needs 2 wait
+          // states, the s_nop behind the last one covers both columns: conv_wino.hip)
+          asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bf[nt]) : "s"(bco[0]), "v"(xr[0][nt]), "v"(xr[5][nt]));
+          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(bco[1]), "v"(xr[1][nt]));
+          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(bco[2]), "v"(xr[2][nt]));
+          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(bco[3]), "v"(xr[3][nt]));
+          if (nt == 0)
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(bco[4]), "v"(xr[4][nt]));
+          else
+            asm("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(bf[nt]) : "s"(bco[4]), "v"(xr[4][nt]));
+        }
+        if (p + 1 < 4 * GC) fetch(p + 1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int e = 2 * (kp & 1) + k2;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[mt][h][e]), bf[nt][k2],
+                                                                 acc[mt][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kp & 1) {                                  // this half of the A registers is free: refill it for the next step
+          const bool same_chunk = g + 1 < GC;
+          load_a_half(h, S, same_chunk ? c : c + 1, same_chunk ? g + 1 : 0, same_chunk || has_next);
+        }
+      }
+      if (has_next) {
+        store_x(xbuf ^ 1);
+        __syncthreads();
+        xbuf ^= 1;
+      }
+    }
+    xbuf ^= 1;                   // the next segment's first slab goes to the buffer nobody is reading
+  };
+
+  // Segments are sorted by tap-group count, descending (host: make_wino_group)
+  int sg = 0;
+  VSeg S0 = load_vseg(&G->seg[0]);
+  auto run_all = [&](auto gc) {
+    while (sg < nseg && S0.ngrp == decltype(gc)::value) {
+      run_segment(gc, S0);
+      ++sg;
+      if (sg < nseg) S0 = load_vseg(&G->seg[sg]);
+    }
+  };
+  run_all(std::integral_constant<int, 4>{});
+  run_all(std::integral_constant<int, 3>{});
+  run_all(std::integral_constant<int, 2>{});
+  run_all(std::integral_constant<int, 1>{});
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------------
+  const int nres = uni(G->nres);
+  const float scale = G->scale;
+  const int cout = uni(G->cout);
+  const float* __restrict__ bias = uni(G->bias);
+  const size_t oslab = (size_t)b * cout * pitch;
+  const unsigned slab_bytes = (unsigned)cout * (unsigned)pitch * 4u;
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(uni((const float*)G->out) + oslab, slab_bytes);
+  const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? uni(G->res[0]) + oslab : nullptr, nres > 0 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? uni(G->res[1]) + oslab : nullptr, nres > 1 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? uni(G->res[2]) + oslab : nullptr, nres > 2 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (unsigned)cout * 4u : 0u);
+  float* const E = lds;                               // [column nt][xi][tile col 32][row, pitch V_EP]
+  float* const Y = lds + V_EPI;                       // [column nt][row 32][160 outputs, pitch V_YP]
+  const int ent = tid >> 8, erq = (tid >> 5) & 7, ecol = tid & 31;        // A^T item: column, row quad, tile
+  const int v_first = tb * V_OUT;                     // decimated index of the block's first output
+  __syncthreads();                                    // every wave is out of the K loop: the slab space is free
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (mt > 0) __syncthreads();                       // (the store phase of the previous round is done with Y and E)
+    {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float* ew = E + ((nt * 8 + xi) * 32 + l31) * V_EP + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(ew + 8 * q) =
+              (f32x4){acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+      }
+    }
+    __syncthreads();
+    {
+      const float* er = E + (ent * 8 * 32 + ecol) * V_EP + 4 * erq;
+      f32x4 m[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) m[x] = *reinterpret_cast<const f32x4*>(er + x * 32 * V_EP);
+      // (vector index = row of the quad) points 0, 1, -1, 2, -2, 1/2, -1/2, inf
+      const f32x4 s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4], s3 = m[5] + m[6], d3 = m[5] - m[6];
+      f32x4 y[5];
+      y[0] = ((m[0] + s1) + s2) + s3;
+      y[1] = __builtin_elementwise_fma((f32x4)(0.5f), d3, __builtin_elementwise_fma((f32x4)(2.f), d2, d1));
+      y[2] = __builtin_elementwise_fma((f32x4)(0.25f), s3, __builtin_elementwise_fma((f32x4)(4.f), s2, s1));
+      y[3] = __builtin_elementwise_fma((f32x4)(0.125f), d3, __builtin_elementwise_fma((f32x4)(8.f), d2, d1));
+      y[4] = __builtin_elementwise_fma((f32x4)(0.0625f), s3, __builtin_elementwise_fma((f32x4)(16.f), s2, s1)) + m[7];
+      float* yw = Y + (ent * 32 + 4 * erq) * V_YP + 5 * ecol;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) yw[i * V_YP + q] = y[q][i];
+    }
+    // store items of this thread: 5 of the 1280 float4 of its column's 32 x 160 sub-tile; first residual requested
+    // in front of the barrier (the A^T registers are dead)
+    u32x4 rpre[5];
+    unsigned soff[5];
+    int srow[5], scol[5], nreal[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int item = (tid & 255) + 256 * i;
+      srow[i] = item / 40;
+      scol[i] = (item % 40) * 4;
+      const int co = co0 + mt * 32 + srow[i];
+      const int v0 = v_first + ent * 160 + scol[i];                       // decimated index of the vector's first output
+      nreal[i] = co < cout ? nvalid - v0 : 0;                             // real outputs from v0 on (<= 0: none)
+      soff[i] = ((unsigned)co * (unsigned)pitch + (unsigned)(rowbase + v0)) * 4u;
+      if (VL && nres > 0)
+        rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, nreal[i] >= 4 ? soff[i] : 0x80000000u, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(Y + (ent * 32 + srow[i]) * V_YP + scol[i]);
+      const int co = co0 + mt * 32 + srow[i];
+      const float bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, nreal[i] > 0 ? (unsigned)co * 4u : 0x80000000u, 0, 0));
+      if (VL && nreal[i] >= 4) {
+        f32x4 o = {yv[0] + bv, yv[1] + bv, yv[2] + bv, yv[3] + bv};
+        if (nres > 0) {
+          u32x4 t = rpre[i];
+          f32x4 rs = {__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+          if (nres > 1) {
+            t = __builtin_amdgcn_raw_buffer_load_b128(rr1, soff[i], 0, 0);
+            rs += (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+          }
+          if (nres > 2) {
+            t = __builtin_amdgcn_raw_buffer_load_b128(rr2, soff[i], 0, 0);
+            rs += (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+          }
+          o += rs;
+        }
+        o *= scale;
+        const u32x4 ou = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(ou, ro, soff[i], 0, 0);
+      } else if (nreal[i] > 0) {                        // the row ends inside this vector, or rows are not 16-byte aligned
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // (plain layout with a dilation: output v sits at ph + dil v of the row)
+          const unsigned off = q < nreal[i] ? (pm || dil == 1 ? soff[i] + 4u * q : soff[i] + 4u * (unsigned)(ph + (dil - 1) * (v_first + ent * 160 + scol[i]) + dil * q)) : 0x80000000u;
+          float o = yv[q] + bv;
+          if (nres > 0) {
+            float rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));
+            if (nres > 1) rs += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off, 0, 0));
+            if (nres > 2) rs += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off, 0, 0));
+            o += rs;
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o * scale), ro, off, 0, 0);
+        }
+      }
+    }
+  }
+  // (keeps pf alive: the prefetch loads above are never read; never true for finite weights)
+  if (pf == 0x7fc12345u) __builtin_amdgcn_s_sleep(1);
+}
+
+template <int MT, bool VL>
+int launch_wino54(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation, int pm,
+                  hipStream_t stream, const int* run_map, int n_runs) {
+  constexpr int BM = 32 * MT;
+  FH_CHECK_ARG(cout_pad > 0 && cout_pad % BM == 0, "fh_conv_wino54_f32: cout_pad %d not a multiple of %d", cout_pad, BM);
+  const int co_tiles = cout_pad / BM;
+  const int n_tiles = fh_cdiv(fh_cdiv(len, dilation), V_OUT) * dilation;
+  const long long panels = (long long)n_groups * batch * co_tiles;
+  const int run_len = fh_cdiv(n_tiles, fh_cdiv(n_tiles, V_RUN));
+  const long long runs = run_map ? (long long)n_runs : panels * fh_cdiv(n_tiles, run_len);
+  const long long blocks = (long long)fh_cdiv(runs, 8) * 8 * run_len;
+  FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino54_f32: grid too large");
+  static std::atomic<bool> lds_opt_in[FH_MAX_DEVICES];      // (> 64 KB of dynamic LDS: once per device, conv_wino.hip)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) {
+    fh_set_error("fh_conv_wino54_f32: no current HIP device (or ordinal >= %d)", FH_MAX_DEVICES);
+    return FH_E_LAUNCH;
+  }
+  if (!lds_opt_in[dev].load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino54_kernel<MT, VL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       V_LDS_FLOATS * 4);
+    if (e != hipSuccess) {
+      fh_set_error("fh_conv_wino54_f32: cannot reserve %d bytes of LDS on device %d: %s", V_LDS_FLOATS * 4, dev, hipGetErrorString(e));
+      return FH_E_LAUNCH;
+    }
+    lds_opt_in[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((conv_wino54_kernel<MT, VL>), dim3((unsigned)blocks), dim3(V_THREADS), V_LDS_FLOATS * 4, stream, groups,
+                     n_groups, batch, co_tiles, n_tiles, run_len, dilation, pm, run_map, n_runs);
+  FH_CHECK_LAUNCH("fh_conv_wino54_f32");
+  return FH_OK;
+}
+
+}  // namespace
+
+extern "C" int fh_wino54_tile_m(int tile_cfg) { return tile_cfg == 0 ? 128 : tile_cfg == 1 ? 96 : tile_cfg == 2 ? 64 : -1; }
+extern "C" int fh_wino54_tile_n(void) { return V_OUT; }
+
+namespace {
+int wino54_dispatch(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation,
+                    int layout_flags, int tile_cfg, hipStream_t st, const int* run_map, int n_runs) {
+  const int pm = layout_flags & 1;
+  // 16-byte accesses need contiguous aligned rows (layout bit 1: the caller rules them out -- ragged launches in which
+  // some group's rows are not 16-byte aligned; `len` is then only the longest group's length)
+  const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(layout_flags & 2);
+#define FH_W54_CASE(id, MT)                                                                                         \
+  case id:                                                                                                          \
+    return vl ? launch_wino54<MT, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs)  \
+              : launch_wino54<MT, false>(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
+  switch (tile_cfg) {
+    FH_W54_CASE(0, 4)
+    FH_W54_CASE(1, 3)
+    FH_W54_CASE(2, 2)
+  }
+#undef FH_W54_CASE
+  fh_set_error("fh_conv_wino54_f32: unknown tile_cfg %d", tile_cfg);
+  return FH_E_ARG;
+}
+}  // namespace
+
+extern "C" int fh_conv_wino54_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
+                                  int dilation, int phase_major, int tile_cfg, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && len > 0, "fh_conv_wino54_f32: bad sizes");
+  FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino54_f32: dilation %d unsupported", dilation);
+  return wino54_dispatch(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0 ? 1 : 0, tile_cfg, (hipStream_t)stream,
+                         nullptr, 0);
+}
+
+extern "C" int fh_wino54_run_len(int n_tiles) { return n_tiles > 0 ? fh_cdiv(n_tiles, fh_cdiv(n_tiles, V_RUN)) : -1; }
+
+extern "C" int fh_conv_wino54_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
+                                         int layout_flags, int tile_cfg, const int* run_map, int n_runs, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && max_len > 0 && run_map && n_runs > 0, "fh_conv_wino54_ragged_f32: bad sizes");
+  FH_CHECK_ARG(layout_flags >= 0 && layout_flags <= 3, "fh_conv_wino54_ragged_f32: layout_flags %d (bit 0 phase-major, bit 1 no vector accesses)", layout_flags);
+  FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino54_ragged_f32: dilation %d unsupported", dilation);
+  return wino54_dispatch(groups, n_groups, 1, cout_pad, max_len, dilation, layout_flags, tile_cfg, (hipStream_t)stream, run_map, n_runs);
+}

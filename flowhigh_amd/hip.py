@@ -76,6 +76,11 @@ _SIGS = {
     "fh_wino_tile_n": [_I],
     "fh_wino_run_len": [_I],
     "fh_conv_wino_ragged_f32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "fh_wino54_tile_m": [_I],
+    "fh_wino54_tile_n": [],
+    "fh_conv_wino54_f32": [_P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fh_wino54_run_len": [_I],
+    "fh_conv_wino54_ragged_f32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "fh_mean_f32": [_P, _P, _P, _P, C.c_longlong, _F, _P],
     "fh_sum_f32": [_P, C.c_int, _P, C.c_longlong, _F, _P],
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

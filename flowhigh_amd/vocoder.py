@@ -147,8 +147,13 @@ def make_act_group(x, y, p):
 
 # Winograd tiles (tile_cfg -> rows x outputs) and their measured block time on one CU: _WINO_COST[cfg] = (a, b),
 # a us per K step (16 input channels x one tap group), b us of prologue + epilogue (tools/wino_cfg_sweep.py)
-_WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256)}
-_WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0), 6: (2.75, 20.0)}
+# | WINO_F54: the F(5,4) kernel (conv_wino54.hip: 8-wave blocks of 128 / 96 / 64 co x 320 outputs; K steps = 16 input
+# channels x one group of FOUR taps; constants from tools/wino54_bench.py fit)
+WINO_F54 = 256            # flag in a plan's tile id: the launch runs fh_conv_wino54_f32 with tile_cfg = id & 15
+_WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256),
+               WINO_F54 | 0: (128, 320), WINO_F54 | 1: (96, 320), WINO_F54 | 2: (64, 320)}
+_WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0), 6: (2.75, 20.0),
+              WINO_F54 | 0: (4.0, 15.0), WINO_F54 | 1: (3.05, 14.0), WINO_F54 | 2: (2.1, 13.0)}
 # 128-row tiles halve the LDS reads and transform instructions per MFMA (one B fragment feeds 4 MFMAs) but
 # double the weight bytes a block streams: beyond this panel size (6 x 128 rows x K, bytes) a chip full of
 # such blocks thrashes the 4 MB L2s (C = 768: 857 us against 732 us with 64 x 512 tiles)
@@ -174,7 +179,7 @@ def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=F
     bm, bt = _WINO_TILES[cfg]
     a, b = _WINO_COST[cfg]
     if bf:
-        a *= _WINO_BF_SPEED[cfg]
+        a *= _WINO_BF_SPEED[cfg]              # (the F(5,4) kernel has no bf16 x 6 form: never asked for)
     n_tiles = -(-(-(-length // dil)) // bt) * dil
     cot = wpad // bm
     panel_w = [a * k + b for k in ksteps for _ in range(batch * cot)]
@@ -208,7 +213,9 @@ def _choose_wino_cfg(ksteps, batch, wpad, length, dil, default, bf=False):
     """Tile shape with the smallest estimated launch time among those the packed weights (cout_pad) allow;
     the default shape stays unless another one is estimated at least 3 % faster (the model is good to a few
     per cent; at large batch every shape is within that and the default has the best steady state)."""
-    cands = [cfg for cfg, (bm, _) in _WINO_TILES.items() if wpad % bm == 0 and cfg not in _WINO_TILES_OFF]
+    fam = WINO_F54 if (default is not None and default & WINO_F54) else 0             # tiles of the default's kernel only
+    cands = [cfg for cfg, (bm, _) in _WINO_TILES.items()
+             if wpad % bm == 0 and cfg not in _WINO_TILES_OFF and (cfg & WINO_F54) == fam]
     cost = {cfg: wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, bf=bf) for cfg in cands}
     best = min(cands, key=lambda cfg: cost[cfg])
     if default in cost and cost[best] > 0.97 * cost[default]:
@@ -230,6 +237,26 @@ def pick_wino_tile(c):
     return 0, -(-c // WINO_BM) * WINO_BM
 
 
+def pick_wino54_tile(c):
+    """(plan tile id, cout_pad) of the F(5,4) kernel: 128-row blocks where they divide c, else 96, else 64 (padded)."""
+    if c % 128 == 0:
+        return WINO_F54 | 0, c
+    if c % 96 == 0:
+        return WINO_F54 | 1, c
+    return WINO_F54 | 2, -(-c // 64) * 64
+
+
+# Residual-stack convs run in the F(5,4) form (conv_wino54.hip) from this many channels on: 20 % fewer matrix
+# instructions and fewer vector / LDS instructions per MFMA than F(4,3) (tools/wino54_bench.py: x 1.15-1.3 per launch at
+# 192-768 channels, x 1.1-1.2 at 96).  FH_WINO54=0 switches it off (every Winograd conv in the F(4,3) form).  The choice
+# is per STAGE (channel count), never per length or batch: a clip gets the same bits alone, batched, ragged, chunked.
+WINO54_MIN_C = 96
+
+
+def use_wino54(c):
+    return os.environ.get("FH_WINO54", "1") != "0" and use_wino(c, 1) and c >= WINO54_MIN_C
+
+
 def pack_wino_weight(w, cout_pad):
     """Conv1d weight [co, ci, k] -> transformed [ci/16, G, 6, cout_pad, 16], G = ceil(k/3):
     u[c, g, xi, co, :] = sum_j G[xi][j] w[co, 16c:16c+16, 3g + j] (float64 on the host, taps past k = 0)."""
@@ -243,6 +270,30 @@ def pack_wino_weight(w, cout_pad):
     u = torch.einsum("xj,ocgj->gxoc", gm, wp.view(co, ci, ng, 3))                 # [G, 6, co, ci]
     u = u.reshape(ng, 6, co, ci // 16, 16).permute(3, 0, 1, 2, 4)                # [ci/16, G, 6, co, 16]
     p = torch.zeros(ci // 16, ng, 6, cout_pad, 16, dtype=torch.float32)
+    p[:, :, :, :co, :] = u.float()
+    return p.contiguous()
+
+
+# Winograd F(5,4) weight transform G (8 x 4); points 0, 1, -1, 2, -2, 1/2, -1/2, inf with the scaling of
+# tests/tools/winograd_numerics.py: toom_cook (B^T then has the small constants of conv_wino54.hip: kB8Coef)
+_WINO54_G = [[-1, 0, 0, 0], [-2 / 9, -2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9, 2 / 9],
+             [1 / 90, 1 / 45, 2 / 45, 4 / 45], [1 / 90, -1 / 45, 2 / 45, -4 / 45],
+             [32 / 45, 16 / 45, 8 / 45, 4 / 45], [32 / 45, -16 / 45, 8 / 45, -4 / 45], [0, 0, 0, 1]]
+
+
+def pack_wino54_weight(w, cout_pad):
+    """Conv1d weight [co, ci, k] -> transformed [ci/16, G, 8, cout_pad, 16], G = ceil(k/4):
+    u[c, g, xi, co, :] = sum_j G8[xi][j] w[co, 16c:16c+16, 4g + j] (float64 on the host, taps past k = 0)."""
+    co, ci, k = w.shape
+    if ci % 16:
+        raise ValueError(f"input channels {ci} must be a multiple of 16")
+    ng = -(-k // 4)
+    wp = torch.zeros(co, ci, 4 * ng, dtype=torch.float64)
+    wp[:, :, :k] = w.double()
+    gm = torch.tensor(_WINO54_G, dtype=torch.float64)
+    u = torch.einsum("xj,ocgj->gxoc", gm, wp.view(co, ci, ng, 4))                 # [G, 8, co, ci]
+    u = u.reshape(ng, 8, co, ci // 16, 16).permute(3, 0, 1, 2, 4)                # [ci/16, G, 8, co, 16]
+    p = torch.zeros(ci // 16, ng, 8, cout_pad, 16, dtype=torch.float32)
     p[:, :, :, :co, :] = u.float()
     return p.contiguous()
 
@@ -282,9 +333,15 @@ def _addr(t):
     return t if isinstance(t, int) else hip.ptr(t)
 
 
+def wino_taps(cfg):
+    """Taps per group of the kernel a plan tile id names: 4 (F(5,4)) or 3 (F(4,3))."""
+    return 4 if cfg & WINO_F54 else 3
+
+
 def wino_split_k(ks, c, wpad, length, dil, default_cfg, bf=False):
     """Number of input-channel slices (1, 2 or 3) of a residual-stack launch (one group per kernel size in ks)."""
-    return wino_split_steps([c // 16 * -(-k // 3) for k in ks], c, wpad, length, dil, default_cfg, bf)
+    t = wino_taps(default_cfg)
+    return wino_split_steps([c // 16 * -(-k // t) for k in ks], c, wpad, length, dil, default_cfg, bf)
 
 
 def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg, bf=False):
@@ -312,6 +369,8 @@ def wino_block_mapping(groups, batch, wpad, length, dil, wcfg):
     a panel's weights are fetched ~once, but the co tiles of a group sit on up to 8 XCDs and each reads the group's
     whole input: input x min(co tiles, 8), weights x min(runs per panel, 8).  By time range: the input is read once,
     every XCD fetches all weights once per rectangle of time tiles: weights x 8 x rectangles.  Same bits either way; transposed-conv phase groups (strided outputs) keep the default."""
+    if wcfg & WINO_F54:
+        return 0
     bm, bt = _WINO_TILES[wcfg]
     n_tiles = -(-(-(-length // dil)) // bt) * dil
     # (batch 1 only: with more batch items the by-panel blocks of different items already share a panel's weights through
@@ -330,9 +389,10 @@ def wino_block_mapping(groups, batch, wpad, length, dil, wcfg):
     return WINO_XCD_RANGES if by_range < 0.9 * by_panel else 0
 
 
-def make_wino_seg(x, u, cin, k, center=None, xlen=0):
+def make_wino_seg(x, u, cin, k, center=None, xlen=0, taps=3):
+    """taps: 3 for the F(4,3) kernel's weights (pack_wino_weight), 4 for F(5,4) (pack_wino54_weight)."""
     s = hip.WinoSeg()
-    s.x, s.u, s.cin, s.ngrp = _addr(x), _addr(u), cin, -(-k // 3)
+    s.x, s.u, s.cin, s.ngrp = _addr(x), _addr(u), cin, -(-k // taps)
     s.center = (k - 1) // 2 if center is None else center
     s.xlen = xlen
     return s
@@ -396,6 +456,10 @@ def from_phase_major(xp, d, length):
 def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0, phase_major=False):
     """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
     d = hip.to_device_struct_array(groups, device)
+    if tile_cfg & WINO_F54:            # (F(5,4) kernel: the groups' weights are pack_wino54_weight, ngrp = ceil(k / 4))
+        hip.check(hip.lib().fh_conv_wino54_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
+                                               int(phase_major), tile_cfg & 15, hip.stream()), "fh_conv_wino54_f32")
+        return d
     hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
                                          int(phase_major), tile_cfg, hip.stream()), "fh_conv_wino_f32")
     return d
@@ -565,14 +629,17 @@ class _PlanBuilder:
                                   B, wpad, length, dil, default=wcfg, bf=self.v.bf)
         wcfg |= wino_block_mapping(groups, B, wpad, length, dil, wcfg)
         if novl:
+            if wcfg & WINO_F54:
+                raise NotImplementedError("the F(5,4) kernel takes no segments with xlen")
             wcfg |= WINO_NOVL
         d = hip.to_device_struct_array(groups, self.v.device)
         self.keep.append(d)
         if flops is None:
             flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
                         for g in groups for i in range(g.nseg))
-        # multiply-adds the matrix cores actually execute: 6 per 4 outputs per tap group
-        self.executed += sum(2.0 * g.cout * g.seg[i].cin * 1.5 * g.seg[i].ngrp * length * B
+        # multiply-adds the matrix cores actually execute: 6 per 4 outputs per group of 3 taps, or 8 per 5 per group of 4
+        per_out = 1.6 if wcfg & WINO_F54 else 1.5
+        self.executed += sum(2.0 * g.cout * g.seg[i].cin * per_out * g.seg[i].ngrp * length * B
                              for g in groups for i in range(g.nseg))
         self.add(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B), groups)
 
@@ -603,7 +670,7 @@ class _PlanBuilder:
                 for sl in range(nsplit):
                     dst = outs[i] if sl == 0 else parts[2 * i + sl - 1]
                     for b in range(B):
-                        seg = make_wino_seg(addr(xs_in[i], b, sl * cs), e["u"][sl * cs // 16:], cs, ks[i])
+                        seg = make_wino_seg(addr(xs_in[i], b, sl * cs), e["u"][sl * cs // 16:], cs, ks[i], taps=st["taps"])
                         groups.append(make_wino_group([seg], biases[i] if sl == 0 else None,
                                                       [addr(r, b, 0) for r in res[i]] if sl == 0 else [],
                                                       addr(dst, b, 0), c, wpad, L))
@@ -614,8 +681,8 @@ class _PlanBuilder:
                     self.add(("sum", pieces[i], outs[i], B * c * pitch, 1.0), key=self.key[:2] + (self.key[2] + 1, i))
             return pieces
         if all_wino:
-            self.wino([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i])], biases[i], res[i], outs[i],
-                                       c, wpad, L) for i in range(len(ents))], wpad, L, dil, st["wcfg"], pm)
+            self.wino([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i], taps=st["taps"])], biases[i], res[i],
+                                       outs[i], c, wpad, L) for i in range(len(ents))], wpad, L, dil, st["wcfg"], pm)
         else:
             groups = []
             for i, e in enumerate(ents):
@@ -690,13 +757,13 @@ class _PlanBuilder:
         # (Winograd phase groups: all have `npos` positions, writes at u * n + r >= L are masked: fh_wino_group.out_len)
         xlen, olen = (lin, L) if extra else (0, 0)
         up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
-        nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"], st["wpad"],
-                                  self.lin_ref + extra, 1, st["wcfg"], v.bf)
+        nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"], st["up_wpad"],
+                                  self.lin_ref + extra, 1, st["up_wcfg"], v.bf)
         if nsplit == 1:
             self.wino([make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"], xlen=xlen)], st["up_b"],
-                                       [], X, c, st["wpad"], npos, stride=u, phase=r, out_len=olen)
+                                       [], X, c, st["up_wpad"], npos, stride=u, phase=r, out_len=olen)
                        for r, ph in enumerate(st["up_wino"])],
-                      st["wpad"], npos, 1, st["wcfg"], flops=up_flops, novl=bool(extra))
+                      st["up_wpad"], npos, 1, st["up_wcfg"], flops=up_flops, novl=bool(extra))
             return
         parts = self.parts_buffer()             # short clips: input channels in slices, as in res_conv
         cs = st["cin"] // nsplit
@@ -704,9 +771,9 @@ class _PlanBuilder:
         groups = [make_wino_group([make_wino_seg(cur.data_ptr() + 4 * (b * st["cin"] + sl * cs) * lin,
                                                  ph["u"][sl * cs // 16:], cs, ph["k"], ph["center"], xlen=xlen)],
                                   st["up_b"] if sl == 0 else None, [], dsts[sl].data_ptr() + 4 * b * c * L,
-                                  c, st["wpad"], npos, stride=u, phase=r, out_len=olen)
+                                  c, st["up_wpad"], npos, stride=u, phase=r, out_len=olen)
                   for r, ph in enumerate(st["up_wino"]) for sl in range(nsplit) for b in range(B)]
-        self.wino(groups, st["wpad"], npos, 1, st["wcfg"], flops=up_flops, batch=1, novl=bool(extra))
+        self.wino(groups, st["up_wpad"], npos, 1, st["up_wcfg"], flops=up_flops, batch=1, novl=bool(extra))
         self.add(("sum", dsts, X, B * c * L, 1.0), key=(i, -1, 1, 0))
 
     def amp1_stack(self, i):
@@ -783,12 +850,12 @@ class _PlanBuilder:
         scale = 1.0 / v.nk
         fusable = v.nk <= hip.CONV_MAX_SEG          # (K segments of one group; more blocks: one group each + one averaging pass)
         if all("u" in e for e in ents):
-            ksteps = [c // 16 * -(-k // 3) for k in ks]
+            ksteps = [c // 16 * -(-k // st["taps"]) for k in ks]
             Lr = self.Lref
             unfuse = not fusable or (v.nk in (2, 3) and (choose_wino_cfg(ksteps, 1, wpad, Lr, 1, st["wcfg"], v.bf)[1] + 4.0 + c * Lr * 16 / 4.0e6
                                                          < choose_wino_cfg([sum(ksteps)], 1, wpad, Lr, 1, st["wcfg"], v.bf)[1]))
             if not unfuse:
-                segs = [make_wino_seg(T1[j], e["u"], c, k) for j, e, k in zip(order, ents, ks)]
+                segs = [make_wino_seg(T1[j], e["u"], c, k, taps=st["taps"]) for j, e, k in zip(order, ents, ks)]
                 self.wino([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, wpad, L, scale=scale)],
                           wpad, L, 1, st["wcfg"])
                 return
@@ -946,7 +1013,14 @@ class Vocoder:
                 if not (wino_k and use_wino(c, 1)) and (kk > hip.CONV_MAX_TAPS or (kk - 1) * max(dl) > hip.CONV_MAX_HALO):
                     raise NotImplementedError(f"resblock kernel {kk} x dilation {max(dl)} exceeds the direct kernel's "
                                               f"{hip.CONV_MAX_TAPS} taps / {hip.CONV_MAX_HALO} samples of reach")
-            st["wcfg"], st["wpad"] = pick_wino_tile(c)
+            # residual stack: F(5,4) kernel from WINO54_MIN_C channels on (not in the bf16 x 6 form), else F(4,3); the
+            # transposed conv's phase groups always run in the F(4,3) kernel (strided outputs)
+            st["up_wcfg"], st["up_wpad"] = pick_wino_tile(c)
+            st["w54"] = use_wino54(c) and not self.bf and max(self.ks) <= WINO_MAX_K
+            st["wcfg"], st["wpad"] = pick_wino54_tile(c) if st["w54"] else (st["up_wcfg"], st["up_wpad"])
+            st["taps"] = 4 if st["w54"] else 3
+            pack_res = (lambda w_: pack_wino54_weight(w_, st["wpad"])) if st["w54"] else \
+                (lambda w_: pack_wino_weight_any(w_, st["wpad"], self.bf))
             wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
             st["up_b"] = g(f"ups.{i}.0.bias").to(dev)
             st["up_phases"] = []
@@ -960,7 +1034,7 @@ class Vocoder:
                 st["up_wino"] = []
                 for taps in transposed_conv_phases(k, u):
                     wph, center = wino_phase_weight(wt, taps)
-                    st["up_wino"].append(dict(u=pack_wino_weight_any(wph, st["wpad"], self.bf).to(dev), k=wph.shape[-1], center=center))
+                    st["up_wino"].append(dict(u=pack_wino_weight_any(wph, st["up_wpad"], self.bf).to(dev), k=wph.shape[-1], center=center))
             st["blocks"] = []
             for j in range(self.nk):
                 r = i * self.nk + j
@@ -971,7 +1045,7 @@ class Vocoder:
                         ent = dict(b=g(f"resblocks.{r}.convs.{m}.bias").to(dev))
                         w = g(f"resblocks.{r}.convs.{m}.weight")
                         if wino_k and use_wino(c, d) and all(self.dil[jj][m] == d for jj in range(self.nk)):
-                            ent["u"] = pack_wino_weight_any(w, st["wpad"], self.bf).to(dev)
+                            ent["u"] = pack_res(w).to(dev)
                         else:
                             ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
                         blk["c1"].append(ent)
@@ -985,7 +1059,7 @@ class Vocoder:
                         # convs1[m] of the nk blocks share one launch: Winograd only if they share the dilation
                         same_d = tag == "convs2" or all(self.dil[jj][m] == d for jj in range(self.nk))
                         if wino_k and use_wino(c, d) and same_d:
-                            ent["u"] = pack_wino_weight_any(w, st["wpad"], self.bf).to(dev)
+                            ent["u"] = pack_res(w).to(dev)
                         else:
                             ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
                         lst.append(ent)
@@ -1106,15 +1180,15 @@ class Vocoder:
                 for ci, st_, groups in items:
                     _, _d, ng, wpad, length, dil, _fl, wcfg, pm, bb = st_
                     assert bb == 1 and ng == len(groups)
-                    classes.setdefault((wpad, dil, pm), []).append((length, wcfg, groups))
-                for (wpad, dil, pm), lst in classes.items():
+                    classes.setdefault((wpad, dil, pm, wcfg & WINO_F54), []).append((length, wcfg, groups))
+                for (wpad, dil, pm, fam), lst in classes.items():
                     allg = [(sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg)), length, g)
                             for length, _, groups in lst for g in groups]
                     allg.sort(key=lambda t: (-t[0], -t[1]))                 # heavy groups first (dispatch order)
                     maxlen = max(t[1] for t in allg)
-                    default = max(lst, key=lambda t: t[0])[1] & 15          # the longest clip's tile shape
+                    default = max(lst, key=lambda t: t[0])[1] & (15 | WINO_F54)          # the longest clip's tile shape
                     wcfg = default
-                    if default in (0, 1, 4, 5):
+                    if default in (0, 1, 4, 5) or fam:
                         # the launch model takes one length: the mean one keeps the block count honest
                         mean_len = max(1, sum(t[1] for t in allg) // len(allg))
                         wcfg, _ = choose_wino_cfg([t[0] for t in allg], 1, wpad, mean_len, dil, default=default, bf=self.bf)
@@ -1125,7 +1199,7 @@ class Vocoder:
                     bm, bt = _WINO_TILES[wcfg]
                     cot = wpad // bm
                     n_tiles = -(-(-(-maxlen // dil)) // bt) * dil
-                    run_len = hip.lib().fh_wino_run_len(n_tiles)
+                    run_len = (hip.lib().fh_wino54_run_len if fam else hip.lib().fh_wino_run_len)(n_tiles)
                     rpp = -(-n_tiles // run_len)
                     runs = []
                     for gi, (_, length, _) in enumerate(allg):
@@ -1204,9 +1278,12 @@ class Vocoder:
         for s in rp["steps"]:
             if s[0] == "rwino":
                 _, off, ng, wpad, maxlen, dil, wcfg, pmflag, off_map, n_runs = s
-                hip.check(L.fh_conv_wino_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, wcfg | self.wino_flag, base + off_map,
-                                                    n_runs, st),
-                          "fh_conv_wino_ragged_f32")
+                if wcfg & WINO_F54:
+                    hip.check(L.fh_conv_wino54_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, wcfg & 15, base + off_map,
+                                                          n_runs, st), "fh_conv_wino54_ragged_f32")
+                else:
+                    hip.check(L.fh_conv_wino_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, wcfg | self.wino_flag,
+                                                        base + off_map, n_runs, st), "fh_conv_wino_ragged_f32")
             elif s[0] == "rconv":
                 _, off, ng, cpad, maxlen, tcfg, ck = s
                 hip.check(L.fh_conv_grouped_f32(base + off, ng, 1, cpad, maxlen, tcfg, ck, st), "fh_conv_grouped_f32")
@@ -1250,10 +1327,11 @@ class Vocoder:
         # 3 more (decimated) samples per side and conv.  Such rounding-level influence is almost always absorbed by the
         # next layer's own rounding -- chunks with the taps-only halo matched bit for bit in every fp32 test -- but
         # "almost" is not the contract (and the bf16 x 6 form, with more rounding steps, did show it): the halo covers it.
-        wino_reach = 3 * sum((d + 1) if self.resblock == "1" else d for d in dmax)
+        # (F(4,3): 6 inputs per 4 outputs, 3 beyond the taps; F(5,4): 8 per 5, 4 beyond)
+        reach1 = sum((d + 1) if self.resblock == "1" else d for d in dmax)
         h = 3.0 + 6.0                                   # conv_post (7 taps) + activation_post, in output samples
         for i in reversed(range(len(self.rates))):
-            h += per_stage + wino_reach                  # residual stack at this stage's rate
+            h += per_stage + (4 if self.stages[i]["w54"] else 3) * reach1      # residual stack at this stage's rate
             h = h / self.rates[i] + self.up_k[i] / self.rates[i] + 1.0 + 3.0     # ... seen from the transposed conv's input
         h += 3.0 + 3.0                                  # conv_pre
         align, rate = 4, 1
@@ -1262,10 +1340,11 @@ class Vocoder:
         for dils in self.dil:
             for d in dils:
                 dl = lcm(dl, d)
-        for u in self.rates:
+        for i, u in enumerate(self.rates):
             align = lcm(align, 4 // math.gcd(4, rate))                      # Winograd transposed conv reads at `rate`
             rate *= u
-            align = lcm(align, 4 * dl // math.gcd(4 * dl, rate))            # residual stack at `rate` samples per frame
+            m = 5 if self.stages[i]["w54"] else 4                           # outputs per tile of the stage's Winograd kernel
+            align = lcm(align, m * dl // math.gcd(m * dl, rate))            # residual stack at `rate` samples per frame
         halo = -(-int(math.ceil(h)) // align) * align
         return halo, align
 
@@ -1333,7 +1412,10 @@ class Vocoder:
             if timing is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, wcfg | self.wino_flag, st), "fh_conv_wino_f32")
+            if wcfg & WINO_F54:
+                hip.check(L.fh_conv_wino54_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, wcfg & 15, st), "fh_conv_wino54_f32")
+            else:
+                hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, wcfg | self.wino_flag, st), "fh_conv_wino_f32")
             if timing is not None:
                 e1.record()
                 timing.append((e0, e1))

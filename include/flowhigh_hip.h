@@ -178,6 +178,25 @@ int fh_wino_run_len(int n_tiles);
 int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
                             int layout_flags, int tile_cfg, const int* run_map, int n_runs, void* stream);
 
+/* The same Conv1d call sites in the minimal-filtering form F(5,4) (8 points 0, +-1, +-2, +-1/2, inf; taps walked in
+ * groups of 4: 1.6 ceil(k/4) multiply-adds per output and channel pair, 20 % fewer than F(4,3) over k = 3 / 7 / 11), for
+ * the wide stages.  Same descriptors with ngrp = ceil(k / 4) and
+ *   u = [cin/16][ngrp][8][cout_pad][16], u[., g, xi, co, .] = sum_j G8[xi][j] * w[co, ., 4g + j]
+ * (flowhigh_amd/vocoder.py: pack_wino54_weight); out_stride <= 1, xlen = 0, out_len = 0 (transposed-conv phases stay
+ * with fh_conv_wino_f32).  tile_cfg: 0 = 128 co x 320 outputs per block,
+ * 1 = 96 x 320, 2 = 64 x 320 (cout_pad % fh_wino54_tile_m(tile_cfg) == 0).  Results differ from the F(4,3) form by
+ * rounding only (tests/tools/winograd_numerics.py). */
+int fh_wino54_tile_m(int tile_cfg);
+int fh_wino54_tile_n(void);
+int fh_conv_wino54_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
+                       int dilation, int phase_major, int tile_cfg, void* stream);
+/* Ragged form, as fh_conv_wino_ragged_f32: runs of fh_wino54_run_len(n_tiles) consecutive 320-output tiles,
+ * n_tiles = ceil(ceil(max_len / dilation) / fh_wino54_tile_n()) * dilation; layout_flags bit 0 = phase-major, bit 1 = some
+ * group's rows are not 16-byte aligned. */
+int fh_wino54_run_len(int n_tiles);
+int fh_conv_wino54_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
+                              int layout_flags, int tile_cfg, const int* run_map, int n_runs, void* stream);
+
 /* out = ((a + b) + c) * scale over n floats (c may be NULL; n % 4 == 0, 16-byte aligned pointers): the
  * `xs += resblock(x); x = xs / num_kernels` of BigVGAN.forward (models/bigvgan/models.py:183-188) for the
  * stages whose closing conv is not fused (too few blocks to fill the chip at batch 1). */

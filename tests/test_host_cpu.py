@@ -120,6 +120,7 @@ def test_plan_ragged_merges_launch_by_launch():
     hold real tiles, and two clips of equal length get plans (buffers) of their own."""
     import ctypes as C
     from flowhigh_amd import hip
+    from flowhigh_amd import vocoder as V
     voc = _cpu_vocoder("SYNTH_CFG")
     frames = [50, 333, 50, 120]
     rp = voc.plan_ragged(frames)
@@ -147,9 +148,12 @@ def test_plan_ragged_merges_launch_by_launch():
             gs = (hip.WinoGroup * ng).from_buffer_copy(raw[off:off + ng * C.sizeof(hip.WinoGroup)])
             assert max(g.len for g in gs) == maxlen
             runs = (C.c_int32 * n_runs).from_buffer_copy(raw[off_map:off_map + 4 * n_runs])
-            bm, bt = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256)}[wcfg]
+            f54 = wcfg & V.WINO_F54                             # (the F(5,4) kernel: 128 / 96 / 64 co x 320 outputs)
+            bm, bt = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256),
+                      V.WINO_F54: (128, 320), V.WINO_F54 | 1: (96, 320), V.WINO_F54 | 2: (64, 320)}[wcfg]
+            assert hip.lib().fh_wino54_tile_n() == 320 and hip.lib().fh_wino54_tile_m(wcfg & 15) == bm if f54 else True
             n_tiles = -(-(-(-maxlen // dil)) // bt) * dil
-            run_len = hip.lib().fh_wino_run_len(n_tiles)
+            run_len = (hip.lib().fh_wino54_run_len if f54 else hip.lib().fh_wino_run_len)(n_tiles)
             rpp = -(-n_tiles // run_len)
             assert len(set(runs)) == n_runs and all(0 <= r < ng * (wpad // bm) * rpp for r in runs)
             for r in runs:                                   # the run's first tile starts inside its group's row

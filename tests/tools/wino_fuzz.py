@@ -1,6 +1,7 @@
 """Randomised check of fh_conv_wino_f32 (all tiles, layouts, dilations, residuals, ragged lengths) against
-float64 F.conv1d.  python tests/tools/wino_fuzz.py [n_cases] [seed] [bf]
-bf: the three-piece bf16 form (tile_cfg | FH_WINO_BF16X6, weights split by vocoder.split_bf3), same tolerance."""
+float64 F.conv1d.  python tests/tools/wino_fuzz.py [n_cases] [seed] [bf | f54]
+bf: the three-piece bf16 form (tile_cfg | FH_WINO_BF16X6, weights split by vocoder.split_bf3), same tolerance.
+f54: fh_conv_wino54_f32 (the F(5,4) kernel: groups of 4 taps, 128 / 96 / 64-row tiles), same tolerance."""
 import sys, random, torch, torch.nn.functional as F
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, vocoder as V
@@ -8,9 +9,10 @@ DEV = torch.device('cuda:0')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 BF = len(sys.argv) > 3 and sys.argv[3] == "bf"
+F54 = len(sys.argv) > 3 and sys.argv[3] == "f54"
 worst = 0.0
 for case in range(n_cases):
-    c = rng.choice([16, 32, 48, 64, 96, 128, 192])
+    c = rng.choice([16, 32, 48, 64, 96, 128, 192] + ([256, 384] if F54 else []))
     k = rng.choice([1, 3, 5, 7, 9, 11])
     d = rng.choice([1, 1, 2, 3, 5])
     B = rng.choice([1, 2, 3])
@@ -27,23 +29,28 @@ for case in range(n_cases):
     scale = rng.choice([1.0, 0.5, 1.0 / 3])
     ref = sum(F.conv1d(x.double(), w.double(), None, dilation=d, padding=(kk - 1) // 2 * d) for x, w, kk in zip(xs, ws, ks))
     ref = ((ref + bias.double().view(1, -1, 1) + sum(r.double() for r in res)) * scale).float()
-    wcfg, cpad = V.pick_wino_tile(c)
+    wcfg, cpad = V.pick_wino54_tile(c) if F54 else V.pick_wino_tile(c)
+    if F54 and rng.random() < 0.3:                                  # (any tile height that divides cout_pad)
+        wcfg = rng.choice([t for t in (V.WINO_F54, V.WINO_F54 | 1, V.WINO_F54 | 2) if cpad % V._WINO_TILES[t][0] == 0])
     if wcfg == 0 and rng.random() < 0.3:
         wcfg = rng.choice([4, 5, 6] if cpad % 128 == 0 else [4, 5])
+    pack = V.pack_wino54_weight if F54 else V.pack_wino_weight
+    taps = 4 if F54 else 3
     conv = lambda t: (V.to_phase_major(t, d) if pm else t).to(DEV)
     xd = [conv(x) for x in xs]
     rd = [conv(r) for r in res]
     out = torch.full_like(xd[0], float("nan"))
-    ud = [(V.split_bf3(V.pack_wino_weight(w, cpad)) if BF else V.pack_wino_weight(w, cpad)).to(DEV) for w in ws]
+    ud = [(V.split_bf3(pack(w, cpad)) if BF else pack(w, cpad)).to(DEV) for w in ws]
     bd = bias.to(DEV)                      # (descriptors hold raw pointers: every tensor must stay referenced)
-    grp = V.make_wino_group([V.make_wino_seg(xd[i], ud[i], c, kk) for i, kk in enumerate(ks)], bd, rd, out,
+    grp = V.make_wino_group([V.make_wino_seg(xd[i], ud[i], c, kk, taps=taps) for i, kk in enumerate(ks)], bd, rd, out,
                             c, cpad, L, scale=scale)
     keep = V.conv_wino([grp], B, cpad, L, d, DEV, wcfg | (V.WINO_BF16X6 if BF else 0), phase_major=pm)
     torch.cuda.synchronize()
     got = V.from_phase_major(out.cpu(), d, L) if pm else out.cpu()
     err = (got - ref).abs().max().item()
     worst = max(worst, err)
-    ok = err <= 3e-5 * nseg and bool(torch.isfinite(got).all())
+    # (outputs are ~N(0, 1) per segment; rounding grows with the depth c k of the sums: the wider layers of the F(5,4) runs get 1.5 x)
+    ok = err <= 3e-5 * nseg * (1.0 if c <= 192 else 1.5) and bool(torch.isfinite(got).all())
     if not ok:
         print(f"FAIL case {case}: c={c} ks={ks} d={d} B={B} L={L} pm={pm} nres={nres} cfg={wcfg} err={err}")
-print(f"{n_cases} cases{' (bf16 x 6)' if BF else ''}, worst error {worst:.2e}")
+print(f"{n_cases} cases{' (bf16 x 6)' if BF else ' (F(5,4))' if F54 else ''}, worst error {worst:.2e}")

@@ -34,14 +34,14 @@ print(f"{'#':>3} {'tile':>8} {'grp':>3} {'cpad':>5} {'n_len':>7} {'blocks':>6} {
 for i, s in enumerate(convs):
     if s[0] == 'wino':
         _, d, ng, cpad, n_len, dil, fl, wcfg, _pm = s[:9]
-        xr, wcfg = wcfg & 32, wcfg & 15
-        bm, bn = (128, 256) if wcfg == 6 else (32, 256) if wcfg == 5 else (64, 256) if wcfg == 4 else (96, 256) if wcfg & 1 else (64, 512)
+        xr, f54, wcfg = wcfg & 32, wcfg & V.WINO_F54, wcfg & 15
+        bm, bn = V._WINO_TILES[wcfg | f54]
         blocks = ng * s[9] * (cpad // bm) * -(-(-(-n_len // dil)) // bn) * dil
     else:
-        xr = 0
+        xr = f54 = 0
         _, d, ng, cpad, n_len, tcfg, ck, fl = s
         bm, bn = TILES[tcfg]
         blocks = ng * B * (cpad // bm) * -(-n_len // bn)
     tot_f += fl; tot_t += acc[i]
-    print(f"{i:3d} {(('R' if xr else 'W') if s[0] == 'wino' else ' ')}{bm:>3}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
+    print(f"{i:3d} {(('R' if xr else 'V' if f54 else 'W') if s[0] == 'wino' else ' ')}{bm:>3}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
 print(f"total {tot_f/1e9:.1f} GFLOP {tot_t/1e3:.3f} ms {tot_f/tot_t/1e6:.1f} TF/s")
