@@ -133,9 +133,9 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   }
   // LDS float offsets of the 6 samples of tap group g relative to the lane's base: sample c = 4 g + off -> plane c % 5,
   // index tile + c / 5
-  int toff[4][6];
+  int toff[3][6];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 3; ++g)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int c = 4 * g + boff[j];
@@ -320,7 +320,9 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
       if (sg < nseg) S0 = load_vseg(&G->seg[sg]);
     }
   };
-  run_all(std::integral_constant<int, 4>{});
+  // (1 .. 3 groups of 4 taps: k <= 12, the host's WINO_MAX_K.  Tried: the three row classes of B^T -- point 0, the six
+  // +- points, inf -- as compile-time sample positions behind one wave-uniform branch per segment, to drop the address
+  // table: the 128 accumulator registers then go through the branch's merge and the compiler spills ~1 900 of them)
   run_all(std::integral_constant<int, 3>{});
   run_all(std::integral_constant<int, 2>{});
   run_all(std::integral_constant<int, 1>{});

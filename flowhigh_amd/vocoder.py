@@ -153,7 +153,8 @@ WINO_F54 = 256            # flag in a plan's tile id: the launch runs fh_conv_wi
 _WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256),
                WINO_F54 | 0: (128, 320), WINO_F54 | 1: (96, 320), WINO_F54 | 2: (64, 320)}
 _WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0), 6: (2.75, 20.0),
-              WINO_F54 | 0: (4.0, 15.0), WINO_F54 | 1: (3.05, 14.0), WINO_F54 | 2: (2.1, 13.0)}
+              # (tools/wino54_cost_fit.py: 4.48 / 3.64 / 2.62 us per step = 0.77 / 0.71 / 0.66 of the matrix-pipe time)
+              WINO_F54 | 0: (4.48, 18.0), WINO_F54 | 1: (3.64, 16.0), WINO_F54 | 2: (2.62, 15.0)}
 # 128-row tiles halve the LDS reads and transform instructions per MFMA (one B fragment feeds 4 MFMAs) but
 # double the weight bytes a block streams: beyond this panel size (6 x 128 rows x K, bytes) a chip full of
 # such blocks thrashes the 4 MB L2s (C = 768: 857 us against 732 us with 64 x 512 tiles)
@@ -189,6 +190,8 @@ def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=F
     load = 1.12 if real > 200 else 1.0 + 0.12 * real / 200        # blocks run ~12 % slower on a full chip
     if cfg == 6 and real > 8 * cus_per_xcd and max(ksteps) * 16 * 6 * bm * 4 > _WINO_WIDE_PANEL_MAX:
         load *= 1.4
+    if cfg == WINO_F54 and real > 8 * cus_per_xcd and max(ksteps) * 16 * 8 * bm * 4 > _WINO_WIDE_PANEL_MAX:
+        load *= 1.15          # (C = 768, dilation 3: 635 us with 128-row blocks against 507 x 18 / 16 = 570 us at 96-row efficiency)
     if real > 16384:                                                  # many blocks per CU: throughput bound
         return load * sum(panel_w) * n_tiles / (8 * cus_per_xcd)
     total_runs = len(panel_w) * rpp
@@ -254,7 +257,7 @@ WINO54_MIN_C = 96
 
 
 def use_wino54(c):
-    return os.environ.get("FH_WINO54", "1") != "0" and use_wino(c, 1) and c >= WINO54_MIN_C
+    return os.environ.get("FH_WINO54", "1") != "0" and use_wino(c, 1) and c >= int(os.environ.get("FH_WINO54_MIN_C", WINO54_MIN_C))
 
 
 def pack_wino_weight(w, cout_pad):
