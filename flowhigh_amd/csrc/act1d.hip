@@ -456,7 +456,9 @@ unsigned act_pad_lds_bytes() {          // static LDS of the variants: 12.7-17.2
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) return 0u;
   switch (g_act_blocks_per_cu[dev].load(std::memory_order_relaxed)) {
-    case 5: return 15u * 1024u;
+    // (n = 5: 26.67 KB < static + pad <= 32 KB for EVERY variant: 12.7 + 14.5 = 27.2, 17.2 + 14.5 = 31.7; 15 KB put the largest
+    // variant at 32.2 KB = 4 blocks)
+    case 5: return 14u * 1024u + 512u;
     case 4: return 22u * 1024u;
     case 3: return 36u * 1024u;
     case 2: return 44u * 1024u;

@@ -420,8 +420,8 @@ class FlowHighSR:
                   "fh_mel_splice_seg_f32")
         return out
 
-    def _sample_ragged(self, conds, noises, time_steps, cfm_method, std_2=None, mels=None, cond_scale=1., mel_pp=False,
-                       decode_to_audio=True):
+    def _sample_ragged(self, conds, noises, time_steps, cfm_method, std_1=None, std_2=None, mels=None, cond_scale=1.,
+                       mel_pp=False, decode_to_audio=True):
         """`sample()` (cfm:162-284, incl. cond_scale != 1 and mel_pp, cfm:162-175,278-279) for clips of DIFFERENT
         lengths as one launch sequence.
         conds: list of [T48_i] device tensors (peak-normalised), noises: list of [1, N_i, n_mels] host tensors.
@@ -430,9 +430,9 @@ class FlowHighSR:
         row-wise operator runs on the packed rows, the operators that look across rows take the clip boundaries (the
         mel cutoff bins are per clip: fh_mel_*_seg_f32), the vocoder runs its merged plan."""
         fh = self.flowhigh
-        std_1 = None
         if cfm_method in _CFM_METHODS[1:]:
-            std_1, std_2 = 1.0, self.sigma                   # cfm:180-183: generate() never passes std_1, so BOTH reset
+            if std_1 is None or std_2 is None:               # cfm:180-183 (resets BOTH; generate() never passes std_1)
+                std_1, std_2 = 1.0, self.sigma
         if mels is None:
             mels = [fh.logmel(c[None]) for c in conds]       # [N_i, n_mels] each
         frames = [m.shape[0] for m in mels]
@@ -464,11 +464,12 @@ class FlowHighSR:
 
     @torch.no_grad()
     @hip.on_device
-    def sample_many(self, conds, *, time_steps=4, cond_scale=1., decode_to_audio=True, mel_pp=False, cfm_method=None,
-                    noise=None, generator=None):
+    def sample_many(self, conds, *, time_steps=4, cond_scale=1., decode_to_audio=True, std_1=None, std_2=None, mel_pp=False,
+                    cfm_method=None, noise=None, generator=None):
         """`sample()` for a LIST of conditioning clips of different lengths (each [T48_i], 48 kHz, peak-normalised) as
         one masked / ragged launch sequence, with the reference's sampler options (cond_scale: classifier-free
-        guidance against null_cond, mel_pp: low-band replacement with per-clip cutoff bins; cfm:162-175,278-279).
+        guidance against null_cond, mel_pp: low-band replacement with per-clip cutoff bins, std_1 / std_2: prior scales of the
+        independent_cfm_* paths, both reset unless both are given; cfm:162-183,278-279).
         Every result is bit-identical to `sample(cond=clip[None], ...)` on that clip alone.  Returns a list of
         [1, 1, 480 N_i] waveforms (or [1, N_i, n_mels] mels)."""
         if cfm_method not in _CFM_METHODS:
@@ -477,9 +478,8 @@ class FlowHighSR:
         frames = [c.shape[0] // 480 for c in conds]
         if noise is None:
             noise = [self._draw_noise(1, n, generator) for n in frames]
-        kw = dict(std_2=1.) if cfm_method == 'independent_cfm_adaptive' else {}
-        outs = self._sample_ragged(conds, noise, time_steps, cfm_method, cond_scale=cond_scale, mel_pp=mel_pp,
-                                   decode_to_audio=decode_to_audio, **kw)
+        outs = self._sample_ragged(conds, noise, time_steps, cfm_method, std_1=std_1, std_2=std_2, cond_scale=cond_scale,
+                                   mel_pp=mel_pp, decode_to_audio=decode_to_audio)
         return [o.clone().unsqueeze(1) if decode_to_audio else o.clone()[None] for o in outs]
 
     @torch.no_grad()
@@ -532,8 +532,13 @@ class FlowHighSR:
         if ragged and len(set(lengths)) > 1 and target_sampling_rate == 48000:
             try:
                 return self._generate_many_ragged(clips, lengths, sr, timestep, noise, max_frames)
-            except NotImplementedError:
-                pass        # a vocoder configuration whose launch positions cannot be merged: one batch per length
+            except NotImplementedError as e:
+                # a vocoder configuration whose launch positions cannot be merged: one batch per length (said once)
+                if not getattr(self, "_ragged_fallback_logged", False):
+                    self._ragged_fallback_logged = True
+                    import logging
+                    logging.getLogger("flowhigh_amd").warning("generate_many: ragged launch sequence not available (%s); "
+                                                              "running one batch per clip length", e)
         buckets = {}
         for i, a in enumerate(clips):
             key = (int(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a).shape[-1]), tuple(noise[i].shape))

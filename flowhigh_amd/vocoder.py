@@ -497,9 +497,44 @@ _act_blocks = {}                        # device ordinal -> setting in force
 
 
 def pick_act_blocks(pair_us, slack=0.98):
-    """The decision rule: no cap unless a capped setting makes the (activation + conv) pair at least 2 % faster."""
-    best = min(pair_us, key=pair_us.get)
-    return best if best != 0 and pair_us[best] < slack * pair_us[0] else 0
+    """The decision rule: no cap unless a capped setting makes the (activation + conv) pair at least 2 % faster -- in EVERY
+    measurement pass (pair_us: one {blocks: us} dict, or a list of them, one per pass): a single noisy pass on a shared
+    or busy GPU must not flip the setting."""
+    passes = [pair_us] if isinstance(pair_us, dict) else list(pair_us)
+    wins = [b for b in passes[0] if b != 0 and all(p[b] < slack * p[0] for p in passes)]
+    if not wins:
+        return 0
+    return min(wins, key=lambda b: sorted(p[b] for p in passes)[len(passes) // 2])
+
+
+def parse_act_blocks(value):
+    """FH_ACT_BLOCKS / Vocoder(act_blocks=): None, '' or 'auto' -> None (measure); 0 or 2..5 -> that setting."""
+    if value is None or str(value).strip().lower() in ("", "auto"):
+        return None
+    try:
+        v = int(str(value).strip())
+    except ValueError:
+        v = -1
+    if v != 0 and not 2 <= v <= 5:
+        raise ValueError(f"FH_ACT_BLOCKS / act_blocks must be 'auto', 0 (no cap) or 2..5 blocks per CU, got {value!r}")
+    return v
+
+
+def decide_act_blocks(measure, group=None):
+    """The node-wide choice: with an initialised torch.distributed process group of more than one rank, rank 0 alone runs
+    `measure()` (-> list of per-pass {blocks: us}) and broadcasts its choice -- eight ranks timing launch pairs while
+    their neighbours load models under one power budget would each measure something else.  Returns (choice, passes)."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        passes = measure()
+        return pick_act_blocks(passes), passes
+    box = [None]
+    if dist.get_rank(group) == 0:
+        passes = measure()
+        box[0] = (pick_act_blocks(passes), passes)
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return box[0]
 
 
 def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100):
@@ -513,10 +548,13 @@ def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100
         ys = [torch.empty(1, c, length, device=dev) for _ in ks]
         outs = [torch.empty(1, c, length, device=dev) for _ in ks]
         bias = torch.zeros(c, device=dev)
-        wcfg, wpad = pick_wino_tile(c)
-        us = [pack_wino_weight(torch.randn(c, c, k, generator=g) * 0.02, wpad).to(dev) for k in ks]
-        gw = hip.to_device_struct_array([make_wino_group([make_wino_seg(ys[i], us[i], c, k)], bias, [], outs[i], c, wpad, length)
-                                         for i, k in enumerate(ks)], dev)
+        # (the conv launch of the model at this width: the F(5,4) kernel unless it is switched off)
+        f54 = use_wino54(c)
+        wcfg, wpad = pick_wino54_tile(c) if f54 else pick_wino_tile(c)
+        pack = pack_wino54_weight if f54 else pack_wino_weight
+        us = [pack(torch.randn(c, c, k, generator=g) * 0.02, wpad).to(dev) for k in ks]
+        gw = hip.to_device_struct_array([make_wino_group([make_wino_seg(ys[i], us[i], c, k, taps=4 if f54 else 3)], bias, [],
+                                                         outs[i], c, wpad, length) for i, k in enumerate(ks)], dev)
         filt = [0.0] * 5 + [0.5, 0.5] + [0.0] * 5
         p = dict(alpha=torch.ones(c, device=dev), inv_beta=torch.ones(c, device=dev), up=filt, down=filt)
         ga = hip.to_device_struct_array([make_act_group(xs[i], ys[i], p) for i in range(len(ks))], dev)
@@ -526,7 +564,10 @@ def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100
         try:
             def pair():
                 hip.check(lib.fh_act1d_grouped_pm_f32(ga.data_ptr(), len(ks), 1, c, length, 1, 1, st), "fh_act1d_grouped_pm_f32")
-                hip.check(lib.fh_conv_wino_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg, st), "fh_conv_wino_f32")
+                if f54:
+                    hip.check(lib.fh_conv_wino54_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg & 15, st), "fh_conv_wino54_f32")
+                else:
+                    hip.check(lib.fh_conv_wino_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg, st), "fh_conv_wino_f32")
             for _ in range(warm):
                 pair()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -540,26 +581,31 @@ def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100
         return e0.elapsed_time(e1) * 1e3 / reps
 
 
-def calibrate_act_occupancy(device, force=False):
-    """Choose and set the activation launches' blocks per CU on `device` (once per device and process; FH_ACT_BLOCKS =
-    auto | 0 | 2..5 overrides the measurement).  Returns the setting.  Results do not depend on it, only launch times."""
+def calibrate_act_occupancy(device, force=False, act_blocks=None):
+    """Choose and set the activation launches' blocks per CU on `device` (once per device and process).
+    act_blocks (Vocoder(act_blocks=)) or FH_ACT_BLOCKS = auto | 0 | 2..5 override the measurement -- a deployment that
+    knows its boxes, or a launcher that wants every rank alike, passes the number.  With torch.distributed initialised
+    rank 0 measures and every rank takes its choice (decide_act_blocks).  The measured pair times are logged
+    (logger 'flowhigh_amd').  Returns the setting.  Results do not depend on it, only launch times."""
     dev = hip.norm_device(device)
     if dev.type != "cuda" or not torch.cuda.is_available():
         return 0
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx in _act_blocks and not force:
+    fixed = parse_act_blocks(act_blocks)
+    if fixed is None:
+        fixed = parse_act_blocks(os.environ.get("FH_ACT_BLOCKS"))
+    if idx in _act_blocks and not force and (fixed is None or fixed == _act_blocks[idx]):
         return _act_blocks[idx]
-    env = os.environ.get("FH_ACT_BLOCKS", "auto")
-    if env != "auto":
-        choice = int(env)
+    if fixed is not None:
+        choice = fixed
     else:
-        pair_us = {}
-        for round_ in range(2):                      # two alternating passes: the chip's state drifts over the first 100 ms
-            for b in ACT_BLOCKS_CHOICES:
-                t = measure_act_conv_pair(dev, b)
-                pair_us[b] = min(pair_us.get(b, t), t)
-        choice = pick_act_blocks(pair_us)
-        calibrate_act_occupancy.last_measurement = dict(pair_us)
+        def measure():                               # two alternating passes: the chip's state drifts over the first 100 ms
+            return [{b: measure_act_conv_pair(dev, b) for b in ACT_BLOCKS_CHOICES} for _ in range(2)]
+        choice, passes = decide_act_blocks(measure)
+        calibrate_act_occupancy.last_measurement = passes
+        import logging
+        logging.getLogger("flowhigh_amd").info("activation occupancy on cuda:%d: %s blocks per CU; (activation, conv) pair us per pass: %s",
+                                               idx, choice or "uncapped (7)", passes)
     with hip.device_guard(dev):
         hip.check(hip.lib().fh_act_set_blocks_per_cu(choice), "fh_act_set_blocks_per_cu")
     _act_blocks[idx] = choice
@@ -903,7 +949,7 @@ class _PlanBuilder:
 class Vocoder:
     """Device-resident BigVGAN weights + per-shape launch plans."""
 
-    def __init__(self, cfg, sd, device, prefix=VOC, bf16x6=None):
+    def __init__(self, cfg, sd, device, prefix=VOC, bf16x6=None, act_blocks=None):
         if isinstance(cfg, (str, bytes)) or hasattr(cfg, "read_text"):
             cfg = json.loads(open(cfg).read())
         self.cfg = dict(cfg)
@@ -1083,7 +1129,8 @@ class Vocoder:
         self.conv_timing = None
         self.act_timing = None
         # blocks per CU of the activation launches on this device (measured once per device and process: see above)
-        self.act_blocks = calibrate_act_occupancy(self.device)
+        # (act_blocks: 'auto' / None = measure unless FH_ACT_BLOCKS says otherwise; 0 or 2..5 = take that, no measurement)
+        self.act_blocks = calibrate_act_occupancy(self.device, act_blocks=act_blocks)
 
     def stage_lengths(self, n_frames):
         """Samples per row after every upsampling stage: L_i = u_i L_(i-1) + (k_i - u_i) % 2 (models.py:141-146,179)."""

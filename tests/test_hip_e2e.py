@@ -604,6 +604,14 @@ def test_sample_many_with_guidance_and_mel_pp_equals_single_calls_bitwise(cfm_me
             one = m.sample(cond=c[None], time_steps=2, cond_scale=1.3, mel_pp=True, cfm_method=cfm_method, noise=z,
                            decode_to_audio=decode)
             assert got.shape == one.shape and torch.equal(got, one)
+    if cfm_method != "basic_cfm":
+        # caller-supplied prior scales (cfm:171-183: honoured only when BOTH are given) reach the ragged path as they reach sample()
+        many = m.sample_many(conds, time_steps=1, cfm_method=cfm_method, noise=noise, decode_to_audio=False, std_1=0.9, std_2=0.2)
+        half = m.sample_many(conds, time_steps=1, cfm_method=cfm_method, noise=noise, decode_to_audio=False, std_2=0.2)
+        dflt = m.sample_many(conds, time_steps=1, cfm_method=cfm_method, noise=noise, decode_to_audio=False)
+        for c, z, got, h, d in zip(conds, noise, many, half, dflt):
+            one = m.sample(cond=c[None], time_steps=1, cfm_method=cfm_method, noise=z, decode_to_audio=False, std_1=0.9, std_2=0.2)
+            assert torch.equal(got, one) and torch.equal(h, d) and not torch.equal(got, d)
 
 
 # ------------------------------------------------------------------------------------------

@@ -258,7 +258,17 @@ def test_act_occupancy_rule_keeps_the_default_unless_a_cap_pays():
     assert V.pick_act_blocks({0: 615.0, 4: 590.0, 3: 562.0}) == 3
     assert V.pick_act_blocks({0: 540.0, 4: 548.0}) == 0                  # a box without it
     assert V.pick_act_blocks({0: 600.0, 4: 592.0}) == 0                  # within 2 %: keep the default
+    # the cap must pay in EVERY pass; among those that do, the lowest median wins
+    assert V.pick_act_blocks([{0: 615.0, 3: 560.0}, {0: 600.0, 3: 597.0}]) == 0
+    assert V.pick_act_blocks([{0: 615.0, 3: 560.0, 4: 570.0}, {0: 610.0, 3: 575.0, 4: 560.0}]) in (3, 4)
+    assert V.pick_act_blocks([{0: 615.0, 3: 560.0, 4: 600.0}, {0: 610.0, 3: 575.0, 4: 605.0}]) == 3
     assert V.calibrate_act_occupancy(torch.device("cpu")) == 0            # nothing to set without a GPU
+    # FH_ACT_BLOCKS / act_blocks=: validated, empty = auto (an empty export must not kill every construction)
+    assert V.parse_act_blocks(None) is None and V.parse_act_blocks("") is None and V.parse_act_blocks(" auto ") is None
+    assert V.parse_act_blocks("0") == 0 and V.parse_act_blocks(3) == 3 and V.parse_act_blocks("5") == 5
+    for bad in ("1", "6", "three", "-2"):
+        with pytest.raises(ValueError, match="FH_ACT_BLOCKS"):
+            V.parse_act_blocks(bad)
 
 
 def test_norm_device_pins_the_ordinal():

@@ -114,3 +114,39 @@ def test_batching_server_groups_and_returns_in_order():
     srv.close()
     with pytest.raises(RuntimeError):
         srv.submit(clips[0], 12000)
+
+
+def _calib_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowhigh_amd import vocoder as V
+        calls = []
+
+        def measure():              # rank 0's box has the clock dip, the others' measurement would say it has not
+            calls.append(rank)
+            return [{0: 615.0, 3: 560.0}, {0: 610.0, 3: 570.0}] if rank == 0 else [{0: 540.0, 3: 560.0}] * 2
+        choice, passes = V.decide_act_blocks(measure)
+        q.put((rank, choice, len(calls), passes[0][3]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_act_occupancy_choice_is_measured_on_rank_0_and_broadcast():
+    """vocoder.decide_act_blocks under torch.distributed: only rank 0 times launch pairs, every rank takes its choice
+    (eight ranks calibrating concurrently under one power budget would each measure something else)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_calib_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, 3, 1, 560.0), (1, 3, 0, 560.0)]
+    # without a process group: measured locally
+    from flowhigh_amd import vocoder as V
+    assert V.decide_act_blocks(lambda: [{0: 540.0, 3: 560.0}] * 2)[0] == 0

@@ -5,7 +5,7 @@ usage: make_traffic_json.py <fetch_dir> <write_dir> <out.json> [conv|act]"""
 import csv, glob, json, sys
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 which = sys.argv[4] if len(sys.argv) > 4 else "conv"
-names = {"conv": ("conv_mfma_kernel", "conv_wino_kernel"), "act": ("act1d_strip_kernel",)}[which]
+names = {"conv": ("conv_mfma_kernel", "conv_wino_kernel", "conv_wino54_kernel"), "act": ("act1d_strip_kernel",)}[which]
 def total(d, name):
     f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
     tot, n = 0.0, 0

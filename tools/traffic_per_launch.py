@@ -7,7 +7,7 @@ from flowhigh_amd import synth
 from flowhigh_amd.vocoder import Vocoder
 
 fetch_dir, write_dir = sys.argv[1], sys.argv[2]
-names = ("conv_mfma_kernel", "conv_wino_kernel")
+names = ("conv_mfma_kernel", "conv_wino_kernel", "conv_wino54_kernel")
 
 
 def series(d, name):
