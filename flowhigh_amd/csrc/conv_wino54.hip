@@ -41,13 +41,14 @@ constexpr int V_OUT = 5 * V_BT;      // outputs per block and row
 constexpr int V_P = 72;              // samples per (plane, channel pair) row: >= V_BT + (4 * 3 + 7) / 5 + 1
 constexpr int V_PAIR = 2 * V_P;      // floats of one channel pair inside a plane
 constexpr int V_PP = 8 * V_PAIR;     // plane pitch, floats
-constexpr int V_SLAB = 5 * V_PP;     // floats per slab buffer (one 16-channel chunk)
+constexpr int V_SLAB = 5 * V_PP;     // floats of a slab (one 16-channel chunk)
+constexpr int V_BUF = V_SLAB + 128;  // ... of a slab buffer: + one trash slot per lane for samples that are not needed
 constexpr int V_XQ = (5 * (V_BT - 1) + 4 * 3 + 7 + 3) / 4 + 1;      // aligned quads a slab can touch (85)
 constexpr int V_EP = 36;             // column pitch (floats) of the exchange tiles: conflict-free b128 (conv_wino.hip)
 constexpr int V_YP = 168;            // row pitch (floats) of the output staging: 16-byte aligned, 4 * 168 % 64 == 32
 constexpr int V_EPI = 2 * 8 * 32 * V_EP;        // exchange tiles of two 32 x 32 sub-tiles (both columns of one mt)
 constexpr int V_Y = 2 * 32 * V_YP;
-constexpr int V_LDS_FLOATS = 2 * V_SLAB > V_EPI + V_Y ? 2 * V_SLAB : V_EPI + V_Y;
+constexpr int V_LDS_FLOATS = 2 * V_BUF > V_EPI + V_Y ? 2 * V_BUF : V_EPI + V_Y;
 constexpr int V_RUN = 8;             // n-blocks of a panel that run together on one XCD (conv_wino.hip: W_RUN)
 
 // Rows of B^T for the points 0, 1, -1, 2, -2, 1/2, -1/2, inf (tests/tools/winograd_numerics.py: toom_cook(5, 4, ...)):
@@ -154,9 +155,18 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   // rows (two 16-byte loads each), then 4 ds_write_b64 (channel pair) per quad into the planes.  Local sample
   // v = 4 q + e lands at position w = v - sh (sh = the 0-3 samples between the quad boundary and the first sample
   // needed), plane w % 5, index w / 5: the readers' offsets do not depend on the block's alignment.
+  // Everything that does not change from chunk to chunk is made once per segment (setup_seg): the loads' byte offsets
+  // inside a chunk's first row (the chunk and the pair's second row are SCALAR offsets of the buffer loads), the LDS
+  // positions, and whether the block touches the row's end at all.  Per chunk a lane then issues 4 loads and 8
+  // unconditional LDS writes (samples that are not needed go to a per-lane trash slot behind the slab): with address
+  // arithmetic and per-sample branches in the chunk loop the staging cost as many vector instructions as the
+  // transform of a one-group chunk.
   constexpr int NXS = VL ? 8 : 6;                      // samples per lane and channel: 2 quads, or lane + 64 i, i < 6
-  int wofs[NXS];                                       // LDS float offsets of this lane's samples, -1 = not stored
+  constexpr int NLD = VL ? 2 : 6;                      // loads per lane and channel
+  int wofs[NXS];                                       // LDS float offsets of this lane's samples inside a slab buffer
+  unsigned voff[NLD];                                  // byte offsets of the loads inside the chunk's first row, or out of range
   int ua = 0;                                          // decimated index of local sample 0 (VL: a multiple of 4)
+  bool tail = false;                                   // (VL) the slab reaches past the row's last real sample
   auto setup_seg = [&](const VSeg& S) {
     const int ub = tb * V_OUT - S.center;
     const int sh = VL ? (ub & 3) : 0;
@@ -165,48 +175,58 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
     for (int i = 0; i < NXS; ++i) {
       const int v = VL ? 4 * (lane + 64 * (i >> 2)) + (i & 3) : lane + 64 * i;
       const int w = v - sh;
-      wofs[i] = (v < 4 * V_XQ && w >= 0) ? (w % 5) * V_PP + xi * V_PAIR + (w / 5) * 2 : -1;
+      wofs[i] = (v < 4 * V_XQ && w >= 0) ? (w % 5) * V_PP + xi * V_PAIR + (w / 5) * 2 : V_SLAB + 2 * lane;
     }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      if constexpr (VL) {
+        const int q = lane + 64 * i, qa = (ua >> 2) + q;
+        const bool ok = q < V_XQ && qa >= 0 && 4 * qa < rowlen;               // (outside the row: zero padding)
+        voff[i] = ok ? (unsigned)(rowbase + 4 * qa) * 4u : 0x80000000u;
+      } else {
+        const int u = ua + lane + 64 * i;                                     // decimated index
+        const int pos = u * dil + ph;                                         // position in the clip
+        const bool ok = lane + 64 * i < 4 * V_XQ && (unsigned)pos < (unsigned)len;
+        voff[i] = ok ? (unsigned)(pm ? rowbase + u : pos) * 4u : 0x80000000u;
+      }
+    }
+    tail = VL && ua + 4 * V_XQ > nvalid;
   };
   unsigned xq[2][NXS];                                 // [channel of the pair][sample]
   auto load_x = [&](const VSeg& S, int chunk, bool valid) {
     const __amdgpu_buffer_rsrc_t r =
         make_rsrc(uni(S.x + (size_t)b * S.cin * pitch), valid ? (unsigned)(S.cin * pitch) * 4u : 0u);
-    const int row0 = (chunk * V_CK + 2 * xi) * pitch;
-    if constexpr (VL) {
+    const int so0 = (chunk * V_CK + 2 * xi) * pitch * 4, so1 = so0 + pitch * 4;        // scalar offsets of the pair's rows
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int q = lane + 64 * i, qa = (ua >> 2) + q;
-        const bool ok = q < V_XQ && qa >= 0 && 4 * qa < rowlen;               // (outside the row: zero padding)
-        const int e0 = row0 + rowbase + 4 * qa;
-        const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)e0 * 4u : 0x80000000u, 0, 0);
-        const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(e0 + pitch) * 4u : 0x80000000u, 0, 0);
+    for (int i = 0; i < NLD; ++i) {
+      if constexpr (VL) {
+        const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(r, voff[i], so0, 0);
+        const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(r, voff[i], so1, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xq[0][4 * i + e] = t0[e];
           xq[1][4 * i + e] = t1[e];
         }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NXS; ++i) {
-        const int u = ua + lane + 64 * i;                                     // decimated index
-        const int pos = u * dil + ph;                                         // position in the clip
-        const bool ok = lane + 64 * i < 4 * V_XQ && (unsigned)pos < (unsigned)len;
-        const int e0 = row0 + (pm ? rowbase + u : pos);
-        xq[0][i] = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)e0 * 4u : 0x80000000u, 0, 0);
-        xq[1][i] = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)(e0 + pitch) * 4u : 0x80000000u, 0, 0);
+      } else {
+        xq[0][i] = __builtin_amdgcn_raw_buffer_load_b32(r, voff[i], so0, 0);
+        xq[1][i] = __builtin_amdgcn_raw_buffer_load_b32(r, voff[i], so1, 0);
       }
     }
   };
   auto store_x = [&](int buf) {
-    float* dst = lds + buf * V_SLAB;
+    float* dst = lds + buf * V_BUF;
+    if (tail) {                                        // (last block of a row: zero past the end; block-uniform branch)
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        const int v = 4 * (lane + 64 * (i >> 2)) + (i & 3);
+        if (ua + v >= nvalid) xq[0][i] = xq[1][i] = 0u;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
-      const int v = VL ? 4 * (lane + 64 * (i >> 2)) + (i & 3) : lane + 64 * i;
-      const bool real = !VL || ua + v < nvalid;                               // (VL, last block of the row: zero past the end)
-      const f32x2 val = {real ? __uint_as_float(xq[0][i]) : 0.f, real ? __uint_as_float(xq[1][i]) : 0.f};
-      if (wofs[i] >= 0) *reinterpret_cast<f32x2*>(dst + wofs[i]) = val;
+      float* q = dst + wofs[i];
+      q[0] = __uint_as_float(xq[0][i]);
+      q[1] = __uint_as_float(xq[1][i]);
     }
   };
 
@@ -250,7 +270,7 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
       const bool has_next = c + 1 < nch;
-      const float* xsb = lds + xbuf * V_SLAB + lane_base;
+      const float* xsb = lds + xbuf * V_BUF + lane_base;
       f32x2 xr[6][2];                                   // [sample slot][column] = (k-step 2 kp, 2 kp + 1)
       auto fetch = [&](int p) {
         const int g = p >> 2, kp = p & 3;
