@@ -5,6 +5,7 @@ import sys
 from pathlib import Path
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out_name = sys.argv[2] if len(sys.argv) > 2 else f"{tag}_pmc_kernels.txt"        # e.g. r04_pmc_kernels_B32.txt for tag r04b32
 root = Path(__file__).resolve().parents[1]
 txt = (root / "gpurun_out" / f"pmc_{tag}.txt").read_text()
 agg = {}
@@ -32,5 +33,5 @@ for n, d in sorted(agg.items()):
                    f"{d['SQ_INSTS_SALU'] / m:.1f} SALU, {d['SQ_INSTS_LDS'] / m:.2f} LDS, "
                    f"{(d['SQ_INSTS_VMEM_RD'] + d['SQ_INSTS_VMEM_WR']) / m:.2f} VMEM; LDS bank conflict cycles "
                    f"{d.get('SQ_LDS_BANK_CONFLICT', 0):.3g}")
-(root / "profiles" / f"{tag}_pmc_kernels.txt").write_text("\n".join(hdr) + "\n" + txt)
+(root / "profiles" / out_name).write_text("\n".join(hdr) + "\n" + txt)
 print("\n".join(hdr[7:]))

@@ -2,7 +2,7 @@
 import csv, json, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 bsuf = sys.argv[2] if len(sys.argv) > 2 else 'B1'        # file-name suffix: B1 (default workload) or e.g. B32 (PROF_ARGS='--batch 32')
-src = f'gpurun_out/prof_{tag}'
+src = f'gpurun_out/prof_{sys.argv[3] if len(sys.argv) > 3 else tag}'         # (third argument: the profile_round.sh tag when it differs, e.g. r04b32)
 shutil.copy(f'{src}/kernel_stats.csv', f'profiles/{tag}_kernel_stats_bench_{bsuf}.csv')
 shutil.copy(f'{src}/bench_line.json', f'profiles/{tag}_bench_line_{bsuf}.json')
 for k in ('conv', 'act'):
