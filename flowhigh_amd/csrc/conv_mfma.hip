@@ -37,15 +37,11 @@ struct ConvCfg {
   static constexpr int BN = 32 * NT * WN;
   static constexpr int WP = CK + 4;                      // LDS pitch of a weight row, floats
   static constexpr int XW = BN + FH_CONV_MAX_HALO;       // staged columns per channel
-  // LDS pitch of a slab row: a B fragment is read by lanes 0-31 from row r and lanes 32-63 from row r + 4, so 4 XP must not
-  // be a multiple of the 64 banks (XW = BN + 64 is: every fragment read was a two-way conflict: 1.8e6 / 4.7e5 conflict cycles
-  // per launch of the 96 x 128 / 32 x 512 shapes, profiles/r03_pmc_kernels.txt); + 8 floats: 4 XP = 32 (mod 64)
-  static constexpr int XP = XW + 8;
   static constexpr int XROWS = CK / 4;                   // rows staged by each wave
   static constexpr int XREG = (XW + 63) / 64;            // dwords per lane per row
   static constexpr int WF4 = BM * CK / 4;                // float4s in a weight tile
   static constexpr int WREG = (WF4 + 255) / 256;
-  static constexpr int LDS_FLOATS = 2 * BM * WP + 2 * CK * XP;
+  static constexpr int LDS_FLOATS = 2 * BM * WP + 2 * CK * XW;
 };
 
 struct SegU {          // wave-uniform copy of the hot fields of one fh_conv_seg
@@ -68,7 +64,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
                                                         int n_groups, int batch, int co_tiles,
                                                         int n_tiles) {
   using Cfg = ConvCfg<MT, NT, WM, WN, CK>;
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, XW = Cfg::XW, XP = Cfg::XP, WP = Cfg::WP;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, XW = Cfg::XW, WP = Cfg::WP;
   constexpr int XROWS = Cfg::XROWS, XREG = Cfg::XREG, WREG = Cfg::WREG, KQ = CK / 8;
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS + FH_CONV_MAX_SEG * FH_CONV_MAX_TAPS];
   float* ws = lds;
@@ -160,7 +156,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   auto store_x = [&](int buf) {
 #pragma unroll
     for (int rr = 0; rr < XROWS; ++rr) {
-      float* dst = xs + buf * CK * XP + (wave * XROWS + rr) * XP;
+      float* dst = xs + buf * CK * XW + (wave * XROWS + rr) * XW;
 #pragma unroll
       for (int i = 0; i < XREG; ++i) {
         const int j = lane + 64 * i;
@@ -210,7 +206,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
     const bool more_chunks = (k0.c + 1) * CK < S0.cin || k0.s + 1 < nseg;
     const bool flip_x = last_tap && more_chunks;
     const float* wsb = ws + wbuf * BM * WP;
-    const float* xsb = xs + xbuf * CK * XP + xoff_cur + wn * NT * 32 + l31 + 4 * lh * XP;
+    const float* xsb = xs + xbuf * CK * XW + xoff_cur + wn * NT * 32 + l31 + 4 * lh * XW;
     f32x4 a[KQ][MT];
 #pragma unroll
     for (int q = 0; q < KQ; ++q)
@@ -226,7 +222,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
       if (ks + 1 < KS) {
         const int q1 = (ks + 1) >> 2, e1 = (ks + 1) & 3;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[(ks + 1) & 1][nt] = xsb[(8 * q1 + e1) * XP + nt * 32];
+        for (int nt = 0; nt < NT; ++nt) bf[(ks + 1) & 1][nt] = xsb[(8 * q1 + e1) * XW + nt * 32];
       }
       if (ks == 1) {                              // global prefetch
         if (it + 2 < nsteps) load_w(LOAD, S2, k2.c, k2.j);

@@ -290,19 +290,18 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
           prefetch_a(S, c + 1, has_next);
         }
         f32x2 bf[2];                                   // [column] = B values of k-steps 2 kp, 2 kp + 1
+        // (inline asm: packed FMAs, and kept out of the MFMA groups below.  The two columns' chains are interleaved so that
+        // no packed FMA reads the result of the one issued just before it; VALU result -> MFMA operand needs 2 wait states:
+        // the s_nop behind the last one covers both columns, conv_wino.hip)
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bf[0]) : "s"(bco[0]), "v"(xr[0][0]), "v"(xr[5][0]));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bf[1]) : "s"(bco[0]), "v"(xr[0][1]), "v"(xr[5][1]));
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          // (inline asm: packed FMAs, and kept out of the MFMA groups below; VALU result -> MFMA operand needs 2 wait
-          // states, the s_nop behind the last one covers both columns: conv_wino.hip)
-          asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bf[nt]) : "s"(bco[0]), "v"(xr[0][nt]), "v"(xr[5][nt]));
-          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(bco[1]), "v"(xr[1][nt]));
-          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(bco[2]), "v"(xr[2][nt]));
-          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(bco[3]), "v"(xr[3][nt]));
-          if (nt == 0)
-            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[nt]) : "s"(bco[4]), "v"(xr[4][nt]));
-          else
-            asm("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(bf[nt]) : "s"(bco[4]), "v"(xr[4][nt]));
+        for (int j = 1; j < 4; ++j) {
+          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[0]) : "s"(bco[j]), "v"(xr[j][0]));
+          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[1]) : "s"(bco[j]), "v"(xr[j][1]));
         }
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[0]) : "s"(bco[4]), "v"(xr[4][0]));
+        asm("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(bf[1]) : "s"(bco[4]), "v"(xr[4][1]));
         if (p + 1 < 4 * GC) fetch(p + 1);
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {

@@ -12,6 +12,9 @@ TILES = {0: (128, 128), 1: (192, 128), 2: (96, 256), 3: (64, 256), 4: (32, 512),
 cfg = synth.SYNTH_CFG
 if len(sys.argv) > 3 and sys.argv[3] == 'bypanel':         # A/B: every Winograd launch with the by-weight-panel block mapping
     V.wino_block_mapping = lambda *a: 0
+import os
+if os.environ.get("TILES_OFF"):                                # A/B: plan tile ids the launch model may not pick (e.g. 257 = F(5,4) 96 x 320)
+    V._WINO_TILES_OFF.update(int(t) for t in os.environ["TILES_OFF"].split(","))
 voc = Vocoder(cfg, synth.make_state_dict(cfg, 0), 'cuda:0')
 p = voc.plan(B, N)
 mel = torch.randn(B, N, cfg["num_mels"], generator=torch.Generator().manual_seed(0)) * 2.0 - 3.0
