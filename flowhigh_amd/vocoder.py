@@ -677,6 +677,9 @@ class _PlanBuilder:
         wcfg, _ = choose_wino_cfg([sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg)) for g in groups],
                                   B, wpad, length, dil, default=wcfg, bf=self.v.bf)
         wcfg |= wino_block_mapping(groups, B, wpad, length, dil, wcfg)
+        if wcfg & WINO_F54 and any(g.out_stride > 1 or g.out_len or g.seg[i].ngrp > 3 or g.seg[i].xlen
+                                   for g in groups for i in range(g.nseg)):
+            raise NotImplementedError("the F(5,4) kernel takes plain convs of at most 12 taps (no strided outputs, xlen, out_len)")
         if novl:
             if wcfg & WINO_F54:
                 raise NotImplementedError("the F(5,4) kernel takes no segments with xlen")

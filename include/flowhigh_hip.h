@@ -182,8 +182,10 @@ int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_
  * groups of 4: 1.6 ceil(k/4) multiply-adds per output and channel pair, 20 % fewer than F(4,3) over k = 3 / 7 / 11), for
  * the wide stages.  Same descriptors with ngrp = ceil(k / 4) and
  *   u = [cin/16][ngrp][8][cout_pad][16], u[., g, xi, co, .] = sum_j G8[xi][j] * w[co, ., 4g + j]
- * (flowhigh_amd/vocoder.py: pack_wino54_weight); out_stride <= 1, xlen = 0, out_len = 0 (transposed-conv phases stay
- * with fh_conv_wino_f32).  tile_cfg: 0 = 128 co x 320 outputs per block,
+ * (flowhigh_amd/vocoder.py: pack_wino54_weight); ngrp <= 3 (k <= 12), out_stride <= 1, xlen = 0, out_len = 0 (longer
+ * kernels run on fh_conv_grouped_f32, transposed-conv phases on fh_conv_wino_f32; the descriptors live in device memory, so
+ * the library cannot check this: flowhigh_amd/vocoder.py does when it builds a launch plan).  Any len and dilation: rows
+ * that are not 16-byte aligned are read and written with 4-byte accesses, same arithmetic.  tile_cfg: 0 = 128 co x 320 outputs per block,
  * 1 = 96 x 320, 2 = 64 x 320 (cout_pad % fh_wino54_tile_m(tile_cfg) == 0).  Results differ from the F(4,3) form by
  * rounding only (tests/tools/winograd_numerics.py). */
 int fh_wino54_tile_m(int tile_cfg);
