@@ -11,7 +11,8 @@
 //
 // Eight transform points = eight waves: block = 8 waves = 2 per SIMD with up to 256 registers each, wave xi owns
 // M_xi for (32 MT) output channels x 64 tiles (2 columns of 32) = 320 outputs.  With MT = 4 one B fragment feeds
-// 8 MFMAs (4 in the 12-wave F(4,3) shapes): per MFMA 0.31 packed vector + 0.375 LDS instructions against 0.75 + 0.5.
+// 8 MFMAs (4 in the 12-wave F(4,3) shapes): per MFMA 0.625 packed vector + 0.375 LDS instructions against 0.75 + 0.5
+// (0.83 + 0.5 in the 96-row shape), for a fifth fewer MFMAs.
 // On this chip every instruction a SIMD issues beside v_mfma_f32_32x32x2_f32 costs matrix-pipe time wherever it is
 // placed (profiles/r04_wino_kloop_handsched.txt), so the instruction count per MFMA is what sets the K loop's rate.
 //   * A (transformed weights [cin/16][tap group][8][cout_pad][16]) goes global -> registers in fragment layout as in
