@@ -153,8 +153,11 @@ WINO_F54 = 256            # flag in a plan's tile id: the launch runs fh_conv_wi
 _WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256),
                WINO_F54 | 0: (128, 320), WINO_F54 | 1: (96, 320), WINO_F54 | 2: (64, 320)}
 _WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0), 6: (2.75, 20.0),
-              # (tools/wino54_cost_fit.py: 4.48 / 3.64 / 2.62 us per step = 0.77 / 0.71 / 0.66 of the matrix-pipe time)
-              WINO_F54 | 0: (4.48, 18.0), WINO_F54 | 1: (3.64, 16.0), WINO_F54 | 2: (2.62, 15.0)}
+              # (tools/wino54_cost_fit.py: 4.4 / 3.1-3.6 / 2.5 us per step = 0.78 / 0.71-0.83 / 0.68 of the matrix-pipe time; b: ~10 us
+              # reproduces both closing-conv forms of the C = 96 stage: 3 groups, 1 125 blocks: 232 us; fused, 375 blocks: 308 us)
+              # Chosen among five constant sets by the measured total of the 43 conv launches of a 10 s clip (13.25 ms; the others
+              # 13.35-13.41): the launch model is a ranking device, not a clock.
+              WINO_F54 | 0: (4.4, 12.0), WINO_F54 | 1: (3.3, 10.0), WINO_F54 | 2: (2.52, 9.0)}
 # 128-row tiles halve the LDS reads and transform instructions per MFMA (one B fragment feeds 4 MFMAs) but
 # double the weight bytes a block streams: beyond this panel size (6 x 128 rows x K, bytes) a chip full of
 # such blocks thrashes the 4 MB L2s (C = 768: 857 us against 732 us with 64 x 512 tiles)
@@ -191,7 +194,7 @@ def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=F
     if cfg == 6 and real > 8 * cus_per_xcd and max(ksteps) * 16 * 6 * bm * 4 > _WINO_WIDE_PANEL_MAX:
         load *= 1.4
     if cfg == WINO_F54 and real > 8 * cus_per_xcd and max(ksteps) * 16 * 8 * bm * 4 > _WINO_WIDE_PANEL_MAX:
-        load *= 1.15          # (C = 768, dilation 3: 635 us with 128-row blocks against 507 x 18 / 16 = 570 us at 96-row efficiency)
+        load *= 1.15          # (C = 768, dilation 3: 625-635 us with 324 128-row blocks against 580 us with 864 96-row half-depth ones)
     if real > 16384:                                                  # many blocks per CU: throughput bound
         return load * sum(panel_w) * n_tiles / (8 * cus_per_xcd)
     total_runs = len(panel_w) * rpp
@@ -904,7 +907,9 @@ class _PlanBuilder:
         if all("u" in e for e in ents):
             ksteps = [c // 16 * -(-k // st["taps"]) for k in ks]
             Lr = self.Lref
-            unfuse = not fusable or (v.nk in (2, 3) and (choose_wino_cfg(ksteps, 1, wpad, Lr, 1, st["wcfg"], v.bf)[1] + 4.0 + c * Lr * 16 / 4.0e6
+            # (averaging pass: 16 bytes per element that the conv launch has just written -- measured 19 us for 184 MB, i.e. it
+            # runs out of the last-level cache, ~8 bytes per ns)
+            unfuse = not fusable or (v.nk in (2, 3) and (choose_wino_cfg(ksteps, 1, wpad, Lr, 1, st["wcfg"], v.bf)[1] + 4.0 + c * Lr * 16 / 8.0e6
                                                          < choose_wino_cfg([sum(ksteps)], 1, wpad, Lr, 1, st["wcfg"], v.bf)[1]))
             if not unfuse:
                 segs = [make_wino_seg(T1[j], e["u"], c, k, taps=st["taps"]) for j, e, k in zip(order, ents, ks)]
