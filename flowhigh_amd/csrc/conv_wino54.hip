@@ -398,7 +398,8 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
         for (int q = 0; q < 5; ++q) yw[i * V_YP + q] = y[q][i];
     }
     // store items of this thread: 5 of the 1280 float4 of its column's 32 x 160 sub-tile; first residual requested
-    // in front of the barrier (the A^T registers are dead)
+    // in front of the barrier (the A^T registers are dead).  (Requested a whole round ahead -- behind the previous round's
+    // exchange writes, two register sets -- the conv launches of a step took 13.50-13.58 ms against 13.45-13.47 ms, same box.)
     u32x4 rpre[5];
     unsigned soff[5];
     int srow[5], scol[5], nreal[5];
