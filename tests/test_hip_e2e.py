@@ -84,6 +84,28 @@ def test_generate_odd_upsamplers_full_width_vs_oracle(sr_in, method, secs, B):
             assert torch.equal(m.generate(clips[b], sr_in, 48000, 1, noise=noise[b:b + 1]), out[b:b + 1])
 
 
+def test_full_size_properties_odd_upsamplers():
+    """BASELINE.json size (10 s clips, full-width vocoder) with the k = 2 u upsamplers on the odd rates (480 N + 98 vocoder
+    samples, stage lengths 5 N + 1, 20 N + 4, 80 N + 16, 240 N + 49, 480 N + 98: rows that are not 16-byte aligned at three of
+    the five stages): determinism, peak normalisation, batch rows = single-clip runs, and the time-chunked vocoder = the
+    unchunked one, all bit for bit."""
+    cfg = dict(synth.ODD_CFG, upsample_initial_channel=1536)
+    m, _ = model_for(cfg, 0, "euler", upsampling="hip")
+    clips = [synth.lowres_clip(70 + i, 10.0, 12000) for i in range(2)]
+    noise = torch.cat([synth.prior_noise(70 + i, 1000) for i in range(2)], 0)
+    out, st = m.generate_batch(clips, 12000, 48000, 1, noise=noise, return_stages=True)
+    assert tuple(out.shape) == (2, 480000) and tuple(st["wav"].shape) == (2, 480098) and torch.isfinite(out).all()
+    assert torch.allclose(out.abs().amax(dim=1).cpu(), torch.full((2,), 0.99), atol=1e-6)
+    assert torch.equal(out, m.generate_batch(clips, 12000, 48000, 1, noise=noise))
+    for b in range(2):
+        assert torch.equal(m.generate(clips[b], 12000, 48000, 1, noise=noise[b:b + 1]), out[b:b + 1])
+    voc = m.flowhigh.vocoder
+    mel = torch.randn(1, 1000, 256, generator=torch.Generator().manual_seed(5)).cuda() * 2.0 - 3.0
+    whole = voc.forward(mel).clone()
+    halo, align = voc.chunk_geometry()
+    assert torch.equal(voc.forward_chunked(mel, 5 * align), whole) and whole.shape[1] == 480098
+
+
 def test_device_resampler_path_vs_oracle():
     cfg = synth.TINY_CFG
     m, sd = model_for(cfg, 0, "euler", upsampling="hip")
