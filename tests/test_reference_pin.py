@@ -13,7 +13,9 @@ from oracle import ref_cpu, ref_shim
 pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
 
 
-@pytest.mark.parametrize("cfgname,sr_in,method,steps", [("ALT_CFG", 12000, "euler", 2), ("TINY_CFG", 24000, "midpoint", 1)])
+@pytest.mark.parametrize("cfgname,sr_in,method,steps", [("ALT_CFG", 12000, "euler", 2), ("TINY_CFG", 24000, "midpoint", 1),
+                                                        # upsamplers with k - u odd (the vocoder returns 480 N + 98 samples), five kernel sizes
+                                                        ("ODD_CFG", 16000, "midpoint", 1), ("NK5_AMP2_CFG", 8000, "euler", 1)])
 def test_oracle_equals_live_reference(cfgname, sr_in, method, steps):
     cfg = getattr(synth, cfgname)
     d = tempfile.mkdtemp(prefix="fh_pin_")
