@@ -52,6 +52,15 @@ constexpr int V_Y = 2 * 32 * V_YP;
 constexpr int V_LDS_FLOATS = 2 * V_BUF > V_EPI + V_Y ? 2 * V_BUF : V_EPI + V_Y;
 constexpr int V_RUN = 8;             // n-blocks of a panel that run together on one XCD (conv_wino.hip: W_RUN)
 
+// Phase-major rows (dilated convs) are tiled as ONE sequence: the d phases one after the other in a "position" space in which
+// every phase owns TS tile slots = its ceil(n / 5) tiles + >= 3 empty ones (multiple of 4, so that a phase starts on a 16-byte
+// boundary of the position axis as it does in memory).  Position P = p (5 TS) + u is sample u of phase p; u >= n_p reads as
+// zero, which is the conv's padding at both ends of every phase (the empty slots are >= 15 positions, the taps reach <= 10), and
+// is not stored.  A block is 64 consecutive tile slots whatever phases they belong to: a dilation-5 conv over 5 x 1 000 samples
+// runs 16 blocks per panel, not 5 x 4 (tiles of 320 outputs per phase: 751 us against 500 us undilated at C = 768).  Which block
+// computes a tile does not change the tile's arithmetic.
+__host__ __device__ inline int v_tile_slots(int len, int dil) { return (((len + dil - 1) / dil + 4) / 5 + 3 + 3) & ~3; }
+
 // Rows of B^T for the points 0, 1, -1, 2, -2, 1/2, -1/2, inf (tests/tools/winograd_numerics.py: toom_cook(5, 4, ...)):
 //   v = x[off[5]];  v = fma(coef[j], x[off[j]], v)  for j = 0 .. 4        (coef 0: the slot repeats a real sample)
 __device__ const int kB8Off[8][6] = {{2, 4, 0, 0, 0, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6},
@@ -105,8 +114,9 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   const int gb = uni(panel / co_tiles);
   const int b = uni(gb % batch);
   const fh_wino_group* __restrict__ G = groups + uni(gb / batch);
-  const int ph = uni(ntile % dil);            // phase of the decimated sequence
-  const int tb = uni(ntile / dil);            // 320-output block within the phase
+  const bool cat = pm != 0;                   // phase-major rows: tiled in the concatenated position space (above)
+  const int ph = cat ? 0 : uni(ntile % dil);  // plain layout: phase of the decimated sequence ...
+  const int tb = cat ? ntile : uni(ntile / dil);        // ... and 320-output block within it
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,14 +124,25 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   const int l31 = lane & 31, lh = lane >> 5;
   const int co0 = cot * BM;
   const int len = uni(G->len), cout_pad = uni(G->cout_pad), nseg = uni(G->nseg);
-  if (tb * V_OUT * dil + ph >= len) return;
+  const int ps = 5 * v_tile_slots(len, dil);         // (cat) positions per phase
+  if (cat ? tb * V_OUT >= dil * ps : tb * V_OUT * dil + ph >= len) return;
 
-  // phase-major tensors (pm): row = dil phases of lp samples, x[p + dil u] at p * lp + u; else dil == 1 (host)
+  // phase-major tensors (pm): row = dil phases of lp samples, x[p + dil u] at p * lp + u
   const int lp = ((len + dil - 1) / dil + 3) & ~3;
   const int pitch = pm ? dil * lp : len;             // floats per (batch, channel) row, inputs and outputs
-  const int rowlen = pm ? lp : len;                  // addressable samples of this block's (phase) row
-  const int nvalid = (len - ph + dil - 1) / dil;                 // ... of which real (decimated samples of this phase)
-  const int rowbase = pm ? ph * lp : 0;
+  const int nvalid = (len - ph + dil - 1) / dil;                 // (plain layout) real decimated samples of this block's phase
+  // aligned position P (a multiple of 4; cat: concatenated space, else decimated index of the plain row at dilation 1) ->
+  // float offset of its quad inside a (batch, channel) row, or -1 outside the tensor; nv = real samples from P on in its row
+  auto locate = [&](int P, int& nv) -> int {
+    if (cat) {
+      const int p = P >= 0 ? P / ps : dil;
+      const int u = P - p * ps;
+      nv = p < dil ? (len - p + dil - 1) / dil - u : 0;
+      return (p < dil && u < lp) ? p * lp + u : -1;
+    }
+    nv = len - P;
+    return (P >= 0 && P < len) ? P : -1;
+  };
 
   // this wave's row of B^T: sample slots and coefficients, wave-uniform
   int boff[6];
@@ -166,8 +187,9 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   constexpr int NLD = VL ? 2 : 6;                      // loads per lane and channel
   int wofs[NXS];                                       // LDS float offsets of this lane's samples inside a slab buffer
   unsigned voff[NLD];                                  // byte offsets of the loads inside the chunk's first row, or out of range
-  int ua = 0;                                          // decimated index of local sample 0 (VL: a multiple of 4)
-  bool tail = false;                                   // (VL) the slab reaches past the row's last real sample
+  int ua = 0;                                          // position of local sample 0 (VL: a multiple of 4)
+  int nvq[NLD];                                        // (VL) real samples from each quad's first sample on
+  bool tail = false;                                   // (VL) the slab holds positions that are not real samples
   auto setup_seg = [&](const VSeg& S) {
     const int ub = tb * V_OUT - S.center;
     const int sh = VL ? (ub & 3) : 0;
@@ -181,17 +203,21 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       if constexpr (VL) {
-        const int q = lane + 64 * i, qa = (ua >> 2) + q;
-        const bool ok = q < V_XQ && qa >= 0 && 4 * qa < rowlen;               // (outside the row: zero padding)
-        voff[i] = ok ? (unsigned)(rowbase + 4 * qa) * 4u : 0x80000000u;
+        const int q = lane + 64 * i;
+        const int off = locate(ua + 4 * q, nvq[i]);                           // (outside the rows: zero padding)
+        voff[i] = (q < V_XQ && off >= 0) ? (unsigned)off * 4u : 0x80000000u;
       } else {
-        const int u = ua + lane + 64 * i;                                     // decimated index
+        const int u = ua + lane + 64 * i;                                     // decimated index (plain layout only: phase-major rows are aligned)
         const int pos = u * dil + ph;                                         // position in the clip
         const bool ok = lane + 64 * i < 4 * V_XQ && (unsigned)pos < (unsigned)len;
-        voff[i] = ok ? (unsigned)(pm ? rowbase + u : pos) * 4u : 0x80000000u;
+        voff[i] = ok ? (unsigned)pos * 4u : 0x80000000u;
+        nvq[i] = 0;
       }
     }
-    tail = VL && ua + 4 * V_XQ > nvalid;
+    if constexpr (VL) {              // block-uniform: does every staged position hold a real sample of one row?
+      int nv0;
+      tail = locate(ua, nv0) < 0 || nv0 < 4 * V_XQ;
+    }
   };
   unsigned xq[2][NXS];                                 // [channel of the pair][sample]
   auto load_x = [&](const VSeg& S, int chunk, bool valid) {
@@ -218,10 +244,8 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
     float* dst = lds + buf * V_BUF;
     if (tail) {                                        // (last block of a row: zero past the end; block-uniform branch)
 #pragma unroll
-      for (int i = 0; i < NXS; ++i) {
-        const int v = 4 * (lane + 64 * (i >> 2)) + (i & 3);
-        if (ua + v >= nvalid) xq[0][i] = xq[1][i] = 0u;
-      }
+      for (int i = 0; i < NXS; ++i)
+        if ((i & 3) >= nvq[i >> 2]) xq[0][i] = xq[1][i] = 0u;
     }
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
@@ -362,7 +386,7 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   float* const E = lds;                               // [column nt][xi][tile col 32][row, pitch V_EP]
   float* const Y = lds + V_EPI;                       // [column nt][row 32][160 outputs, pitch V_YP]
   const int ent = tid >> 8, erq = (tid >> 5) & 7, ecol = tid & 31;        // A^T item: column, row quad, tile
-  const int v_first = tb * V_OUT;                     // decimated index of the block's first output
+  const int v_first = tb * V_OUT;                     // position of the block's first output
   __syncthreads();                                    // every wave is out of the K loop: the slab space is free
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -409,9 +433,11 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
       srow[i] = item / 40;
       scol[i] = (item % 40) * 4;
       const int co = co0 + mt * 32 + srow[i];
-      const int v0 = v_first + ent * 160 + scol[i];                       // decimated index of the vector's first output
-      nreal[i] = co < cout ? nvalid - v0 : 0;                             // real outputs from v0 on (<= 0: none)
-      soff[i] = ((unsigned)co * (unsigned)pitch + (unsigned)(rowbase + v0)) * 4u;
+      const int v0 = v_first + ent * 160 + scol[i];                       // position of the vector's first output
+      int nv;
+      const int off = VL ? locate(v0, nv) : (nv = nvalid - v0, v0);
+      nreal[i] = (co < cout && off >= 0) ? nv : 0;                        // real outputs from v0 on (<= 0: none)
+      soff[i] = ((unsigned)co * (unsigned)pitch + (unsigned)(off >= 0 ? off : 0)) * 4u;
       if (VL && nres > 0)
         rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, nreal[i] >= 4 ? soff[i] : 0x80000000u, 0, 0);
     }
@@ -460,13 +486,18 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   if (pf == 0x7fc12345u) __builtin_amdgcn_s_sleep(1);
 }
 
+// 320-output blocks of a row: per phase in the plain layout, over the concatenated tile slots of all phases in the phase-major one
+int wino54_n_tiles(int len, int dilation, int pm) {
+  return pm ? fh_cdiv((long long)dilation * v_tile_slots(len, dilation), V_BT) : fh_cdiv(fh_cdiv(len, dilation), V_OUT) * dilation;
+}
+
 template <int MT, bool VL>
 int launch_wino54(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation, int pm,
                   hipStream_t stream, const int* run_map, int n_runs) {
   constexpr int BM = 32 * MT;
   FH_CHECK_ARG(cout_pad > 0 && cout_pad % BM == 0, "fh_conv_wino54_f32: cout_pad %d not a multiple of %d", cout_pad, BM);
   const int co_tiles = cout_pad / BM;
-  const int n_tiles = fh_cdiv(fh_cdiv(len, dilation), V_OUT) * dilation;
+  const int n_tiles = wino54_n_tiles(len, dilation, pm);
   const long long panels = (long long)n_groups * batch * co_tiles;
   const int run_len = fh_cdiv(n_tiles, fh_cdiv(n_tiles, V_RUN));
   const long long runs = run_map ? (long long)n_runs : panels * fh_cdiv(n_tiles, run_len);
@@ -504,7 +535,8 @@ int wino54_dispatch(const fh_wino_group* groups, int n_groups, int batch, int co
   const int pm = layout_flags & 1;
   // 16-byte accesses need contiguous aligned rows (layout bit 1: the caller rules them out -- ragged launches in which
   // some group's rows are not 16-byte aligned; `len` is then only the longest group's length)
-  const bool vl = (pm || (dilation == 1 && len % 4 == 0)) && !(layout_flags & 2);
+  // (phase-major rows are always aligned: bit 1 is about plain rows)
+  const bool vl = pm || (dilation == 1 && len % 4 == 0 && !(layout_flags & 2));
 #define FH_W54_CASE(id, MT)                                                                                         \
   case id:                                                                                                          \
     return vl ? launch_wino54<MT, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs)  \
@@ -526,6 +558,10 @@ extern "C" int fh_conv_wino54_f32(const fh_wino_group* groups, int n_groups, int
   FH_CHECK_ARG(dilation >= 1 && dilation <= 64, "fh_conv_wino54_f32: dilation %d unsupported", dilation);
   return wino54_dispatch(groups, n_groups, batch, cout_pad, len, dilation, phase_major != 0 ? 1 : 0, tile_cfg, (hipStream_t)stream,
                          nullptr, 0);
+}
+
+extern "C" int fh_wino54_n_tiles(int len, int dilation, int phase_major) {
+  return (len > 0 && dilation >= 1) ? wino54_n_tiles(len, dilation, phase_major != 0) : -1;
 }
 
 extern "C" int fh_wino54_run_len(int n_tiles) { return n_tiles > 0 ? fh_cdiv(n_tiles, fh_cdiv(n_tiles, V_RUN)) : -1; }

@@ -79,6 +79,7 @@ _SIGS = {
     "fh_wino54_tile_m": [_I],
     "fh_wino54_tile_n": [],
     "fh_conv_wino54_f32": [_P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fh_wino54_n_tiles": [_I, _I, _I],
     "fh_wino54_run_len": [_I],
     "fh_conv_wino54_ragged_f32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "fh_mean_f32": [_P, _P, _P, _P, C.c_longlong, _F, _P],

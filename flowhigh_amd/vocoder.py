@@ -173,6 +173,16 @@ _WINO_RUN = 8                      # W_RUN of conv_wino.hip
 _WINO_BF_SPEED = {0: 0.75, 1: 0.76, 4: 0.72, 5: 0.94, 6: 0.75}
 
 
+def wino_n_tiles(cfg, length, dil, pm):
+    """Output tiles per (group, batch, co tile) panel of a Winograd launch (the kernels' launchers compute the same): per phase in
+    general; the F(5,4) kernel tiles phase-major rows as one sequence of 5-output tile slots (conv_wino54.hip: v_tile_slots)."""
+    bm, bt = _WINO_TILES[cfg & (15 | WINO_F54)]
+    if cfg & WINO_F54 and pm:
+        slots = ((-(-length // dil) + 4) // 5 + 3 + 3) & ~3
+        return -(-dil * slots // 64)
+    return -(-(-(-length // dil)) // bt) * dil
+
+
 def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=False):
     """Estimated duration (us) of one fh_conv_wino_f32 launch: the kernel's block -> (panel, tile) map replayed
     on 8 XCDs x 32 CUs with in-order dispatch per XCD (block i goes to XCD i % 8).  ksteps: K steps
@@ -184,7 +194,7 @@ def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=F
     a, b = _WINO_COST[cfg]
     if bf:
         a *= _WINO_BF_SPEED[cfg]              # (the F(5,4) kernel has no bf16 x 6 form: never asked for)
-    n_tiles = -(-(-(-length // dil)) // bt) * dil
+    n_tiles = wino_n_tiles(cfg, length, dil, dil > 1)       # (dilated Winograd launches of the model are phase-major)
     cot = wpad // bm
     panel_w = [a * k + b for k in ksteps for _ in range(batch * cot)]
     run_len = -(-n_tiles // -(-n_tiles // _WINO_RUN))
@@ -1256,7 +1266,7 @@ class Vocoder:
                     # runs (consecutive tiles of one (group, co tile) panel, dealt to one XCD) that hold real tiles
                     bm, bt = _WINO_TILES[wcfg]
                     cot = wpad // bm
-                    n_tiles = -(-(-(-maxlen // dil)) // bt) * dil
+                    n_tiles = wino_n_tiles(wcfg, maxlen, dil, pm)
                     run_len = (hip.lib().fh_wino54_run_len if fam else hip.lib().fh_wino_run_len)(n_tiles)
                     rpp = -(-n_tiles // run_len)
                     runs = []
@@ -1264,8 +1274,11 @@ class Vocoder:
                         # tile index = (block of bt outputs within the phase) * dil + phase: real while its first
                         # output (phase + dil * bt * block) lies inside the row
                         # (blocks per phase differ by at most one, so the real tiles are 0 .. t_last without holes)
-                        nb = [max(0, -(-(length - ph) // (dil * bt))) for ph in range(dil)]
-                        t_last = dil * (nb[0] - 1) + sum(1 for v in nb if v == nb[0]) - 1
+                        if fam and pm:                  # (the F(5,4) kernel's concatenated tiling: a group's real tiles are the first ones)
+                            t_last = wino_n_tiles(wcfg, length, dil, pm) - 1
+                        else:
+                            nb = [max(0, -(-(length - ph) // (dil * bt))) for ph in range(dil)]
+                            t_last = dil * (nb[0] - 1) + sum(1 for v in nb if v == nb[0]) - 1
                         own = range(t_last // run_len + 1)
                         for ct in range(cot):
                             runs += [(gi * cot + ct) * rpp + r for r in own]

@@ -193,8 +193,12 @@ int fh_wino54_tile_n(void);
 int fh_conv_wino54_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,
                        int dilation, int phase_major, int tile_cfg, void* stream);
 /* Ragged form, as fh_conv_wino_ragged_f32: runs of fh_wino54_run_len(n_tiles) consecutive 320-output tiles,
- * n_tiles = ceil(ceil(max_len / dilation) / fh_wino54_tile_n()) * dilation; layout_flags bit 0 = phase-major, bit 1 = some
- * group's rows are not 16-byte aligned. */
+ * n_tiles = fh_wino54_n_tiles(max_len, dilation, phase-major?): in the plain layout ceil(ceil(len / dilation) / 320) tiles per
+ * phase, tile index = block-in-phase * dilation + phase; in the phase-major layout the d phases are tiled as ONE sequence
+ * (every phase owns ceil(n / 5) + >= 3 five-output tile slots, rounded up to a multiple of 4; a tile is 64 consecutive slots), a
+ * group's real tiles are 0 .. fh_wino54_n_tiles(its len, ...) - 1.  layout_flags bit 0 = phase-major, bit 1 = some group's
+ * plain rows are not 16-byte aligned. */
+int fh_wino54_n_tiles(int len, int dilation, int phase_major);   /* 320-output blocks per (group, batch, co tile) panel */
 int fh_wino54_run_len(int n_tiles);
 int fh_conv_wino54_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_pad, int max_len, int dilation,
                               int layout_flags, int tile_cfg, const int* run_map, int n_runs, void* stream);

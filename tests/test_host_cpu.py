@@ -152,17 +152,22 @@ def test_plan_ragged_merges_launch_by_launch():
             bm, bt = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256),
                       V.WINO_F54: (128, 320), V.WINO_F54 | 1: (96, 320), V.WINO_F54 | 2: (64, 320)}[wcfg]
             assert hip.lib().fh_wino54_tile_n() == 320 and hip.lib().fh_wino54_tile_m(wcfg & 15) == bm if f54 else True
-            n_tiles = -(-(-(-maxlen // dil)) // bt) * dil
+            pm = pmflag & 1
+            n_tiles = V.wino_n_tiles(wcfg, maxlen, dil, pm)
+            if f54:
+                assert n_tiles == hip.lib().fh_wino54_n_tiles(maxlen, dil, pm)
             run_len = (hip.lib().fh_wino54_run_len if f54 else hip.lib().fh_wino_run_len)(n_tiles)
             rpp = -(-n_tiles // run_len)
             assert len(set(runs)) == n_runs and all(0 <= r < ng * (wpad // bm) * rpp for r in runs)
-            for r in runs:                                   # the run's first tile starts inside its group's row
+            # real tiles of a group: per phase (tile = block-in-phase * dil + phase) in general; the F(5,4) kernel tiles
+            # phase-major rows as one sequence, a group's real tiles are then the first fh_wino54_n_tiles(its len)
+            real = (lambda t, g: t < V.wino_n_tiles(wcfg, g.len, dil, pm)) if (f54 and pm) else \
+                (lambda t, g: (t % dil) + dil * bt * (t // dil) < g.len)
+            for r in runs:                                   # the run's first tile is a real tile of its group
                 g = gs[(r // rpp) // (wpad // bm)]
-                t = (r % rpp) * run_len
-                assert (t % dil) + dil * bt * (t // dil) < g.len
+                assert real((r % rpp) * run_len, g)
             # ... and every real tile is covered
-            want = sum((wpad // bm) * len({t // run_len for t in range(n_tiles) if (t % dil) + dil * bt * (t // dil) < g.len})
-                       for g in gs)
+            want = sum((wpad // bm) * len({t // run_len for t in range(n_tiles) if real(t, g)}) for g in gs)
             assert want == n_runs
             got_wino += ng
     assert got_act == n_act_groups and got_wino == n_wino_groups

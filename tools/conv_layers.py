@@ -39,7 +39,7 @@ for i, s in enumerate(convs):
         _, d, ng, cpad, n_len, dil, fl, wcfg, _pm = s[:9]
         xr, f54, wcfg = wcfg & 32, wcfg & V.WINO_F54, wcfg & 15
         bm, bn = V._WINO_TILES[wcfg | f54]
-        blocks = ng * s[9] * (cpad // bm) * -(-(-(-n_len // dil)) // bn) * dil
+        blocks = ng * s[9] * (cpad // bm) * V.wino_n_tiles(wcfg | f54, n_len, dil, _pm)
     else:
         xr = f54 = 0
         _, d, ng, cpad, n_len, tcfg, ck, fl = s
