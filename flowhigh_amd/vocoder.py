@@ -505,7 +505,7 @@ def act1d_grouped(groups, batch, channels, length, device, din=1, dout=1):
 # (tools/exp/occ_ab.sh on both kinds of affected boxes: 4 blocks help on one kind only (bench 500 -> 527) and do nothing on the
 # other (the clock is clamped as before); 3 blocks help on both (488 -> 522, 500 -> 524); 2 blocks: the activation itself
 # is too slow then (512))
-ACT_BLOCKS_CHOICES = (0, 3)             # 0 = no cap
+ACT_BLOCKS_CHOICES = (0, 3, 4)          # 0 = no cap; 4 is enough on one kind of affected box (and costs the activation less), 3 on both
 _act_blocks = {}                        # device ordinal -> setting in force
 
 
