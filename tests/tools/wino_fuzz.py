@@ -49,10 +49,12 @@ for case in range(n_cases):
     got = V.from_phase_major(out.cpu(), d, L) if pm else out.cpu()
     err = (got - ref).abs().max().item()
     worst = max(worst, err)
-    # (outputs are ~N(0, 1) per segment; rounding grows with the depth c k of the sums: the wider layers of the F(5,4) runs get 1.5 x)
-    # ... and a ONE-tap filter is the worst case of an 8-point transform: four of the five outputs of a tile must cancel to the
-    # tap's product out of eight terms with coefficients up to 16 (600 + 150 cases: 3.1e-5 twice at k = 1; every other case inside 3e-5 per segment)
-    tol = 3e-5 * nseg * (1.0 if c <= 192 else 1.5) * (1.35 if F54 and min(ks) == 1 else 1.0)
+    # (outputs are ~N(0, 1) per segment; rounding grows with the depth c k of the sums: the wider layers of the F(5,4) runs get
+    # 1.5 x.  The 8-point transform's constants -- up to 16 in A^T, 5.25 in B^T -- put its worst cases a third above F(4,3)'s:
+    # 1 350 random cases: 3.1e-5 for ONE-tap filters (four of five outputs of a tile must cancel), 3.2e-5 per segment for a
+    # k = 9 + 11 pair at C = 192, everything else inside 3e-5; per conv on average and end to end the two forms are equal,
+    # profiles/r04_winograd_numerics.txt)
+    tol = (4e-5 if F54 else 3e-5) * nseg * (1.0 if c <= 192 else 1.5)
     ok = err <= tol and bool(torch.isfinite(got).all())
     if not ok:
         print(f"FAIL case {case}: c={c} ks={ks} d={d} B={B} L={L} pm={pm} nres={nres} cfg={wcfg} err={err}")
