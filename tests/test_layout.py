@@ -123,6 +123,71 @@ def test_pack_wino_weight_is_the_f43_transform_of_the_conv(c, k):
     assert (y - ref).abs().max().item() <= 1e-5 * float(ref.abs().max())
 
 
+# F(5,4): rows of B^T as conv_wino54.hip applies them (kB8Off / kB8Coef: v = x[unit] + sum_j coef_j x[off_j]) and A^T (the sums /
+# differences of its epilogue); points 0, 1, -1, 2, -2, 1/2, -1/2, inf
+_B8_OFF = [[2, 4, 0, 0, 0, 6]] + [[1, 2, 3, 4, 5, 6]] * 6 + [[1, 3, 5, 1, 1, 7]]
+_B8_COEF = [[5.25, -5.25, -1, 0, 0], [1, 1, -4.25, -4.25, 1], [-1, 1, 4.25, -4.25, -1], [.5, .25, -2.5, -1.25, 2],
+            [-.5, .25, 2.5, -1.25, -2], [2, 4, -2.5, -5, .5], [-2, 4, 2.5, -5, -.5], [-1, 5.25, -5.25, 0, 0]]
+_AT8 = torch.tensor([[1, 1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, .5, -.5, 0], [0, 1, 1, 4, 4, .25, .25, 0],
+                     [0, 1, -1, 8, -8, .125, -.125, 0], [0, 1, 1, 16, 16, .0625, .0625, 1]], dtype=torch.float64)
+
+
+@pytest.mark.parametrize("c,k", [(16, 3), (32, 7), (48, 11), (16, 5), (16, 12)])
+def test_pack_wino54_weight_is_the_f54_transform_of_the_conv(c, k):
+    """pack_wino54_weight ([ci/16, G, 8, cout_pad, 16], taps in groups of 4) with the B^T rows and A^T of conv_wino54.hip
+    reproduces F.conv1d: y[5t + i] = sum_xi A^T[i, xi] sum_{g, ci} U[g, xi, co, ci] (B^T x[5t + 4g - center ..])[xi]; and the
+    constants are the Toom-Cook matrices of tests/tools/winograd_numerics.py for the same points."""
+    import importlib.util
+    import torch.nn.functional as F
+    from flowhigh_amd import vocoder as V
+    bt = torch.zeros(8, 8, dtype=torch.float64)
+    for xi in range(8):
+        bt[xi, _B8_OFF[xi][5]] += 1.0
+        for j in range(5):
+            bt[xi, _B8_OFF[xi][j]] += _B8_COEF[xi][j]
+    spec = importlib.util.spec_from_file_location("wn", ROOT / "tests" / "tools" / "winograd_numerics.py")
+    wn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wn)
+    from fractions import Fraction as Fr
+    at_ref, g_ref, bt_ref = wn.toom_cook(5, 4, [0, 1, -1, 2, -2, Fr(1, 2), -Fr(1, 2)])
+    assert torch.equal(bt, bt_ref) and torch.equal(_AT8, at_ref)
+    assert (torch.tensor(V._WINO54_G, dtype=torch.float64) - g_ref).abs().max().item() < 1e-15
+    g = torch.Generator().manual_seed(k)
+    w = torch.randn(c, c, k, generator=g, dtype=torch.float64)
+    x = torch.randn(1, c, 60, generator=g, dtype=torch.float64)
+    cpad = 64
+    u = V.pack_wino54_weight(w, cpad).double()                    # [c/16, G, 8, cpad, 16]
+    ng, center = -(-k // 4), (k - 1) // 2
+    assert tuple(u.shape) == (c // 16, ng, 8, cpad, 16) and float(u[:, :, :, c:].abs().max()) == 0.0
+    xp = torch.nn.functional.pad(x, (center, 4 * ng + 8))
+    tiles = 60 // 5
+    m = torch.zeros(8, cpad, tiles, dtype=torch.float64)
+    for gi in range(ng):
+        d = xp[0, :, 4 * gi:].unfold(-1, 8, 5)[:, :tiles]         # [c, tiles, 8]
+        v = torch.einsum("xj,ctj->xct", bt, d)
+        ug = u[:, gi].permute(1, 2, 0, 3).reshape(8, cpad, c)     # [8, cpad, ci]
+        m += torch.einsum("xoc,xct->xot", ug, v)
+    y = torch.einsum("ix,xot->oti", _AT8, m).reshape(cpad, 60)[:c]
+    xr = F.pad(x, (center, k - 1 - center))                       # (even k: one more sample on the right)
+    ref = F.conv1d(xr, w)[0]
+    assert (y - ref).abs().max().item() <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("L,d,pm", [(5000, 5, 1), (5000, 3, 1), (20000, 5, 1), (250, 5, 1), (13, 3, 1), (1, 1, 1), (5000, 5, 0), (777, 1, 0)])
+def test_wino54_tile_counts_host_and_library_agree(L, d, pm):
+    """vocoder.wino_n_tiles (run maps, launch model) = fh_wino54_n_tiles (the launcher): phase-major rows are tiled as one
+    sequence of 5-output tile slots, every phase its ceil(n / 5) tiles + >= 3 empty ones, rounded up to a multiple of 4."""
+    from flowhigh_amd import hip, vocoder as V
+    got = V.wino_n_tiles(V.WINO_F54, L, d, pm)
+    assert got == hip.lib().fh_wino54_n_tiles(L, d, pm)
+    n = -(-L // d)
+    if pm:
+        slots = (-(-n // 5) + 3 + 3) // 4 * 4
+        assert got == -(-d * slots // 64) and slots >= -(-n // 5) + 3
+    else:
+        assert got == -(-n // 320) * d
+
+
 @pytest.mark.parametrize("L,d", [(23, 3), (1000, 5), (17, 1), (4, 5)])
 def test_phase_major_round_trip(L, d):
     from flowhigh_amd import hip, vocoder as V
