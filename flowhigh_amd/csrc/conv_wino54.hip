@@ -49,7 +49,11 @@ constexpr int V_EP = 36;             // column pitch (floats) of the exchange ti
 constexpr int V_YP = 168;            // row pitch (floats) of the output staging: 16-byte aligned, 4 * 168 % 64 == 32
 constexpr int V_EPI = 2 * 8 * 32 * V_EP;        // exchange tiles of two 32 x 32 sub-tiles (both columns of one mt)
 constexpr int V_Y = 2 * 32 * V_YP;
-constexpr int V_LDS_FLOATS = 2 * V_BUF > V_EPI + V_Y ? 2 * V_BUF : V_EPI + V_Y;
+// LDS: [two slab buffers | exchange tiles]; the output staging reuses the slab space (the exchange tiles do not: a wave that
+// leaves the K loop writes its accumulators while slower waves still read the slab, and a round's exchange writes need not wait
+// for the previous round's stores: 2 MT block barriers in the epilogue instead of 3 MT)
+static_assert(V_Y <= 2 * V_BUF, "output staging does not fit the slab space");
+constexpr int V_LDS_FLOATS = 2 * V_BUF + V_EPI;
 constexpr int V_RUN = 8;             // n-blocks of a panel that run together on one XCD (conv_wino.hip: W_RUN)
 
 // Phase-major rows (dilated convs) are tiled as ONE sequence: the d phases one after the other in a "position" space in which
@@ -383,14 +387,13 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? uni(G->res[1]) + oslab : nullptr, nres > 1 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? uni(G->res[2]) + oslab : nullptr, nres > 2 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (unsigned)cout * 4u : 0u);
-  float* const E = lds;                               // [column nt][xi][tile col 32][row, pitch V_EP]
-  float* const Y = lds + V_EPI;                       // [column nt][row 32][160 outputs, pitch V_YP]
+  float* const E = lds + 2 * V_BUF;                   // [column nt][xi][tile col 32][row, pitch V_EP]: behind the slab buffers
+  float* const Y = lds;                               // [column nt][row 32][160 outputs, pitch V_YP]: in the slab space
   const int ent = tid >> 8, erq = (tid >> 5) & 7, ecol = tid & 31;        // A^T item: column, row quad, tile
   const int v_first = tb * V_OUT;                     // position of the block's first output
-  __syncthreads();                                    // every wave is out of the K loop: the slab space is free
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    if (mt > 0) __syncthreads();                       // (the store phase of the previous round is done with Y and E)
+    // (no barrier here: E is not the slab, and the readers of the previous round's E are past that round's second barrier)
     {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
