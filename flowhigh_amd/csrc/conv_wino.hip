@@ -144,11 +144,16 @@ __device__ __forceinline__ WSeg load_wseg(const fh_wino_seg* S) {
 // row and chunk: lane (row, half) reads its 8 channels of each piece as one 16-byte load), the B fragments are
 // split in registers, and a 16-channel k-block is six v_mfma_f32_32x32x16_bf16 (see split8 above).  The lane <->
 // channel assignment is the one of the fp32 form: lane half h owns channels 8 h .. 8 h + 7 of the chunk.
+// launch constants the block -> work mapping divides by (fh_common.h: fh_fastdiv); rect_*: the xcd_ranges mapping
+struct WDivs {
+  fh_fastdiv run_len, runs_per_panel, co_tiles, batch, dil, rect_r, rect_cr, rect_gb;
+};
+
 template <int MT, int NT, int SUBS, bool VL, bool BF>
 __global__ __attribute__((amdgpu_flat_work_group_size(W_THREADS, W_THREADS), amdgpu_waves_per_eu(3, 3)))
 void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles,
                       int n_tiles, int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs,
-                      int xcd_ranges) {
+                      int xcd_ranges, WDivs dv) {
   using Cfg = WCfg<MT, NT, SUBS>;
   constexpr int W_BM = Cfg::BM, W_BT = Cfg::BT, W_P = Cfg::P, W_RP2 = Cfg::RP2, W_XPT = Cfg::XPT, W_SLAB = Cfg::SLAB;
   constexpr int W_SUB = (W_CK / 2) * W_RP2;          // floats of one 16-channel chunk inside a slab buffer
@@ -158,7 +163,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   const int panels = n_groups * batch * co_tiles;
   // (a panel's n blocks are cut into equal runs of <= W_RUN: with fixed runs of 8 and 10 blocks per
   // panel, every other XCD would get the 2-block remainders only)
-  const int runs_per_panel = (n_tiles + run_len - 1) / run_len;
+  const int runs_per_panel = (int)dv.runs_per_panel.d;
   const int total_runs = panels * runs_per_panel;
   const int bid = blockIdx.x;
   const int slot = bid >> 3;
@@ -171,19 +176,20 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
     // stream that panel's weights in lockstep.  Price: every XCD fetches every weight panel (once per rectangle): the
     // mapping for launches whose weights are small beside their activations (tools/traffic_per_launch.py), chosen by
     // the host plan; groups still in launch order (heavy first).
+    // (host: rect_r = R, rect_cr = co_tiles R, rect_gb = co_tiles ceil(tpx / R) R = slots per (group, batch item))
     const int tpx = (n_tiles + 7) >> 3;
-    const int R = co_tiles < 32 ? 32 / co_tiles : 1;
-    const int nrect = (tpx + R - 1) / R;
-    const int per_gb = co_tiles * nrect * R;
-    const int gbi = uni(slot / per_gb), rem = slot % per_gb;
-    const int rect = rem / (co_tiles * R), w = rem % (co_tiles * R);
-    const int t = rect * R + w % R;
+    const int R = (int)dv.rect_r.d;
+    const int gbi = fh_div(slot, dv.rect_gb), rem = fh_mod(slot, gbi, dv.rect_gb);
+    const int rect = fh_div(rem, dv.rect_cr), w = fh_mod(rem, rect, dv.rect_cr);
+    const int wq = fh_div(w, dv.rect_r);
+    const int t = rect * R + fh_mod(w, wq, dv.rect_r);
     if (gbi >= n_groups * batch || t >= tpx) return;
-    panel = uni(gbi * co_tiles + w / R);
-    ntile = uni((bid & 7) * tpx + t);
+    panel = gbi * co_tiles + wq;
+    ntile = (bid & 7) * tpx + t;
     if (ntile >= n_tiles) return;
   } else {
-    int run = (slot / run_len) * 8 + (bid & 7);
+    const int slot_run = fh_div(slot, dv.run_len);
+    int run = slot_run * 8 + (bid & 7);
     // Ragged launches (groups of different lengths, grid sized for the longest): only the runs that hold real tiles
     // are launched, listed heavy-first in run_map -- otherwise the empty runs of the short clips, which fall on
     // the same XCDs for every panel (run r of a panel -> XCD (panel * runs_per_panel + r) % 8), leave the real work
@@ -193,16 +199,17 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       run = uni(run_map[run]);
     }
     if (run >= total_runs) return;
-    panel = uni(run / runs_per_panel);
-    ntile = uni((run % runs_per_panel) * run_len + (slot % run_len));
+    panel = fh_div(run, dv.runs_per_panel);
+    ntile = fh_mod(run, panel, dv.runs_per_panel) * run_len + fh_mod(slot, slot_run, dv.run_len);
     if (ntile >= n_tiles) return;
   }
-  const int cot = uni(panel % co_tiles);
-  const int gb = uni(panel / co_tiles);
-  const int b = uni(gb % batch);
-  const fh_wino_group* __restrict__ G = groups + uni(gb / batch);
-  const int ph = uni(ntile % dil);            // phase of the decimated sequence
-  const int tb = uni(ntile / dil);            // 256-output block within the phase
+  const int gb = fh_div(panel, dv.co_tiles);
+  const int cot = fh_mod(panel, gb, dv.co_tiles);
+  const int gi = fh_div(gb, dv.batch);
+  const int b = fh_mod(gb, gi, dv.batch);
+  const fh_wino_group* __restrict__ G = groups + gi;
+  const int tb = fh_div(ntile, dv.dil);              // 256-output block within the phase
+  const int ph = fh_mod(ntile, tb, dv.dil);          // phase of the decimated sequence
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -217,7 +224,8 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   if (tb * (4 * W_BT) * dil + ph >= len) return;
 
   // phase-major tensors (pm): row = dil phases of lp samples, x[p + dil u] at p * lp + u
-  const int lp = ((len + dil - 1) / dil + 3) & ~3;
+  const int lq = fh_div(len, dv.dil), lr = fh_mod(len, lq, dv.dil);         // phase p of a row holds lq + (p < lr) samples
+  const int lp = (lq + (lr > 0) + 3) & ~3;
   const int pitch = pm ? dil * lp : len;             // floats per (batch, channel) row, inputs and outputs
 
   const int bo0 = kBtOff[xi][0], bo1 = kBtOff[xi][1], bo2 = kBtOff[xi][2], bo3 = kBtOff[xi][3];
@@ -294,7 +302,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
     const int ub = tb * (4 * W_BT) - S.center;
     const int ua = ub - (ub & 3);                                        // decimated index of slab sample 0
     const int q = vt + 96 * item;
-    const int nvalid = pm ? (len - ph + dil - 1) / dil : (S.xlen > 0 ? S.xlen : len);   // samples of this phase / row
+    const int nvalid = pm ? lq + (ph < lr) : (S.xlen > 0 ? S.xlen : len);               // samples of this phase / row
     if (ua + 4 * W_XQ > nvalid) {                                        // last block of the row: zero past the end
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -783,6 +791,10 @@ int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cou
   const long long blocks = xcd_ranges ? 8ll * n_groups * batch * co_tiles * fh_cdiv(tpx, rect_r) * rect_r
                                       : (long long)fh_cdiv(runs, 8) * 8 * run_len;
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino_f32: grid too large");
+  const WDivs dv = {fh_make_fastdiv((unsigned)run_len), fh_make_fastdiv((unsigned)fh_cdiv(n_tiles, run_len)),
+                    fh_make_fastdiv((unsigned)co_tiles), fh_make_fastdiv((unsigned)batch), fh_make_fastdiv((unsigned)dilation),
+                    fh_make_fastdiv((unsigned)rect_r), fh_make_fastdiv((unsigned)(co_tiles * rect_r)),
+                    fh_make_fastdiv((unsigned)(co_tiles * fh_cdiv(tpx, rect_r) * rect_r))};
   // > 64 KB of dynamic LDS needs the attribute once per DEVICE (a kernel has one function object per device, and
   // a process may hold models on several): one flag per device ordinal and template instance.
   static std::atomic<bool> lds_opt_in[FH_MAX_DEVICES];
@@ -802,7 +814,7 @@ int launch_wino_vl(const fh_wino_group* groups, int n_groups, int batch, int cou
   }
   hipLaunchKernelGGL((conv_wino_kernel<MT, NT, SUBS, VL, BF>), dim3((unsigned)blocks), dim3(W_THREADS), Cfg::LDS_FLOATS * 4,
                      stream, groups, n_groups, batch, co_tiles, n_tiles, run_len, dilation, phase_major, run_map, n_runs,
-                     xcd_ranges ? 1 : 0);
+                     xcd_ranges ? 1 : 0, dv);
   FH_CHECK_LAUNCH("fh_conv_wino_f32");
   return FH_OK;
 }

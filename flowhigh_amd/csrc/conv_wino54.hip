@@ -67,12 +67,29 @@ __host__ __device__ inline int v_tile_slots(int len, int dil) { return (((len + 
 
 // Rows of B^T for the points 0, 1, -1, 2, -2, 1/2, -1/2, inf (tests/tools/winograd_numerics.py: toom_cook(5, 4, ...)):
 //   v = x[off[5]];  v = fma(coef[j], x[off[j]], v)  for j = 0 .. 4        (coef 0: the slot repeats a real sample)
-__device__ const int kB8Off[8][6] = {{2, 4, 0, 0, 0, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6},
-                                     {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 3, 5, 1, 1, 7}};
+constexpr int kB8Off[8][6] = {{2, 4, 0, 0, 0, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6},
+                              {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 2, 3, 4, 5, 6}, {1, 3, 5, 1, 1, 7}};
 __device__ const float kB8Coef[8][5] = {{5.25f, -5.25f, -1.f, 0.f, 0.f},      {1.f, 1.f, -4.25f, -4.25f, 1.f},
                                         {-1.f, 1.f, 4.25f, -4.25f, -1.f},     {0.5f, 0.25f, -2.5f, -1.25f, 2.f},
                                         {-0.5f, 0.25f, 2.5f, -1.25f, -2.f},   {2.f, 4.f, -2.5f, -5.f, 0.5f},
                                         {-2.f, 4.f, 2.5f, -5.f, -0.5f},       {-1.f, 5.25f, -5.25f, 0.f, 0.f}};
+
+// LDS float offsets of the 6 samples of tap group g relative to a lane's base, [point][g][j]: sample c = 4 g + kB8Off[point][j]
+// lies in plane c % 5 at index c / 5 (made here: from the run-time point they were ~200 scalar instructions per wave and block)
+struct VToff {
+  int v[8][3][6];
+};
+constexpr VToff make_vtoff() {
+  VToff t = {};
+  for (int x = 0; x < 8; ++x)
+    for (int g = 0; g < 3; ++g)
+      for (int j = 0; j < 6; ++j) {
+        const int c = 4 * g + kB8Off[x][j];
+        t.v[x][g][j] = (c % 5) * V_PP + (c / 5) * 2;
+      }
+  return t;
+}
+__device__ const VToff kB8Toff = make_vtoff();
 
 struct VSeg {
   const float* x;
@@ -92,35 +109,43 @@ __device__ __forceinline__ VSeg load_vseg(const fh_wino_seg* S) {
 // VL: rows are contiguous and 16-byte aligned (phase-major tensors, or dilation 1 and len % 4 == 0): the slab is fetched
 // with 16-byte loads and the outputs leave as 16-byte vectors; else 4-byte accesses (any length, any dilation in the
 // plain layout).  Same arithmetic either way.
+// launch constants the block -> work mapping divides by (fh_common.h: fh_fastdiv)
+struct VDivs {
+  fh_fastdiv run_len, runs_per_panel, co_tiles, batch, dil;
+};
+
 template <int MT, bool VL>
 __global__ __attribute__((amdgpu_flat_work_group_size(V_THREADS, V_THREADS), amdgpu_waves_per_eu(2, 2)))
 void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles, int n_tiles,
-                        int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs) {
+                        int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs, VDivs dv) {
   constexpr int BM = 32 * MT;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // V_LDS_FLOATS
 
   // ---- block -> (panel, n block): panels = (group, batch, co tile), heavy groups first (conv_wino.hip) ----------
   const int panels = n_groups * batch * co_tiles;
-  const int runs_per_panel = (n_tiles + run_len - 1) / run_len;
+  const int runs_per_panel = (int)dv.runs_per_panel.d;
   const int total_runs = panels * runs_per_panel;
   const int bid = blockIdx.x;
   const int slot = bid >> 3;
-  int run = (slot / run_len) * 8 + (bid & 7);
+  const int slot_run = fh_div(slot, dv.run_len);
+  int run = slot_run * 8 + (bid & 7);
   if (run_map) {
     if (run >= n_runs) return;
     run = uni(run_map[run]);
   }
   if (run >= total_runs) return;
-  const int panel = uni(run / runs_per_panel);
-  const int ntile = uni((run % runs_per_panel) * run_len + (slot % run_len));
+  const int panel = fh_div(run, dv.runs_per_panel);
+  const int ntile = fh_mod(run, panel, dv.runs_per_panel) * run_len + fh_mod(slot, slot_run, dv.run_len);
   if (ntile >= n_tiles) return;
-  const int cot = uni(panel % co_tiles);
-  const int gb = uni(panel / co_tiles);
-  const int b = uni(gb % batch);
-  const fh_wino_group* __restrict__ G = groups + uni(gb / batch);
+  const int gb = fh_div(panel, dv.co_tiles);
+  const int cot = fh_mod(panel, gb, dv.co_tiles);
+  const int gi = fh_div(gb, dv.batch);
+  const int b = fh_mod(gb, gi, dv.batch);
+  const fh_wino_group* __restrict__ G = groups + gi;
   const bool cat = pm != 0;                   // phase-major rows: tiled in the concatenated position space (above)
-  const int ph = cat ? 0 : uni(ntile % dil);  // plain layout: phase of the decimated sequence ...
-  const int tb = cat ? ntile : uni(ntile / dil);        // ... and 320-output block within it
+  const int ntile_d = cat ? 0 : fh_div(ntile, dv.dil);
+  const int ph = cat ? 0 : fh_mod(ntile, ntile_d, dv.dil);      // plain layout: phase of the decimated sequence ...
+  const int tb = cat ? ntile : ntile_d;                          // ... and 320-output block within it
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -128,46 +153,47 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   const int l31 = lane & 31, lh = lane >> 5;
   const int co0 = cot * BM;
   const int len = uni(G->len), cout_pad = uni(G->cout_pad), nseg = uni(G->nseg);
-  const int ps = 5 * v_tile_slots(len, dil);         // (cat) positions per phase
+  // len = lq dil + lr: phase p of a row holds lq + (p < lr) samples
+  const int lq = fh_div(len, dv.dil), lr = fh_mod(len, lq, dv.dil);
+  const int lmax = lq + (lr > 0);                    // samples of phase 0 = ceil(len / dil)
+  const int ps = 5 * (((lmax + 4) / 5 + 3 + 3) & ~3);            // (cat) positions per phase = 5 v_tile_slots(len, dil)
   if (cat ? tb * V_OUT >= dil * ps : tb * V_OUT * dil + ph >= len) return;
 
   // phase-major tensors (pm): row = dil phases of lp samples, x[p + dil u] at p * lp + u
-  const int lp = ((len + dil - 1) / dil + 3) & ~3;
+  const int lp = (lmax + 3) & ~3;
   const int pitch = pm ? dil * lp : len;             // floats per (batch, channel) row, inputs and outputs
-  const int nvalid = (len - ph + dil - 1) / dil;                 // (plain layout) real decimated samples of this block's phase
+  const int nvalid = lq + (ph < lr);                 // (plain layout) real decimated samples of this block's phase
   // aligned position P (a multiple of 4; cat: concatenated space, else decimated index of the plain row at dilation 1) ->
-  // float offset of its quad inside a (batch, channel) row, or -1 outside the tensor; nv = real samples from P on in its row
+  // float offset of its quad inside a (batch, channel) row, or -1 outside the tensor; nv = real samples from P on in its row.
+  // (P / ps per lane: ps is a per-group value, so no host-made multiplier; P < 2^24 is exact in fp32, the product with the
+  // rounded reciprocal is within 1 of the quotient, and one step either way corrects it: 12 vector instructions against
+  // the ~30 of the generic division, 5 calls per lane and epilogue round)
+  const float ps_inv = __builtin_amdgcn_rcpf((float)ps);
   auto locate = [&](int P, int& nv) -> int {
     if (cat) {
-      const int p = P >= 0 ? P / ps : dil;
-      const int u = P - p * ps;
-      nv = p < dil ? (len - p + dil - 1) / dil - u : 0;
+      int p = P >= 0 ? (int)((float)P * ps_inv) : dil;
+      int u = P - p * ps;
+      if (P >= 0 && u < 0) { --p; u += ps; }
+      if (P >= 0 && u >= ps) { ++p; u -= ps; }
+      nv = p < dil ? lq + (p < lr) - u : 0;
       return (p < dil && u < lp) ? p * lp + u : -1;
     }
     nv = len - P;
     return (P >= 0 && P < len) ? P : -1;
   };
 
-  // this wave's row of B^T: sample slots and coefficients, wave-uniform
-  int boff[6];
+  // this wave's row of B^T: coefficients and sample slots, wave-uniform
   f32x2 bco[5];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) boff[j] = uni(kB8Off[xi][j]);
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const float c = __uint_as_float(uni((int)__float_as_uint(kB8Coef[xi][j])));
     bco[j] = (f32x2){c, c};
   }
-  // LDS float offsets of the 6 samples of tap group g relative to the lane's base: sample c = 4 g + off -> plane c % 5,
-  // index tile + c / 5
   int toff[3][6];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int c = 4 * g + boff[j];
-      toff[g][j] = (c % 5) * V_PP + (c / 5) * 2;
-    }
+    for (int j = 0; j < 6; ++j) toff[g][j] = uni(kB8Toff.v[xi][g][j]);
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -391,6 +417,17 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   float* const Y = lds;                               // [column nt][row 32][160 outputs, pitch V_YP]: in the slab space
   const int ent = tid >> 8, erq = (tid >> 5) & 7, ecol = tid & 31;        // A^T item: column, row quad, tile
   const int v_first = tb * V_OUT;                     // position of the block's first output
+  // store items of this thread: 5 of the 1280 float4 of its column's 32 x 160 sub-tile, the same 5 in every round:
+  // where their vectors lie in a row is found once
+  int srow[5], scol[5], ioff[5], inv[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int item = (tid & 255) + 256 * i;
+    srow[i] = item / 40;
+    scol[i] = (item % 40) * 4;
+    const int v0 = v_first + ent * 160 + scol[i];                         // position of the vector's first output
+    ioff[i] = VL ? locate(v0, inv[i]) : (inv[i] = nvalid - v0, v0);
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     // (no barrier here: E is not the slab, and the readers of the previous round's E are past that round's second barrier)
@@ -424,22 +461,16 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
 #pragma unroll
         for (int q = 0; q < 5; ++q) yw[i * V_YP + q] = y[q][i];
     }
-    // store items of this thread: 5 of the 1280 float4 of its column's 32 x 160 sub-tile; first residual requested
-    // in front of the barrier (the A^T registers are dead).  (Requested a whole round ahead -- behind the previous round's
+    // first residual requested in front of the barrier (the A^T registers are dead).  (Requested a whole round ahead -- behind the previous round's
     // exchange writes, two register sets -- the conv launches of a step took 13.50-13.58 ms against 13.45-13.47 ms, same box.)
     u32x4 rpre[5];
     unsigned soff[5];
-    int srow[5], scol[5], nreal[5];
+    int nreal[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      const int item = (tid & 255) + 256 * i;
-      srow[i] = item / 40;
-      scol[i] = (item % 40) * 4;
       const int co = co0 + mt * 32 + srow[i];
-      const int v0 = v_first + ent * 160 + scol[i];                       // position of the vector's first output
-      int nv;
-      const int off = VL ? locate(v0, nv) : (nv = nvalid - v0, v0);
-      nreal[i] = (co < cout && off >= 0) ? nv : 0;                        // real outputs from v0 on (<= 0: none)
+      const int off = ioff[i];
+      nreal[i] = (co < cout && off >= 0) ? inv[i] : 0;                    // real outputs from v0 on (<= 0: none)
       soff[i] = ((unsigned)co * (unsigned)pitch + (unsigned)(off >= 0 ? off : 0)) * 4u;
       if (VL && nres > 0)
         rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, nreal[i] >= 4 ? soff[i] : 0x80000000u, 0, 0);
@@ -506,6 +537,8 @@ int launch_wino54(const fh_wino_group* groups, int n_groups, int batch, int cout
   const long long runs = run_map ? (long long)n_runs : panels * fh_cdiv(n_tiles, run_len);
   const long long blocks = (long long)fh_cdiv(runs, 8) * 8 * run_len;
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_wino54_f32: grid too large");
+  const VDivs dv = {fh_make_fastdiv((unsigned)run_len), fh_make_fastdiv((unsigned)fh_cdiv(n_tiles, run_len)),
+                    fh_make_fastdiv((unsigned)co_tiles), fh_make_fastdiv((unsigned)batch), fh_make_fastdiv((unsigned)dilation)};
   static std::atomic<bool> lds_opt_in[FH_MAX_DEVICES];      // (> 64 KB of dynamic LDS: once per device, conv_wino.hip)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) {
@@ -522,7 +555,7 @@ int launch_wino54(const fh_wino_group* groups, int n_groups, int batch, int cout
     lds_opt_in[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((conv_wino54_kernel<MT, VL>), dim3((unsigned)blocks), dim3(V_THREADS), V_LDS_FLOATS * 4, stream, groups,
-                     n_groups, batch, co_tiles, n_tiles, run_len, dilation, pm, run_map, n_runs);
+                     n_groups, batch, co_tiles, n_tiles, run_len, dilation, pm, run_map, n_runs, dv);
   FH_CHECK_LAUNCH("fh_conv_wino54_f32");
   return FH_OK;
 }
@@ -540,6 +573,8 @@ int wino54_dispatch(const fh_wino_group* groups, int n_groups, int batch, int co
   // some group's rows are not 16-byte aligned; `len` is then only the longest group's length)
   // (phase-major rows are always aligned: bit 1 is about plain rows)
   const bool vl = pm || (dilation == 1 && len % 4 == 0 && !(layout_flags & 2));
+  // (the kernel finds a position's phase through fp32: positions, < len + 40 dilation, must be exact there)
+  FH_CHECK_ARG(len < (1 << 24) - 4096, "fh_conv_wino54_f32: rows of %d samples: at most %d", len, (1 << 24) - 4097);
 #define FH_W54_CASE(id, MT)                                                                                         \
   case id:                                                                                                          \
     return vl ? launch_wino54<MT, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs)  \

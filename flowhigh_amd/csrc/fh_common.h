@@ -51,6 +51,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 static inline int fh_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Division of a wave-uniform 0 <= n < 2^31 by a launch constant d >= 1 without the ~30-instruction expansion of a run-time
+// integer division: the launcher makes (mul, shift) once on the host, the kernel takes floor(n / d) = (mulhi(mul, n) + n) >> shift
+// (3 scalar instructions; Granlund-Montgomery round-up form: mul = floor(2^32 (2^shift - d) / d) + 1, shift = ceil(log2 d)).
+// The block -> work mappings of the conv kernels are 8-12 such divisions per block, on the scalar unit all waves of a CU share.
+struct fh_fastdiv {
+  unsigned mul, shift, d;
+};
+static inline fh_fastdiv fh_make_fastdiv(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  return {(unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1), l, d};
+}
+__device__ __forceinline__ int fh_div(int n, const fh_fastdiv& f) {
+  return (int)((__umulhi(f.mul, (unsigned)n) + (unsigned)n) >> f.shift);
+}
+__device__ __forceinline__ int fh_mod(int n, int q, const fh_fastdiv& f) { return n - q * (int)f.d; }      // q = fh_div(n, f)
+
 // 64-lane butterfly reductions (wave = 64 on gfx950).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
