@@ -124,15 +124,36 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   u32x4 wregA[WREG], wregB[WREG];
   unsigned xreg[XROWS][XREG];
 
-  // ---- loaders (all addresses wave-uniform base + per-lane 32-bit offset) -------------------
-  auto load_w = [&](u32x4 (&wreg)[WREG], const SegU& S, int chunk, int tap) {
-    const float* wp = uni(S.w + ((size_t)(chunk * S.ntaps + tap) * cout_pad + co0) * CK);
-    __amdgpu_buffer_rsrc_t r = make_rsrc(wp, BM * CK * 4);
+  // ---- cursors ------------------------------------------------------------------------------------
+  // Steps run over (segment, chunk, tap) in that order; three cursors walk them, each with a few scalar adds per step
+  // (rebuilding every address from (segment, chunk, tap) cost 50-100 scalar instructions per 16-MFMA step):
+  //   K  the step that computes: its tap (LDS shift), whether it is a chunk's first / last tap;
+  //   W  the step whose weight tile is requested next (two ahead): the tiles of a segment are contiguous in step order,
+  //      [ci/CK][tap][cout_pad][CK], so one descriptor per segment and a scalar byte offset that grows by one tile row
+  //      block (cout_pad CK floats) per step;
+  //   X  the chunk whose slab is requested next (one ahead): pointer to this wave's first row of it.
+  // A segment's fields are read when a cursor enters it.
+  struct Cur { int s, j, nt, cl; };          // segment, tap, taps per chunk, chunks left in the segment (this one included)
+  Cur K = {0, 0, uni(G->seg[0].ntaps), uni(G->seg[0].cin) / CK};
+  const unsigned wstep = (unsigned)cout_pad * CK * 4u;
+  int w_seg = -1, w_left = 0;
+  unsigned w_soff = 0;
+  __amdgpu_buffer_rsrc_t w_r = make_rsrc(nullptr, 0);
+  auto w_enter = [&]() {                       // W cursor: first step of the next segment
+    ++w_seg;
+    const fh_conv_seg* sg = &G->seg[w_seg < nseg ? w_seg : nseg - 1];
+    w_left = w_seg < nseg ? (uni(sg->cin) / CK) * uni(sg->ntaps) : 0x7fffffff;
+    w_r = make_rsrc(uni(sg->w) + (size_t)co0 * CK, w_seg < nseg ? (unsigned)w_left * wstep - (unsigned)co0 * CK * 4u : 0u);
+    w_soff = 0;
+  };
+  unsigned wvoff[WREG];                        // lanes beyond the tile request nothing (out-of-range offset, never stored)
 #pragma unroll
-    for (int i = 0; i < WREG; ++i) {
-      const int f = tid + 256 * i;            // beyond the tile: out of range -> 0, never stored
-      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(r, f * 16, 0, 0);
-    }
+  for (int i = 0; i < WREG; ++i) wvoff[i] = tid + 256 * i < Cfg::WF4 ? (unsigned)(tid + 256 * i) * 16u : 0x80000000u;
+  auto load_w = [&](u32x4 (&wreg)[WREG]) {     // the W cursor's tile, then on to the next step
+#pragma unroll
+    for (int i = 0; i < WREG; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(w_r, wvoff[i], w_soff, 0);
+    w_soff += wstep;
+    if (--w_left == 0) w_enter();
   };
   auto store_w = [&](const u32x4 (&wreg)[WREG], int buf) {
     float* dst = ws + buf * BM * WP;
@@ -142,16 +163,26 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
       if (f < Cfg::WF4) *reinterpret_cast<u32x4*>(dst + (f / (CK / 4)) * WP + 4 * (f % (CK / 4))) = wreg[i];
     }
   };
-  auto load_x = [&](const SegU& S, int chunk) {
-    const int t0 = n0 + S.off_min;
+  int x_seg = -1, x_left = 0, x_t0 = 0;
+  const float* x_row = nullptr;                // first row of the X cursor's chunk that this wave stages
+  auto x_enter = [&]() {
+    ++x_seg;
+    const fh_conv_seg* sg = &G->seg[x_seg < nseg ? x_seg : nseg - 1];
+    const int cin = uni(sg->cin);
+    x_left = x_seg < nseg ? cin / CK : 0x7fffffff;
+    x_row = uni(sg->x) + ((size_t)b * cin + wave * XROWS) * lin;
+    x_t0 = n0 + uni(sg->off_min);
+  };
+  auto load_x = [&]() {                        // the X cursor's chunk, then on to the next one
 #pragma unroll
     for (int rr = 0; rr < XROWS; ++rr) {
-      const float* xp = uni(S.x + ((size_t)b * S.cin + chunk * CK + wave * XROWS + rr) * lin);
-      __amdgpu_buffer_rsrc_t r = make_rsrc(xp, (unsigned)lin * 4u);
+      __amdgpu_buffer_rsrc_t r = make_rsrc(x_row + (size_t)rr * lin, (unsigned)lin * 4u);
 #pragma unroll
       for (int i = 0; i < XREG; ++i)   // t < 0 wraps to a huge unsigned offset: out of range -> 0
-        xreg[rr][i] = __builtin_amdgcn_raw_buffer_load_b32(r, (t0 + lane + 64 * i) * 4, 0, 0);
+        xreg[rr][i] = __builtin_amdgcn_raw_buffer_load_b32(r, (x_t0 + lane + 64 * i) * 4, 0, 0);
     }
+    x_row += (size_t)CK * lin;
+    if (--x_left == 0) x_enter();
   };
   auto store_x = [&](int buf) {
 #pragma unroll
@@ -165,31 +196,13 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
     }
   };
 
-  // ---- scalar step cursors: (segment, chunk, tap) of steps it, it+1, it+2 -----------------------
-  struct Cur { int s, c, j; };
-  auto advance = [&](Cur& k, SegU& S) {
-    if (++k.j == S.ntaps) {
-      k.j = 0;
-      if (++k.c * CK == S.cin) {
-        k.c = 0;
-        if (++k.s < nseg) S = load_seg(&G->seg[k.s]);
-      }
-    }
-  };
-
   // ---- prologue ----------------------------------------------------------------------------
-  Cur k0 = {0, 0, 0};
-  SegU S0 = load_seg(&G->seg[0]);
   int wbuf = 0, xbuf = 0;
-  load_w(wregA, S0, 0, 0);
-  load_x(S0, 0);
-  Cur k1 = k0;
-  SegU S1 = S0;
-  advance(k1, S1);
-  if (nsteps > 1) load_w(wregB, S1, k1.c, k1.j);       // tile of step 1, stored at the end of step 0
-  Cur k2 = k1;
-  SegU S2 = S1;
-  advance(k2, S2);
+  w_enter();
+  x_enter();
+  load_w(wregA);
+  load_x();
+  if (nsteps > 1) load_w(wregB);                       // tile of step 1, stored at the end of step 0
   store_w(wregA, 0);
   store_x(0);
   __syncthreads();
@@ -202,9 +215,12 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   int xoff_cur = toff[0];
   auto step = [&](int it, u32x4 (&LOAD)[WREG], const u32x4 (&STORE)[WREG]) {
     constexpr int KS = 4 * KQ;
-    const bool last_tap = k0.j == S0.ntaps - 1;
-    const bool more_chunks = (k0.c + 1) * CK < S0.cin || k0.s + 1 < nseg;
+    const bool last_tap = K.j == K.nt - 1;
+    const bool more_chunks = K.cl > 1 || K.s + 1 < nseg;
     const bool flip_x = last_tap && more_chunks;
+    // (segment, tap) of the next step, for its LDS shift
+    const int j1 = last_tap ? 0 : K.j + 1;
+    const int s1 = (last_tap && K.cl == 1 && K.s + 1 < nseg) ? K.s + 1 : K.s;
     const float* wsb = ws + wbuf * BM * WP;
     const float* xsb = xs + xbuf * CK * XW + xoff_cur + wn * NT * 32 + l31 + 4 * lh * XW;
     f32x4 a[KQ][MT];
@@ -225,21 +241,14 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
         for (int nt = 0; nt < NT; ++nt) bf[(ks + 1) & 1][nt] = xsb[(8 * q1 + e1) * XW + nt * 32];
       }
       if (ks == 1) {                              // global prefetch
-        if (it + 2 < nsteps) load_w(LOAD, S2, k2.c, k2.j);
-        if (k0.j == 0 && more_chunks) {           // slab of the next chunk, stored after its last tap
-          if ((k0.c + 1) * CK < S0.cin) {
-            load_x(S0, k0.c + 1);
-          } else {
-            const SegU Sn = load_seg(&G->seg[k0.s + 1]);
-            load_x(Sn, 0);
-          }
-        }
+        if (it + 2 < nsteps) load_w(LOAD);
+        if (K.j == 0 && more_chunks) load_x();    // slab of the next chunk, stored after this chunk's last tap
       }
       if (ks == KS / 2) {                         // LDS stores of the tiles of step it+1
         if (it + 1 < nsteps) store_w(STORE, wbuf ^ 1);
         if (flip_x) store_x(xbuf ^ 1);
       }
-      if (ks == KS - 2) xoff_next = toff[k1.s * FH_CONV_MAX_TAPS + k1.j];
+      if (ks == KS - 2) xoff_next = toff[s1 * FH_CONV_MAX_TAPS + j1];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -253,11 +262,16 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
     wbuf ^= 1;
     if (flip_x) xbuf ^= 1;
     xoff_cur = xoff_next;
-    k0 = k1;
-    S0 = S1;
-    k1 = k2;
-    S1 = S2;
-    advance(k2, S2);
+    if (last_tap) {
+      K.j = 0;
+      if (--K.cl == 0 && K.s + 1 < nseg) {
+        ++K.s;
+        K.nt = uni(G->seg[K.s].ntaps);
+        K.cl = uni(G->seg[K.s].cin) / CK;
+      }
+    } else {
+      ++K.j;
+    }
   };
 
   for (int it = 0; it < nsteps; it += 2) {
