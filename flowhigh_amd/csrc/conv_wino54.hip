@@ -153,6 +153,12 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   const int l31 = lane & 31, lh = lane >> 5;
   const int co0 = cot * BM;
   const int len = uni(G->len), cout_pad = uni(G->cout_pad), nseg = uni(G->nseg);
+  // (the epilogue's fields too: read there, they are a scalar-cache miss -- ~1 us -- with every wave of the CU waiting)
+  const int nres = uni(G->nres), cout = uni(G->cout);
+  const float scale = G->scale;
+  const float* __restrict__ const bias = uni(G->bias);
+  const float* const outp = uni((const float*)G->out);
+  const float* const resp[3] = {uni(G->res[0]), uni(G->res[1]), uni(G->res[2])};
   // len = lq dil + lr: phase p of a row holds lq + (p < lr) samples
   const int lq = fh_div(len, dv.dil), lr = fh_mod(len, lq, dv.dil);
   const int lmax = lq + (lr > 0);                    // samples of phase 0 = ceil(len / dil)
@@ -402,16 +408,12 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   run_all(std::integral_constant<int, 1>{});
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
-  const int nres = uni(G->nres);
-  const float scale = G->scale;
-  const int cout = uni(G->cout);
-  const float* __restrict__ bias = uni(G->bias);
   const size_t oslab = (size_t)b * cout * pitch;
   const unsigned slab_bytes = (unsigned)cout * (unsigned)pitch * 4u;
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc(uni((const float*)G->out) + oslab, slab_bytes);
-  const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? uni(G->res[0]) + oslab : nullptr, nres > 0 ? slab_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? uni(G->res[1]) + oslab : nullptr, nres > 1 ? slab_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? uni(G->res[2]) + oslab : nullptr, nres > 2 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(outp + oslab, slab_bytes);
+  const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? resp[0] + oslab : nullptr, nres > 0 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? resp[1] + oslab : nullptr, nres > 1 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? resp[2] + oslab : nullptr, nres > 2 ? slab_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (unsigned)cout * 4u : 0u);
   float* const E = lds + 2 * V_BUF;                   // [column nt][xi][tile col 32][row, pitch V_EP]: behind the slab buffers
   float* const Y = lds;                               // [column nt][row 32][160 outputs, pitch V_YP]: in the slab space
@@ -428,6 +430,39 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
     const int v0 = v_first + ent * 160 + scol[i];                         // position of the vector's first output
     ioff[i] = VL ? locate(v0, inv[i]) : (inv[i] = nvalid - v0, v0);
   }
+  // Requests of the store phases: the bias of every round's items now (the K loop's registers are free; a load in a round is
+  // an HBM round trip the round waits out), the first residual of a round's items one round ahead -- round 0's here,
+  // round r + 1's in front of round r's stores, two register sets: vmcnt counts loads and stores in order, so a load
+  // requested BEHIND a round's stores is not there before those stores are acknowledged.
+  // (the 128-row tile has no registers for the second set: its residual is requested in the round that adds it)
+  constexpr bool AHEAD = MT < 4;
+  float bvall[MT][5];
+  u32x4 rpre[AHEAD ? 2 : 1][5];
+  auto item_geom = [&](int mt, int i, int& nreal, unsigned& soff) {
+    const int co = co0 + mt * 32 + srow[i];
+    nreal = (co < cout && ioff[i] >= 0) ? inv[i] : 0;                     // real outputs from the vector's first on (<= 0: none)
+    soff = ((unsigned)co * (unsigned)pitch + (unsigned)(ioff[i] >= 0 ? ioff[i] : 0)) * 4u;
+    return co;
+  };
+  auto request_res = [&](int mt, u32x4 (&rp)[5]) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int nreal;
+      unsigned soff;
+      item_geom(mt, i, nreal, soff);
+      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, nreal >= 4 ? soff : 0x80000000u, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int nreal;
+      unsigned soff;
+      const int co = item_geom(mt, i, nreal, soff);
+      bvall[mt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, nreal > 0 ? (unsigned)co * 4u : 0x80000000u, 0, 0));
+    }
+  if (AHEAD && VL && nres > 0) request_res(0, rpre[0]);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     // (no barrier here: E is not the slab, and the readers of the previous round's E are past that round's second barrier)
@@ -461,57 +496,86 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
 #pragma unroll
         for (int q = 0; q < 5; ++q) yw[i * V_YP + q] = y[q][i];
     }
-    // first residual requested in front of the barrier (the A^T registers are dead).  (Requested a whole round ahead -- behind the previous round's
-    // exchange writes, two register sets -- the conv launches of a step took 13.50-13.58 ms against 13.45-13.47 ms, same box.)
-    u32x4 rpre[5];
+    // Store phase.  Every global access below is an unconditional buffer operation (nothing to do = out-of-range offset)
+    // in straight-line code.  (With the bias load and a per-lane "whole vector?" branch inside the item loop the compiler put
+    // s_waitcnt vmcnt(0) behind every item's loads: each of the 15 items of a block waited for its load AND for the write
+    // acknowledge of the item before it: tools/exp/w54_fixed_cost.py.)
+    const float (&bv)[5] = bvall[mt];
     unsigned soff[5];
     int nreal[5];
+    bool vec = VL;                                      // every item of this lane is a whole vector, or nothing
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      const int co = co0 + mt * 32 + srow[i];
-      const int off = ioff[i];
-      nreal[i] = (co < cout && off >= 0) ? inv[i] : 0;                    // real outputs from v0 on (<= 0: none)
-      soff[i] = ((unsigned)co * (unsigned)pitch + (unsigned)(off >= 0 ? off : 0)) * 4u;
-      if (VL && nres > 0)
-        rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, nreal[i] >= 4 ? soff[i] : 0x80000000u, 0, 0);
+      item_geom(mt, i, nreal[i], soff[i]);
+      vec = vec && (nreal[i] >= 4 || nreal[i] <= 0);
     }
+    if (VL && nres > 0 && (AHEAD ? mt + 1 < MT : true)) request_res(AHEAD ? mt + 1 : mt, rpre[AHEAD ? (mt + 1) & 1 : 0]);
+    const u32x4 (&rp)[5] = rpre[AHEAD ? mt & 1 : 0];
+    // one path per WAVE: whole vectors everywhere (all blocks but a row's last, when rows are 16-byte aligned), or 4-byte accesses
+    const bool wave_vec = VL && __builtin_amdgcn_ballot_w64(!vec) == 0ull;
     __syncthreads();
+    f32x4 yv[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(Y + (ent * 32 + srow[i]) * V_YP + scol[i]);
-      const int co = co0 + mt * 32 + srow[i];
-      const float bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, nreal[i] > 0 ? (unsigned)co * 4u : 0x80000000u, 0, 0));
-      if (VL && nreal[i] >= 4) {
-        f32x4 o = {yv[0] + bv, yv[1] + bv, yv[2] + bv, yv[3] + bv};
-        if (nres > 0) {
-          u32x4 t = rpre[i];
-          f32x4 rs = {__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
-          if (nres > 1) {
-            t = __builtin_amdgcn_raw_buffer_load_b128(rr1, soff[i], 0, 0);
-            rs += (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
-          }
-          if (nres > 2) {
-            t = __builtin_amdgcn_raw_buffer_load_b128(rr2, soff[i], 0, 0);
-            rs += (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
-          }
-          o += rs;
+    for (int i = 0; i < 5; ++i) yv[i] = *reinterpret_cast<const f32x4*>(Y + (ent * 32 + srow[i]) * V_YP + scol[i]);
+    if (wave_vec) {
+      f32x4 rs[5];
+      if (nres > 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+          rs[i] = (f32x4){__uint_as_float(rp[i][0]), __uint_as_float(rp[i][1]), __uint_as_float(rp[i][2]), __uint_as_float(rp[i][3])};
+        if (nres > 1) {
+          u32x4 t[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rr1, nreal[i] >= 4 ? soff[i] : 0x80000000u, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            rs[i] += (f32x4){__uint_as_float(t[i][0]), __uint_as_float(t[i][1]), __uint_as_float(t[i][2]), __uint_as_float(t[i][3])};
         }
+        if (nres > 2) {
+          u32x4 t[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rr2, nreal[i] >= 4 ? soff[i] : 0x80000000u, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            rs[i] += (f32x4){__uint_as_float(t[i][0]), __uint_as_float(t[i][1]), __uint_as_float(t[i][2]), __uint_as_float(t[i][3])};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        f32x4 o = {yv[i][0] + bv[i], yv[i][1] + bv[i], yv[i][2] + bv[i], yv[i][3] + bv[i]};
+        if (nres > 0) o += rs[i];
         o *= scale;
         const u32x4 ou = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(ou, ro, soff[i], 0, 0);
-      } else if (nreal[i] > 0) {                        // the row ends inside this vector, or rows are not 16-byte aligned
+        __builtin_amdgcn_raw_buffer_store_b128(ou, ro, nreal[i] >= 4 ? soff[i] : 0x80000000u, 0, 0);
+      }
+    } else {                                            // a row ends inside this wave's vectors, or rows are not 16-byte aligned
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        unsigned off[4];
+        float rs[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           // (plain layout with a dilation: output v sits at ph + dil v of the row)
-          const unsigned off = q < nreal[i] ? (pm || dil == 1 ? soff[i] + 4u * q : soff[i] + 4u * (unsigned)(ph + (dil - 1) * (v_first + ent * 160 + scol[i]) + dil * q)) : 0x80000000u;
-          float o = yv[q] + bv;
-          if (nres > 0) {
-            float rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));
-            if (nres > 1) rs += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off, 0, 0));
-            if (nres > 2) rs += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off, 0, 0));
-            o += rs;
+          off[q] = q < nreal[i] ? (pm || dil == 1 ? soff[i] + 4u * q : soff[i] + 4u * (unsigned)(ph + (dil - 1) * (v_first + ent * 160 + scol[i]) + dil * q)) : 0x80000000u;
+          rs[q] = 0.f;
+        }
+        if (nres > 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off[q], 0, 0));
+          if (nres > 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rs[q] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off[q], 0, 0));
           }
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o * scale), ro, off, 0, 0);
+          if (nres > 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rs[q] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off[q], 0, 0));
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float o = yv[i][q] + bv[i];
+          if (nres > 0) o += rs[q];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o * scale), ro, off[q], 0, 0);
         }
       }
     }
