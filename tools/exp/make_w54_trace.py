@@ -15,7 +15,11 @@ def sub(old, new):
 sub('#include "fh_common.h"', '#include "fh_common.h"\n__device__ unsigned long long* g_w54_trace = nullptr;\n'
     '#define TR(k) do { if (g_w54_trace && threadIdx.x == 0) g_w54_trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)\n'
     'extern "C" int fh_w54_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_w54_trace), &p, sizeof(p)); }')
-sub("  const int tid = threadIdx.x;\n", "  const int tid = threadIdx.x;\n  TR(0);\n")
+sub("  const int tid = threadIdx.x;\n", "  const int tid = threadIdx.x;\n  TR(0);\n"
+    "  if (g_w54_trace && threadIdx.x == 0) {\n    unsigned hw, xcc;\n"
+    "    asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw));\n"
+    "    asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n"
+    "    g_w54_trace[(size_t)blockIdx.x * 16 + 11] = ((unsigned long long)xcc << 32) | hw;\n  }\n")
 sub("    setup_seg(S);\n", "    setup_seg(S);\n    TR(1);\n")
 sub("    store_x(xbuf);\n    __syncthreads();\n", "    TR(2);\n    store_x(xbuf);\n    __syncthreads();\n    TR(3);\n")
 sub("  // ---- epilogue ---", "  TR(4);\n  // ---- epilogue ---")
