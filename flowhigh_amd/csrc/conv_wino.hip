@@ -647,16 +647,19 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
         const f32x4 y1 = __builtin_elementwise_fma((f32x4)(2.f), d34, d12);
         const f32x4 y2 = __builtin_elementwise_fma((f32x4)(4.f), s34, s12);
         const f32x4 y3 = __builtin_elementwise_fma((f32x4)(8.f), d34, d12) + m5;
+        // One store path per WAVE, every access an unconditional buffer operation (nothing to do = out-of-range offset):
+        // with a per-lane "whole vector?" branch around them the compiler's s_waitcnt in front of each residual use let
+        // only 2-3 operations stay in flight, and vmcnt counts loads and stores in order -- every sub-tile then waited
+        // for the write acknowledge of the one before it (conv_wino54.hip, tools/exp/w54_fixed_cost.py).
+        const float y[4][4] = {{y0[0], y1[0], y2[0], y3[0]}, {y0[1], y1[1], y2[1], y3[1]}, {y0[2], y1[2], y2[2], y3[2]},
+                               {y0[3], y1[3], y2[3], y3[3]}};                       // [row i][output q]
+        const unsigned phoff = pm ? (unsigned)(ph * lp) : 0u;
+        if (vec && __builtin_amdgcn_ballot_w64(!colok) == 0ull) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int co = corow + i;
-          const bool rowok = co < cout;
-          const float bv = bpre[mt][i];
-          const unsigned rowoff = (unsigned)co * (unsigned)opitch + (pm ? (unsigned)(ph * lp) : 0u);
-          const float y[4] = {y0[i], y1[i], y2[i], y3[i]};
-          if (vec && colok) {
-            const unsigned off = rowok ? (rowoff + (unsigned)v0) * 4u : 0x80000000u;
-            f32x4 o = {y[0] + bv, y[1] + bv, y[2] + bv, y[3] + bv};
+          for (int i = 0; i < 4; ++i) {
+            const unsigned off = corow + i < cout ? ((unsigned)(corow + i) * (unsigned)opitch + phoff + (unsigned)v0) * 4u : 0x80000000u;
+            const float bv = bpre[mt][i];
+            f32x4 o = {y[i][0] + bv, y[i][1] + bv, y[i][2] + bv, y[i][3] + bv};
             if (nres > 0) {
               u32x4 t = rpre[sub % kRB][i];
               f32x4 rs = {__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
@@ -673,20 +676,39 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
             o *= scale;
             const u32x4 ou = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
             __builtin_amdgcn_raw_buffer_store_b128(ou, ro, off, 0, 0);
-          } else {
+          }
+        } else {                                        // a row ends inside this wave's tiles, strided or unaligned rows
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int co = corow + i;
+            const unsigned rowoff = (unsigned)co * (unsigned)opitch + phoff;
+            const float bv = bpre[mt][i];
+            unsigned off[4];
+            float rs[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int n = ph + dil * (v0 + q);
-              const unsigned off = (rowok && n < len && (ostride == 1 || n * ostride + ophase < opitch))
-                                       ? (rowoff + (unsigned)(pm ? v0 + q : n * ostride + ophase)) * 4u : 0x80000000u;
-              float o = y[q] + bv;
-              if (nres > 0) {
-                float rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));
-                if (nres > 1) rs += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off, 0, 0));
-                if (nres > 2) rs += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off, 0, 0));
-                o += rs;
+              off[q] = (co < cout && n < len && (ostride == 1 || n * ostride + ophase < opitch))
+                           ? (rowoff + (unsigned)(pm ? v0 + q : n * ostride + ophase)) * 4u : 0x80000000u;
+              rs[q] = 0.f;
+            }
+            if (nres > 0) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) rs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off[q], 0, 0));
+              if (nres > 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rs[q] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off[q], 0, 0));
               }
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o * scale), ro, off, 0, 0);
+              if (nres > 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rs[q] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off[q], 0, 0));
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float o = y[i][q] + bv;
+              if (nres > 0) o += rs[q];
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o * scale), ro, off[q], 0, 0);
             }
           }
         }
