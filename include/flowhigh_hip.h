@@ -184,7 +184,8 @@ int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_
  *   u = [cin/16][ngrp][8][cout_pad][16], u[., g, xi, co, .] = sum_j G8[xi][j] * w[co, ., 4g + j]
  * (flowhigh_amd/vocoder.py: pack_wino54_weight); ngrp <= 3 (k <= 12), out_stride <= 1, xlen = 0, out_len = 0 (longer
  * kernels run on fh_conv_grouped_f32, transposed-conv phases on fh_conv_wino_f32; the descriptors live in device memory, so
- * the library cannot check this: flowhigh_amd/vocoder.py does when it builds a launch plan).  Any len and dilation: rows
+ * the library cannot check this: flowhigh_amd/vocoder.py does when it builds a launch plan).  Any dilation and any
+ * len < 2^24 - 4096 (16.7 M samples = 5.8 min at 48 kHz per row; FH_E_ARG beyond: the kernel finds a sample's phase in fp32): rows
  * that are not 16-byte aligned are read and written with 4-byte accesses, same arithmetic.  tile_cfg: 0 = 128 co x 320 outputs per block,
  * 1 = 96 x 320, 2 = 64 x 320 (cout_pad % fh_wino54_tile_m(tile_cfg) == 0).  Results differ from the F(4,3) form by
  * rounding only (tests/tools/winograd_numerics.py). */

@@ -35,6 +35,11 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.fh_gemm_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 0, 0) == -1
     assert b"fh_gemm_f32" in lib.fh_last_error()
     assert lib.fh_conv_grouped_f32(0, 1, 1, 128, 10, 9, 8, 0) == -1
+    # F(5,4): rows of 2^24 - 4096 samples or more are refused before anything is launched (the kernel finds a sample's phase
+    # in fp32: include/flowhigh_hip.h); a fake non-null descriptor pointer is enough for the argument checks
+    assert lib.fh_conv_wino54_f32(16, 1, 1, 96, (1 << 24) - 4096, 1, 0, 1, 0) == -1
+    assert b"fh_conv_wino54_f32" in lib.fh_last_error() and b"rows of" in lib.fh_last_error()
+    assert lib.fh_conv_wino54_f32(16, 1, 1, 100, 1000, 1, 0, 1, 0) == -1          # cout_pad not a multiple of the 96-row tile
 
 
 def test_product_never_imports_oracle():
