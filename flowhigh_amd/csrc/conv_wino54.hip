@@ -114,11 +114,21 @@ struct VDivs {
   fh_fastdiv run_len, runs_per_panel, co_tiles, batch, dil;
 };
 
-template <int MT, bool VL>
+// H16 (MT = 2 only): the block is 48 output channels, three 16-row tiles of v_mfma_f32_16x16x4_f32 instead of two 32-row tiles of
+// the 32x32x2 form -- the C = 48 stage in 64-row blocks spent a quarter of its matrix instructions on padding rows.  The B
+// operands are the same registers: lane (tile l31, channel half lh) of the k-step pair (e, e + 1) becomes, after one
+// v_permlane16_swap of the pair's two registers, lane (tile l & 15, channel {e, e + 1} x {half 0, 1} = l >> 4) for tiles 0-15 in one
+// register and tiles 16-31 in the other; the A lanes read their 4 channels one float later when (l >> 4) is odd, so that elements
+// 0 and 2 of a fragment are the channels e + (g & 1) of the two k-step pairs of a half.  The epilogue keeps its two 32-row rounds
+// (the second has 16 real rows).  The sum over a chunk's channels runs in another order than in the 32x32x2 form: a conv's
+// bits depend on H16, which is fixed per stage (cout_pad), never chosen per launch.
+template <int MT, bool VL, bool H16 = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(V_THREADS, V_THREADS), amdgpu_waves_per_eu(2, 2)))
 void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, int batch, int co_tiles, int n_tiles,
                         int run_len, int dil, int pm, const int* __restrict__ run_map, int n_runs, VDivs dv) {
-  constexpr int BM = 32 * MT;
+  static_assert(!H16 || MT == 2, "the 16-row form is the 48-row block");
+  constexpr int BM = H16 ? 48 : 32 * MT;
+  constexpr int MA = H16 ? 3 : MT;                    // A fragments (row tiles) per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];      // V_LDS_FLOATS
 
   // ---- block -> (panel, n block): panels = (group, batch, co tile), heavy groups first (conv_wino.hip) ----------
@@ -201,9 +211,14 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
 #pragma unroll
     for (int j = 0; j < 6; ++j) toff[g][j] = uni(kB8Toff.v[xi][g][j]);
 
-  f32x16 acc[MT][2];
+  f32x4 acc16[H16 ? 3 : 1][2][2];                     // (H16) [16-row tile][column][tiles 0-15 / 16-31]
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < (H16 ? 3 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc16[i][j][0] = acc16[i][j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x16 acc[H16 ? 1 : MT][2];
+#pragma unroll
+  for (int i = 0; i < (H16 ? 1 : MT); ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -292,14 +307,15 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   };
 
   // A fragments of one step, [mt][half]: half h holds k-steps 4h .. 4h+3 (conv_wino.hip)
-  u32x4 areg[MT][2];
-  const int a_lane = (l31 * V_CK + lh * 8) * 4;
+  // (H16: row l & 15 of a 16-row tile, channels 8 (g >> 1) + (g & 1) + 4 h .. + 3 with g = l >> 4: a 4-byte aligned 16-byte load)
+  u32x4 areg[MA][2];
+  const int a_lane = H16 ? ((lane & 15) * V_CK + 8 * (lane >> 5) + ((lane >> 4) & 1)) * 4 : (l31 * V_CK + lh * 8) * 4;
   auto load_a_half = [&](int h, const VSeg& S, int chunk, int g, bool valid) {
     const float* up = uni(S.u + ((size_t)((chunk * S.ngrp + g) * 8 + xi) * cout_pad + co0) * V_CK);
     const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? BM * V_CK * 4 : 0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      areg[mt][h] = __builtin_amdgcn_raw_buffer_load_b128(r, a_lane + mt * 32 * V_CK * 4 + 16 * h, 0, 0);
+    for (int mt = 0; mt < MA; ++mt)
+      areg[mt][h] = __builtin_amdgcn_raw_buffer_load_b128(r, a_lane + mt * (H16 ? 16 : 32) * V_CK * 4 + 16 * h, 0, 0);
   };
   // L2 warm-up of the A tiles of the NEXT chunk (all its tap groups, this wave's xi), as in conv_wino.hip
   unsigned pf = 0;
@@ -364,17 +380,37 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
         asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bf[0]) : "s"(bco[4]), "v"(xr[4][0]));
         asm("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(bf[1]) : "s"(bco[4]), "v"(xr[4][1]));
         if (p + 1 < 4 * GC) fetch(p + 1);
+        if constexpr (H16) {
+          float b16[2][2];                             // [column][tiles 0-15 / 16-31]: 4 channels x 16 tiles each
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const int e = 2 * (kp & 1) + k2;
+          for (int nt = 0; nt < 2; ++nt) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(bf[nt][0]), __float_as_uint(bf[nt][1]), false, false);
+            b16[nt][0] = __uint_as_float(sw[0]);
+            b16[nt][1] = __uint_as_float(sw[1]);
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+          for (int m16 = 0; m16 < 3; ++m16)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[mt][h][e]), bf[nt][k2],
-                                                                 acc[mt][nt], 0, 0, 0);
+#pragma unroll
+              for (int hf = 0; hf < 2; ++hf)
+                acc16[m16][nt][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(areg[m16][h][2 * (kp & 1)]), b16[nt][hf],
+                                                                          acc16[m16][nt][hf], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const int e = 2 * (kp & 1) + k2;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[mt][h][e]), bf[nt][k2],
+                                                                   acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
         if (kp & 1) {                                  // this half of the A registers is free: refill it for the next step
           const bool same_chunk = g + 1 < GC;
@@ -440,7 +476,8 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   u32x4 rpre[AHEAD ? 2 : 1][5];
   auto item_geom = [&](int mt, int i, int& nreal, unsigned& soff) {
     const int co = co0 + mt * 32 + srow[i];
-    nreal = (co < cout && ioff[i] >= 0) ? inv[i] : 0;                     // real outputs from the vector's first on (<= 0: none)
+    // (mt * 32 + srow < BM: the 48-row block's second round has 16 rows)
+    nreal = (co < cout && mt * 32 + srow[i] < BM && ioff[i] >= 0) ? inv[i] : 0;       // real outputs from the vector's first on (<= 0: none)
     soff = ((unsigned)co * (unsigned)pitch + (unsigned)(ioff[i] >= 0 ? ioff[i] : 0)) * 4u;
     return co;
   };
@@ -466,7 +503,19 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     // (no barrier here: E is not the slab, and the readers of the previous round's E are past that round's second barrier)
-    {
+    if constexpr (H16) {
+      // a lane's 4 accumulators of a 16 x 16 tile: rows 4 (l >> 4) .. + 3 of column l & 15; round mt holds the 16-row tiles
+      // 2 mt and 2 mt + 1 (the third tile is round 1's rows 0-15: its rows 16-31 are not written and their outputs not stored)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            if (2 * mt + t < 3)
+              *reinterpret_cast<f32x4*>(E + ((nt * 8 + xi) * 32 + (lane & 15) + 16 * hf) * V_EP + 16 * t + 4 * (lane >> 4)) =
+                  acc16[2 * mt + t][nt][hf];
+    } else {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         float* ew = E + ((nt * 8 + xi) * 32 + l31) * V_EP + 4 * lh;
@@ -589,10 +638,10 @@ int wino54_n_tiles(int len, int dilation, int pm) {
   return pm ? fh_cdiv((long long)dilation * v_tile_slots(len, dilation), V_BT) : fh_cdiv(fh_cdiv(len, dilation), V_OUT) * dilation;
 }
 
-template <int MT, bool VL>
+template <int MT, bool VL, bool H16 = false>
 int launch_wino54(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation, int pm,
                   hipStream_t stream, const int* run_map, int n_runs) {
-  constexpr int BM = 32 * MT;
+  constexpr int BM = H16 ? 48 : 32 * MT;
   FH_CHECK_ARG(cout_pad > 0 && cout_pad % BM == 0, "fh_conv_wino54_f32: cout_pad %d not a multiple of %d", cout_pad, BM);
   const int co_tiles = cout_pad / BM;
   const int n_tiles = wino54_n_tiles(len, dilation, pm);
@@ -610,7 +659,7 @@ int launch_wino54(const fh_wino_group* groups, int n_groups, int batch, int cout
     return FH_E_LAUNCH;
   }
   if (!lds_opt_in[dev].load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino54_kernel<MT, VL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino54_kernel<MT, VL, H16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        V_LDS_FLOATS * 4);
     if (e != hipSuccess) {
       fh_set_error("fh_conv_wino54_f32: cannot reserve %d bytes of LDS on device %d: %s", V_LDS_FLOATS * 4, dev, hipGetErrorString(e));
@@ -618,7 +667,7 @@ int launch_wino54(const fh_wino_group* groups, int n_groups, int batch, int cout
     }
     lds_opt_in[dev].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL((conv_wino54_kernel<MT, VL>), dim3((unsigned)blocks), dim3(V_THREADS), V_LDS_FLOATS * 4, stream, groups,
+  hipLaunchKernelGGL((conv_wino54_kernel<MT, VL, H16>), dim3((unsigned)blocks), dim3(V_THREADS), V_LDS_FLOATS * 4, stream, groups,
                      n_groups, batch, co_tiles, n_tiles, run_len, dilation, pm, run_map, n_runs, dv);
   FH_CHECK_LAUNCH("fh_conv_wino54_f32");
   return FH_OK;
@@ -626,7 +675,7 @@ int launch_wino54(const fh_wino_group* groups, int n_groups, int batch, int cout
 
 }  // namespace
 
-extern "C" int fh_wino54_tile_m(int tile_cfg) { return tile_cfg == 0 ? 128 : tile_cfg == 1 ? 96 : tile_cfg == 2 ? 64 : -1; }
+extern "C" int fh_wino54_tile_m(int tile_cfg) { return tile_cfg == 0 ? 128 : tile_cfg == 1 ? 96 : tile_cfg == 2 ? 64 : tile_cfg == 3 ? 48 : -1; }
 extern "C" int fh_wino54_tile_n(void) { return V_OUT; }
 
 namespace {
@@ -647,6 +696,9 @@ int wino54_dispatch(const fh_wino_group* groups, int n_groups, int batch, int co
     FH_W54_CASE(0, 4)
     FH_W54_CASE(1, 3)
     FH_W54_CASE(2, 2)
+    case 3:
+      return vl ? launch_wino54<2, true, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs)
+                : launch_wino54<2, false, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
   }
 #undef FH_W54_CASE
   fh_set_error("fh_conv_wino54_f32: unknown tile_cfg %d", tile_cfg);

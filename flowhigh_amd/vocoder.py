@@ -151,13 +151,14 @@ def make_act_group(x, y, p):
 # channels x one group of FOUR taps; constants from tools/wino54_bench.py fit)
 WINO_F54 = 256            # flag in a plan's tile id: the launch runs fh_conv_wino54_f32 with tile_cfg = id & 15
 _WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256),
-               WINO_F54 | 0: (128, 320), WINO_F54 | 1: (96, 320), WINO_F54 | 2: (64, 320)}
+               WINO_F54 | 0: (128, 320), WINO_F54 | 1: (96, 320), WINO_F54 | 2: (64, 320), WINO_F54 | 3: (48, 320)}
 _WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0), 6: (2.75, 20.0),
               # (tools/wino54_cost_fit.py: 4.4 / 3.1-3.6 / 2.5 us per step = 0.78 / 0.71-0.83 / 0.68 of the matrix-pipe time; b: ~10 us
               # reproduces both closing-conv forms of the C = 96 stage: 3 groups, 1 125 blocks: 232 us; fused, 375 blocks: 308 us)
               # Chosen among five constant sets by the measured total of the 43 conv launches of a 10 s clip (13.25 ms; the others
               # 13.35-13.41): the launch model is a ranking device, not a clock.
-              WINO_F54 | 0: (4.4, 12.0), WINO_F54 | 1: (3.3, 10.0), WINO_F54 | 2: (2.52, 9.0)}
+              # (| 3: the 48-row block, three 16-row MFMA tiles: 3/4 of the 64-row block's matrix instructions)
+              WINO_F54 | 0: (4.4, 12.0), WINO_F54 | 1: (3.3, 10.0), WINO_F54 | 2: (2.52, 9.0), WINO_F54 | 3: (1.95, 9.0)}
 # 128-row tiles halve the LDS reads and transform instructions per MFMA (one B fragment feeds 4 MFMAs) but
 # double the weight bytes a block streams: beyond this panel size (6 x 128 rows x K, bytes) a chip full of
 # such blocks thrashes the 4 MB L2s (C = 768: 857 us against 732 us with 64 x 512 tiles)
@@ -230,8 +231,11 @@ def _choose_wino_cfg(ksteps, batch, wpad, length, dil, default, bf=False):
     the default shape stays unless another one is estimated at least 3 % faster (the model is good to a few
     per cent; at large batch every shape is within that and the default has the best steady state)."""
     fam = WINO_F54 if (default is not None and default & WINO_F54) else 0             # tiles of the default's kernel only
+    # (the 48-row F(5,4) block sums a chunk's channels in another order than the 32-row-tile blocks: it is the shape of the
+    # weights it alone divides, never an alternative to the 96-row block)
     cands = [cfg for cfg, (bm, _) in _WINO_TILES.items()
-             if wpad % bm == 0 and cfg not in _WINO_TILES_OFF and (cfg & WINO_F54) == fam]
+             if wpad % bm == 0 and cfg not in _WINO_TILES_OFF and (cfg & WINO_F54) == fam
+             and not (cfg == WINO_F54 | 3 and wpad % 96 == 0)]
     cost = {cfg: wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, bf=bf) for cfg in cands}
     best = min(cands, key=lambda cfg: cost[cfg])
     if default in cost and cost[best] > 0.97 * cost[default]:
@@ -254,11 +258,14 @@ def pick_wino_tile(c):
 
 
 def pick_wino54_tile(c):
-    """(plan tile id, cout_pad) of the F(5,4) kernel: 128-row blocks where they divide c, else 96, else 64 (padded)."""
+    """(plan tile id, cout_pad) of the F(5,4) kernel: 128-row blocks where they divide c, else 96, else 48 (three 16-row MFMA
+    tiles), else 64 (padded)."""
     if c % 128 == 0:
         return WINO_F54 | 0, c
     if c % 96 == 0:
         return WINO_F54 | 1, c
+    if c % 48 == 0:
+        return WINO_F54 | 3, c
     return WINO_F54 | 2, -(-c // 64) * 64
 
 
@@ -270,7 +277,11 @@ WINO54_MIN_C = 96
 
 
 def use_wino54(c):
-    return os.environ.get("FH_WINO54", "1") != "0" and use_wino(c, 1) and c >= int(os.environ.get("FH_WINO54_MIN_C", WINO54_MIN_C))
+    """... and at the odd multiples of 48 channels below it (C = 48: the 48-row block has no padding rows, the F(4,3) kernel's
+    64-row tile a quarter; FH_WINO54_H16=0: not there)."""
+    if os.environ.get("FH_WINO54", "1") == "0" or not use_wino(c, 1):
+        return False
+    return c >= int(os.environ.get("FH_WINO54_MIN_C", WINO54_MIN_C)) or (c % 48 == 0 and os.environ.get("FH_WINO54_H16", "1") != "0")
 
 
 def pack_wino_weight(w, cout_pad):

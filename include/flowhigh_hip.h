@@ -187,7 +187,8 @@ int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_
  * the library cannot check this: flowhigh_amd/vocoder.py does when it builds a launch plan).  Any dilation and any
  * len < 2^24 - 4096 (16.7 M samples = 5.8 min at 48 kHz per row; FH_E_ARG beyond: the kernel finds a sample's phase in fp32): rows
  * that are not 16-byte aligned are read and written with 4-byte accesses, same arithmetic.  tile_cfg: 0 = 128 co x 320 outputs per block,
- * 1 = 96 x 320, 2 = 64 x 320 (cout_pad % fh_wino54_tile_m(tile_cfg) == 0).  Results differ from the F(4,3) form by
+ * 1 = 96 x 320, 2 = 64 x 320, 3 = 48 x 320 (three 16-row tiles of v_mfma_f32_16x16x4_f32: it sums a chunk's channels in another
+ * order than the others, so a caller keeps ONE of {0, 1, 2} / 3 per weight tensor) (cout_pad % fh_wino54_tile_m(tile_cfg) == 0).  Results differ from the F(4,3) form by
  * rounding only (tests/tools/winograd_numerics.py). */
 int fh_wino54_tile_m(int tile_cfg);
 int fh_wino54_tile_n(void);

@@ -140,7 +140,10 @@ def test_conv_wino(c, k, d, L, B):
                                           (128, 11, 3, 999, 2, True), (192, 7, 5, 2001, 1, True), (256, 5, 1, 321, 1, False),
                                           # rows that are not 16-byte aligned (4-byte accesses), plain dilated layout
                                           (128, 11, 1, 1001, 2, False), (96, 3, 1, 13, 1, False), (128, 7, 3, 778, 2, False),
-                                          (48, 11, 1, 1203, 1, False), (384, 12, 1, 2000, 1, False)])
+                                          (48, 11, 1, 1203, 1, False), (384, 12, 1, 2000, 1, False),
+                                          # 48-row blocks (three 16-row MFMA tiles): one and three of them per group, both layouts
+                                          (48, 7, 3, 999, 2, True), (144, 3, 1, 644, 2, False), (48, 11, 5, 2001, 1, True),
+                                          (48, 3, 1, 13, 2, False), (144, 12, 1, 1000, 1, False)])
 def test_conv_wino54(c, k, d, L, B, pm):
     """Winograd F(5,4) form of the residual-stack convs (conv_wino54.hip: points 0, +-1, +-2, +-1/2, inf; taps in groups of
     4) against the direct fp64 definition, bias + residual + scale; same tolerance as the F(4,3) form."""

@@ -150,7 +150,7 @@ def test_plan_ragged_merges_launch_by_launch():
             runs = (C.c_int32 * n_runs).from_buffer_copy(raw[off_map:off_map + 4 * n_runs])
             f54 = wcfg & V.WINO_F54                             # (the F(5,4) kernel: 128 / 96 / 64 co x 320 outputs)
             bm, bt = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256),
-                      V.WINO_F54: (128, 320), V.WINO_F54 | 1: (96, 320), V.WINO_F54 | 2: (64, 320)}[wcfg]
+                      V.WINO_F54: (128, 320), V.WINO_F54 | 1: (96, 320), V.WINO_F54 | 2: (64, 320), V.WINO_F54 | 3: (48, 320)}[wcfg]
             assert hip.lib().fh_wino54_tile_n() == 320 and hip.lib().fh_wino54_tile_m(wcfg & 15) == bm if f54 else True
             pm = pmflag & 1
             n_tiles = V.wino_n_tiles(wcfg, maxlen, dil, pm)

@@ -12,7 +12,7 @@ BF = len(sys.argv) > 3 and sys.argv[3] == "bf"
 F54 = len(sys.argv) > 3 and sys.argv[3] == "f54"
 worst = 0.0
 for case in range(n_cases):
-    c = rng.choice([16, 32, 48, 64, 96, 128, 192] + ([256, 384] if F54 else []))
+    c = rng.choice([16, 32, 48, 64, 96, 128, 192] + ([256, 384, 48, 144] if F54 else []))
     k = rng.choice([1, 3, 5, 7, 9, 11])
     d = rng.choice([1, 1, 2, 3, 5])
     B = rng.choice([1, 2, 3])
@@ -31,7 +31,8 @@ for case in range(n_cases):
     ref = ((ref + bias.double().view(1, -1, 1) + sum(r.double() for r in res)) * scale).float()
     wcfg, cpad = V.pick_wino54_tile(c) if F54 else V.pick_wino_tile(c)
     if F54 and rng.random() < 0.3:                                  # (any tile height that divides cout_pad)
-        wcfg = rng.choice([t for t in (V.WINO_F54, V.WINO_F54 | 1, V.WINO_F54 | 2) if cpad % V._WINO_TILES[t][0] == 0])
+        wcfg = rng.choice([t for t in (V.WINO_F54, V.WINO_F54 | 1, V.WINO_F54 | 2, V.WINO_F54 | 3) if cpad % V._WINO_TILES[t][0] == 0
+                           and not (t == V.WINO_F54 | 3 and cpad % 96 == 0)])      # (the 48-row block: only where no 96-row block fits)
     if wcfg == 0 and rng.random() < 0.3:
         wcfg = rng.choice([4, 5, 6] if cpad % 128 == 0 else [4, 5])
     pack = V.pack_wino54_weight if F54 else V.pack_wino_weight
