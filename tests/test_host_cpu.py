@@ -282,3 +282,28 @@ def test_norm_device_pins_the_ordinal():
     assert hip.norm_device("cpu") == torch.device("cpu")
     if not torch.cuda.is_available():
         assert hip.norm_device("cuda") == torch.device("cuda")          # nothing to pin without a GPU
+
+
+def test_f54_tile_family_is_fixed_by_the_channel_count(monkeypatch):
+    """Which F(5,4) block shape a stage's weights are packed for depends on its channel count only; the 48-row block (three
+    16-row MFMA tiles: another summation order than the 32-row-tile blocks) is never an alternative of the launch model where
+    a 96-row block fits, so a conv's bits do not depend on batch or length (conv_wino54.hip, vocoder._choose_wino_cfg)."""
+    from flowhigh_amd import vocoder as V
+    for var in ("FH_WINO54", "FH_WINO54_MIN_C", "FH_WINO54_H16", "FH_WINO"):
+        monkeypatch.delenv(var, raising=False)
+    assert V.pick_wino54_tile(768) == (V.WINO_F54 | 0, 768) and V.pick_wino54_tile(96) == (V.WINO_F54 | 1, 96)
+    assert V.pick_wino54_tile(48) == (V.WINO_F54 | 3, 48) and V.pick_wino54_tile(144) == (V.WINO_F54 | 3, 144)
+    assert V.pick_wino54_tile(64) == (V.WINO_F54 | 2, 64) and V.pick_wino54_tile(24) == (V.WINO_F54 | 2, 64)
+    assert V.pick_wino54_tile(240) == (V.WINO_F54 | 3, 240)
+    # (144 channels are not a Winograd stage at all: use_wino)
+    assert V.use_wino54(96) and V.use_wino54(48) and V.use_wino54(240) and not V.use_wino54(64) and not V.use_wino54(24)
+    monkeypatch.setenv("FH_WINO54_H16", "0")
+    assert V.use_wino54(96) and not V.use_wino54(48)
+    monkeypatch.delenv("FH_WINO54_H16")
+    # the launch model's candidates: every shape of the family that divides cout_pad, the 48-row block only where it is the one
+    for wpad, batch, length in ((96, 1, 120000), (96, 32, 120000), (192, 1, 60000), (384, 8, 2000), (288, 1, 5000)):
+        cfg, _ = V.choose_wino_cfg([6, 12, 18], batch, wpad, length, 1, default=V.pick_wino54_tile(wpad)[0])
+        assert cfg & V.WINO_F54 and cfg != V.WINO_F54 | 3, (wpad, batch, length, cfg)
+    for wpad, batch, length in ((48, 1, 240000), (48, 32, 240000), (144, 2, 700)):
+        cfg, _ = V.choose_wino_cfg([3, 6, 9], batch, wpad, length, 1, default=V.WINO_F54 | 3)
+        assert cfg == V.WINO_F54 | 3
