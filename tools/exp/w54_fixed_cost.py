@@ -26,7 +26,7 @@ def bench(fn, reps=30):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-cfg54 = 0 if cout % 128 == 0 else 1 if cout % 96 == 0 else 2
+cfg54 = 0 if cout % 128 == 0 else 1 if cout % 96 == 0 else 3 if cout % 48 == 0 else 2
 bm = lib.fh_wino54_tile_m(cfg54)
 cpad = -(-cout // bm) * bm
 print(f"cout {cout} len {L} tile rows {bm}: {3 * (cpad // bm) * lib.fh_wino54_n_tiles(L, 1, 0)} blocks")

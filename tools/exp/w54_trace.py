@@ -12,7 +12,7 @@ nres = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 KS = [11, 7, 3]
 st = hip.stream()
 lib = hip.lib()
-cfg54 = 0 if cout % 128 == 0 else 1 if cout % 96 == 0 else 2
+cfg54 = 0 if cout % 128 == 0 else 1 if cout % 96 == 0 else 3 if cout % 48 == 0 else 2
 bm = lib.fh_wino54_tile_m(cfg54)
 cpad = -(-cout // bm) * bm
 xs = [torch.randn(1, cin, L, device=DEV) for _ in KS]
