@@ -7,8 +7,8 @@ echo "== $(hostname) $(date -u +%H:%M:%S)"
 tools/micro/mfma_mix 2>/dev/null | sed -n 1p
 python tools/copy_bench.py 2>/dev/null | tail -2
 python tools/wino_sustained.py 2>/dev/null | tail -3
-if [ -f flowhigh_amd/lib/abl/trace2.so ]; then       # in-kernel shader clock of a conv launch, alone and after activation launches
-  for alt in 0 1; do echo -n "ALT=$alt: "; ALT=$alt WARM=200 FH_LIB_PATH=flowhigh_amd/lib/abl/trace2.so python tools/wino_trace2.py 192 60000 1 0 1 2>/dev/null | grep "launch\|shader clock" | tr '\n' ' '; echo; done
+if [ -f tools/abl/trace2.so ]; then       # in-kernel shader clock of a conv launch, alone and after activation launches
+  for alt in 0 1; do echo -n "ALT=$alt: "; ALT=$alt WARM=200 FH_LIB_PATH=tools/abl/trace2.so python tools/wino_trace2.py 192 60000 1 0 1 2>/dev/null | grep "launch\|shader clock" | tr '\n' ' '; echo; done
 fi
 python tools/conv_layers.py 1 1000 2>/dev/null | tail -1
 python tools/act_bench.py 2>/dev/null | sed -n 3,4p

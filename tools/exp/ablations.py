@@ -1,10 +1,10 @@
 """Timing-experiment (ablation) builds of the product kernels.  The product sources carry no experiment switches: this
 script applies textual patches to COPIES of them (tools/exp/_abl_<name>.hip), builds each as a variant library
-(tools/build_variant.sh -> flowhigh_amd/lib/abl/<name>.so) and prints how to time it.  Results of ablation builds are
+(tools/build_variant.sh -> tools/abl/<name>.so) and prints how to time it.  Results of ablation builds are
 wrong by construction; only the time matters.
 
     python tools/exp/ablations.py wino_notransform wino_noweights wino_noslab act_nosin act_noup act_nodown act_dataonly
-    FH_LIB_PATH=flowhigh_amd/lib/abl/<name>.so python tools/wino_time.py 768 5000 1      (or tools/act_bench.py)
+    FH_LIB_PATH=tools/abl/<name>.so python tools/wino_time.py 768 5000 1      (or tools/act_bench.py)
 """
 import subprocess
 import sys
@@ -89,7 +89,7 @@ def build(name):
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     finally:
         tmp.unlink()
-    print(f"flowhigh_amd/lib/abl/{name}.so")
+    print(f"tools/abl/{name}.so")
 
 
 if __name__ == "__main__":

@@ -30,5 +30,5 @@ for res in (False, True):
 PY
 for v in "" c_noepi c_nomfma; do
   echo "== ${v:-product}"
-  if [ -z "$v" ]; then python /tmp/c24.py 2>&1 | grep -v amdgpu; else FH_LIB_PATH=flowhigh_amd/lib/abl/$v.so python /tmp/c24.py 2>&1 | grep -v amdgpu; fi
+  if [ -z "$v" ]; then python /tmp/c24.py 2>&1 | grep -v amdgpu; else FH_LIB_PATH=tools/abl/$v.so python /tmp/c24.py 2>&1 | grep -v amdgpu; fi
 done

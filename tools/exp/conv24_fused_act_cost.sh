@@ -33,4 +33,4 @@ for res in (False, True):
     cb.run(24, 480000, [3, 3, 3], 4, res=res, label="  k=3 x3 res=%d" % res)
 PY
 echo "== product"; python /tmp/c24b.py 2>&1 | grep -v amdgpu
-echo "== + 33 FMAs per staged sample"; FH_LIB_PATH=flowhigh_amd/lib/abl/c_actcost.so python /tmp/c24b.py 2>&1 | grep -v amdgpu
+echo "== + 33 FMAs per staged sample"; FH_LIB_PATH=tools/abl/c_actcost.so python /tmp/c24b.py 2>&1 | grep -v amdgpu

@@ -1,5 +1,5 @@
 """Phase timeline of the F(5,4) kernel's blocks (tools/exp/make_w54_trace.py build):
-FH_LIB_PATH=flowhigh_amd/lib/abl/w54trace.so python tools/exp/w54_trace.py [cout] [cin] [len] [nres]"""
+FH_LIB_PATH=tools/abl/w54trace.so python tools/exp/w54_trace.py [cout] [cin] [len] [nres]"""
 import ctypes, sys, torch
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, vocoder as V

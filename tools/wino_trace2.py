@@ -2,7 +2,7 @@
 Needs the trace2 variant (tools/exp/conv_wino_trace2.hip: stamps around descriptor fetch, prologue, K loop and the
 four phases of every epilogue sub-tile):
     tools/build_variant.sh trace2 tools/exp/conv_wino_trace2.hip=conv_wino.hip
-    FH_LIB_PATH=flowhigh_amd/lib/abl/trace2.so python tools/wino_trace2.py <C> <L> <dil> [tile_cfg] [nres]"""
+    FH_LIB_PATH=tools/abl/trace2.so python tools/wino_trace2.py <C> <L> <dil> [tile_cfg] [nres]"""
 import sys, ctypes, torch, numpy as np
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, vocoder as V
