@@ -7,7 +7,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libflowhigh_hip.so"
-SOURCES = ["api_common.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino54.hip", "act1d.hip", "gemm_mfma.hip", "flow_ops.hip",
+SOURCES = ["api_common.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino54.hip", "amp_fused.hip", "act1d.hip", "gemm_mfma.hip", "flow_ops.hip",
            "attention.hip", "frontend.hip", "fft.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,593 @@
+// Narrow stages of BigVGAN (C <= 48): anti-aliased activation and the conv behind it in ONE launch.
+//
+// Replaces, per launch, one `xt = act(x); xt = conv(xt)` pair of the AMP blocks
+// (/root/reference/src/flowhigh/models/bigvgan/models.py:63-72 AMPBlock1, :108-117 AMPBlock2;
+//  Activation1d alias_free_torch/act.py:23-28 = UpSample1d resample.py:25-33 -> SnakeBeta activations.py:107-120 ->
+//  DownSample1d filter.py:86-95; the convs are "same"-padded, k = 3 / 7 / 11, dilation 1 / 3 / 5), including "+ x"
+//  (:70) and the "xs / num_kernels" average over the blocks (:181-187, K segments of one group).
+//
+// Why: at 24 / 48 channels the unfused pair was 2.5 x above its own HBM floor -- the activation launch wrote the [B, C, L]
+// tensor, the conv launch read it back, and the conv kernels built for wide stages spent 37 % of a block outside their K loop
+// (eight transform points in eight waves meet through LDS) or multiplied 25 % padding rows.  Here the activated samples only
+// ever exist in LDS and the conv is shaped for few channels:
+//   * block = 4 waves, 64 F(5,4) tiles = 300-320 outputs of every channel (a multiple of 20 x dilation, so that every block
+//     starts on a tile boundary of every dilation phase and on a 16-byte boundary); two blocks per CU, so that one block's
+//     prologue / epilogue / barriers run under the other's K loop;
+//   * the K loop walks 8-channel chunks.  For the NEXT chunk, wave w runs the activation of channel pair w over the block's
+//     samples + halo (one pass of 384 z pairs per channel through wave-private LDS: no block barrier) and writes the result
+//     into the chunk's slab in the Winograd read layout: per dilation phase 5 planes (sample w -> plane w % 5, index w / 5),
+//     channel pairs interleaved, so that lane `tile` reads sample 5 tile + e with ONE conflict-free ds_read_b64 for both
+//     channels of its pair;
+//   * ONE wave owns all 8 transform points of its 16 tiles: v_mfma_f32_16x16x4_f32 with M = 16 output channels, N = 16
+//     tiles, K = 4 channels; 8 x ceil(C / 16) accumulator tiles per wave.  B^T (8 x 8) is applied per lane on the packed
+//     fp32 ALU over the k-step pair with the even / odd halves of the +- points shared (26 packed ops for 8 points), A^T
+//     per lane in the epilogue: no exchange between waves anywhere;
+//   * transformed weights [chunk][tap group][point][lane][row tile][2] stream L2 -> LDS one (chunk, tap group) stage ahead
+//     (4-12 KB), every wave reads its A fragments from there (the whole set is 25-220 KB per conv: it does not fit beside
+//     the slabs, and from global memory it would be one dword per MFMA and lane);
+//   * epilogue: A^T, then the 5-output tiles of all dilation phases are re-interleaved through LDS into plain rows and leave
+//     as 16-byte vectors with bias, residuals and scale.  No phase-major tensors on either side.
+// Every sample's arithmetic depends on its absolute position only (tiles are anchored at multiples of 5 of the decimated
+// index, the channel order of the sum is fixed), so a clip gives the same bits alone, in a batch, in a ragged launch and in
+// aligned time chunks.
+#include "fh_common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int F_THREADS = 256;             // 4 waves
+constexpr int F_PPT = 6;                   // z pairs (and activation outputs) per lane
+constexpr int F_PAIRS = 64 * F_PPT;        // z pairs of a wave pass: samples i = tA - 4 + q
+constexpr int F_NOUT = F_PAIRS - 8;        // activation outputs of a pass: t = tA + j, j < 376
+constexpr int F_XS = F_PAIRS + 16;         // staged inputs x[tA - 8 .. tA + 391]
+constexpr int F_ZS = 2 * F_PAIRS + 16;
+constexpr int F_SCR = F_XS + F_ZS;         // wave-private scratch, floats
+constexpr int F_SLAB = 3840;               // floats of a slab (one 8-channel chunk): 40 d PL <= this for d <= 6
+constexpr int F_SLAB_BUF = F_SLAB + 128;   // + one trash pair per lane
+constexpr int F_YP = 324;                  // row pitch of the output staging
+constexpr int F_MAX_D = 6;
+
+// tiles per dilation phase and plane length (index units) of the slab
+__host__ __device__ constexpr int f_ntp(int d) { return 4 * (16 / d); }
+__host__ __device__ constexpr int f_tb(int d) { return 5 * d * f_ntp(d); }
+__host__ __device__ constexpr int f_pl(int d) { return d == 1 ? 80 : d == 2 ? 48 : f_ntp(d) + 5; }
+static_assert(40 * 1 * f_pl(1) <= F_SLAB && 40 * 2 * f_pl(2) <= F_SLAB && 40 * 3 * f_pl(3) <= F_SLAB &&
+              40 * 4 * f_pl(4) <= F_SLAB && 40 * 5 * f_pl(5) <= F_SLAB && 40 * 6 * f_pl(6) <= F_SLAB, "slab size");
+
+template <int MA>
+constexpr int f_wstage() { return 1024 * MA; }           // floats of one (chunk, tap group) weight stage
+
+template <int MA>
+constexpr int f_lds_floats() { return 2 * F_SLAB_BUF + 2 * f_wstage<MA>() + 4 * F_SCR + 3 * 32; }
+
+// sin^2 of two values (act1d.hip: sin_squared2; |a| >= 32768 is patched by the caller)
+__device__ __forceinline__ f32x2 f_sin_squared2(f32x2 a) {
+  const f32x2 k = __builtin_elementwise_fma(a, (f32x2)(0.31830988618379067154f), (f32x2)(12582912.f)) - 12582912.f;
+  f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-3.14159274101257324f), a);
+  r = __builtin_elementwise_fma(k, (f32x2)(8.742277657347586e-08f), r);
+  const f32x2 w = r * r;
+  f32x2 p = __builtin_elementwise_fma(w, (f32x2)(-3.6304279547e-06f), (f32x2)(1.3934598246e-04f));
+  p = __builtin_elementwise_fma(w, p, (f32x2)(-3.1723924913e-03f));
+  p = __builtin_elementwise_fma(w, p, (f32x2)(4.4443175197e-02f));
+  p = __builtin_elementwise_fma(w, p, (f32x2)(-3.3333307505e-01f));
+  p = __builtin_elementwise_fma(w, p, (f32x2)(1.0f));
+  return w * p;
+}
+__device__ __noinline__ float f_sin_squared_slow(float a) {
+  const float s = sinf(a);
+  return s * s;
+}
+
+// MA: 16-row output tiles (channels <= 16 MA).  VEC: rows are 16-byte aligned (len % 4 == 0 for every group).
+// ACT = false: the activation is skipped (x is staged as it is): conv-only form for tests and measurements.
+template <int MA, bool VEC, bool ACT>
+__global__ __attribute__((amdgpu_flat_work_group_size(F_THREADS, F_THREADS), amdgpu_waves_per_eu(2, 2)))
+void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, int n_groups, int channels, int d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const slab0 = lds;
+  float* const wbuf0 = lds + 2 * F_SLAB_BUF;
+  float* const scr0 = wbuf0 + 2 * f_wstage<MA>();
+  f32x2* const taps = reinterpret_cast<f32x2*>(scr0 + 4 * F_SCR);        // [seg][16]: 0..5 up pairs (x 2), 6..11 down pairs
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = blockIdx.x;
+
+  // ---- block -> (group, batch item, tile): groups carry the prefix of their tile counts ------------------------------
+  int cnt = 0;
+  for (int base = 0; base < n_groups; base += 64) {
+    const int idx = base + lane;
+    const bool le = idx < n_groups && groups[idx].tile_base <= bid;
+    cnt += __popcll(__ballot(le));
+  }
+  const fh_amp_group* __restrict__ const G = groups + uni(cnt - 1);
+  const int len = uni(G->len);
+  const int NTP = f_ntp(d), TB = 5 * d * NTP, PL = f_pl(d), NT = d * NTP;
+  const int tpr = (len + TB - 1) / TB;
+  const int local = bid - uni(G->tile_base);
+  const int bb = uni(local / tpr);
+  const int t0 = (local - bb * tpr) * TB;
+  const int nseg = uni(G->nseg);
+  int cmax = 0;
+  for (int s = 0; s < nseg; ++s) cmax = max(cmax, uni(G->seg[s].center));
+  const int A = (cmax * d + 3) & ~3;                   // the activation pass starts at tA = t0 - A (16-byte aligned)
+  const int tA = t0 - A;
+  const int nch = channels >> 3;
+  float* const xs = scr0 + wv * F_SCR;
+  float* const zs = xs + F_XS;
+
+  // taps of every segment -> LDS (read as broadcasts by the activation passes)
+  if (ACT && tid < 12 * nseg) {
+    const int s = tid / 12, e = tid - 12 * s;
+    const bool up = e < 6;
+    const int j = up ? e : e - 6;
+    const float* src = up ? G->seg[s].up_taps : G->seg[s].down_taps;
+    const int i0 = up ? 10 - 2 * j : 2 * j;
+    const float sc = up ? 2.f : 1.f;                  // (the 2x of UpSample1d folded in: exact)
+    taps[s * 16 + e] = (f32x2){sc * src[i0], sc * src[i0 + 1]};
+  }
+
+  // ---- slab geometry of this lane --------------------------------------------------------------------------------
+  // writer: activation output j = 6 lane + r is sample t = tA + j: rel = j - A = d u + p, slab sample w = u + cmax of phase p
+  int wofs[F_PPT];
+#pragma unroll
+  for (int r = 0; r < F_PPT; ++r) {
+    const int j = F_PPT * lane + r;
+    const int rel = j - A;
+    int u = rel / d;
+    int p = rel - u * d;
+    if (p < 0) { p += d; --u; }
+    const int w = u + cmax;
+    const int q = w / 5;
+    const bool ok = j < F_NOUT && w >= 0 && q < PL;
+    wofs[r] = ok ? (((p * 5 + (w - 5 * q)) * 4 + wv) * PL + q) * 2 : F_SLAB + 2 * lane;
+  }
+  // reader: lane (tile n = lane & 15 of this wave's 16, channel pair kq = lane >> 4)
+  const int kq = lane >> 4;
+  int tl = 16 * wv + (lane & 15);
+  const bool tile_ok = tl < NT;
+  if (!tile_ok) tl = NT - 1;
+  const int tp = tl / NTP, tit = tl - tp * NTP;
+  const int rd_base = ((tp * 5 * 4 + kq) * PL + tit) * 2;
+
+  // ---- loads --------------------------------------------------------------------------------------------------------
+  struct Seg {
+    const float* x;
+    const float* u;
+    const float* alpha;
+    const float* inv_beta;
+    int ngrp, center;
+  };
+  auto load_seg = [&](int s) {
+    Seg S;
+    const fh_amp_seg* P = &G->seg[s];
+    S.x = uni(P->x);
+    S.u = uni(P->u);
+    S.alpha = uni(P->alpha);
+    S.inv_beta = uni(P->inv_beta);
+    S.ngrp = uni(P->ngrp);
+    S.center = uni(P->center);
+    return S;
+  };
+  u32x4 xq[2][2];                                    // [channel of the pair][vector]: x[tA - 8 + 4 f ..], f = lane, lane + 64
+  float al[2], ib[2];
+  auto load_x = [&](const Seg& S, int chunk, bool valid) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ch = chunk * 8 + 2 * wv + h;
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(S.x + ((size_t)bb * channels + ch) * (size_t)len, valid ? (unsigned)len * 4u : 0u);
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int f = lane + 64 * v;
+        const int t = tA - 8 + 4 * f;
+        if (VEC) {
+          xq[h][v] = __builtin_amdgcn_raw_buffer_load_b128(r, f < F_XS / 4 ? (unsigned)(t * 4) : 0x80000000u, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            xq[h][v][e] = __builtin_amdgcn_raw_buffer_load_b32(r, f < F_XS / 4 ? (unsigned)((t + e) * 4) : 0x80000000u, 0, 0);
+        }
+      }
+      if (ACT) {
+        al[h] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(S.alpha, valid ? (unsigned)channels * 4u : 0u), (unsigned)ch * 4u, 0, 0));
+        ib[h] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(S.inv_beta, valid ? (unsigned)channels * 4u : 0u), (unsigned)ch * 4u, 0, 0));
+      }
+    }
+  };
+  u32x4 wq[MA];                                      // this thread's 16-byte pieces of the next weight stage
+  auto load_w = [&](const float* p, bool valid) {
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(p, valid ? (unsigned)f_wstage<MA>() * 4u : 0u);
+#pragma unroll
+    for (int i = 0; i < MA; ++i) wq[i] = __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(tid + 256 * i) * 16u, 0, 0);
+  };
+  auto store_w = [&](int buf) {
+    float* dst = wbuf0 + buf * f_wstage<MA>();
+#pragma unroll
+    for (int i = 0; i < MA; ++i) *reinterpret_cast<u32x4*>(dst + (tid + 256 * i) * 4) = wq[i];
+  };
+
+  // ---- the activation of this wave's channel pair over the block's samples -> slab --------------------------------
+  const bool edge = tA - 8 < 0 || tA - 8 + F_XS > len;          // the pass touches a row end (block-uniform)
+  auto stage_pair = [&](int sbuf, int seg_idx) {
+    float* const sl = slab0 + sbuf * F_SLAB_BUF;
+    float out[2][F_PPT];
+    const f32x2* tp_ = taps + seg_idx * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __builtin_amdgcn_wave_barrier();
+      *reinterpret_cast<u32x4*>(xs + 4 * lane) = xq[h][0];
+      if (lane < F_XS / 4 - 64) *reinterpret_cast<u32x4*>(xs + 4 * (lane + 64)) = xq[h][1];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (!ACT) {
+        // conv-only form: the staged samples are the conv's input (zero outside the row: the loads' out-of-range value)
+#pragma unroll
+        for (int r = 0; r < F_PPT; ++r) out[h][r] = xs[F_PPT * lane + r + 8];
+        continue;
+      }
+      if (edge) {                                    // replicate padding at the row ends (act1d.hip)
+        const int tb = tA - 8;
+        for (int j = lane; j < F_XS; j += 64) {
+          const int t = tb + j;
+          if (t < 0) xs[j] = xs[-tb];
+          else if (t >= len && len - 1 - tb >= 0) xs[j] = xs[len - 1 - tb];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      const float alpha = al[h], inv_beta = ib[h];
+      {   // z pairs q = 6 lane + r: P = (z[2i+1], z[2i+2]), i = tA - 4 + q, from x[i-2 .. i+3] = xs[q + 2 .. q + 7]
+        f32x2 fu2[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fu2[q] = tp_[q];
+        float xv[12];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+          const f32x2 t2 = *reinterpret_cast<const f32x2*>(xs + F_PPT * lane + 2 + 2 * v);
+          xv[2 * v] = t2[0];
+          xv[2 * v + 1] = t2[1];
+        }
+        f32x2 zf[F_PPT], arg[F_PPT], s2[F_PPT];
+        float amax = 0.f;
+#pragma unroll
+        for (int r = 0; r < F_PPT; ++r) {
+          f32x2 z = {0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 6; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + q]), fu2[q], z);
+          zf[r] = z;
+          arg[r] = z * alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < F_PPT; ++r) {
+          s2[r] = f_sin_squared2(arg[r]);
+          amax = fmaxf(fmaxf(amax, fabsf(arg[r][0])), fabsf(arg[r][1]));
+        }
+        if (__builtin_expect(amax >= 32768.f, 0)) {
+#pragma unroll 1
+          for (int r = 0; r < F_PPT; ++r)
+            if (fabsf(arg[r][0]) >= 32768.f || fabsf(arg[r][1]) >= 32768.f) {
+              s2[r][0] = f_sin_squared_slow(arg[r][0]);
+              s2[r][1] = f_sin_squared_slow(arg[r][1]);
+            }
+        }
+        f32x4* zw = reinterpret_cast<f32x4*>(zs + 2 * F_PPT * lane);
+#pragma unroll
+        for (int v = 0; v < F_PPT / 2; ++v) {
+          const f32x2 a = __builtin_elementwise_fma((f32x2)(inv_beta), s2[2 * v], zf[2 * v]);
+          const f32x2 b = __builtin_elementwise_fma((f32x2)(inv_beta), s2[2 * v + 1], zf[2 * v + 1]);
+          zw[v] = (f32x4){a[0], a[1], b[0], b[1]};
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      {   // outputs j = 6 lane + r (t = tA + j): y = sum_m P_{t - 3 + m} . (f_dn[2m], f_dn[2m+1]); P_{t-3+m} is pair q = j + 1 + m
+        f32x2 fdp[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fdp[j] = tp_[6 + j];
+        float zv[24];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 2 * F_PPT * lane + 4 * v);
+          zv[4 * v] = t4[0]; zv[4 * v + 1] = t4[1]; zv[4 * v + 2] = t4[2]; zv[4 * v + 3] = t4[3];
+        }
+#pragma unroll
+        for (int r = 0; r < F_PPT; ++r) {
+          f32x2 a2 = {0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
+          out[h][r] = a2[0] + a2[1];
+        }
+        if (edge) {
+          // outputs whose taps leave [0, 2 len - 1] (z index clamped), and the conv's zero padding outside the row
+          const int zlast = 2 * len - 1, zbase = 2 * (tA - 4) + 1;           // zs[m - zbase] = z[m]
+          const fh_amp_seg* SG = &G->seg[seg_idx];
+#pragma unroll 1
+          for (int r = 0; r < F_PPT; ++r) {
+            const int i = tA + F_PPT * lane + r;
+            if (i < 0 || i >= len) out[h][r] = 0.f;
+            else if (!(2 * i - 5 >= 0 && 2 * i + 6 <= zlast) && F_PPT * lane + r < F_NOUT) {
+              float acc = 0.f;
+#pragma unroll
+              for (int k = 0; k < 12; ++k) {
+                int m = 2 * i + k - 5;
+                m = m < 0 ? 0 : (m > zlast ? zlast : m);
+                acc = fmaf(zs[m - zbase], SG->down_taps[k], acc);
+              }
+              out[h][r] = acc;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < F_PPT; ++r) *reinterpret_cast<f32x2*>(sl + wofs[r]) = (f32x2){out[0][r], out[1][r]};
+  };
+
+  // ---- accumulators: [point][row tile]: rows 4 (lane >> 4) .. + 3 of tile column lane & 15 --------------------------
+  f32x4 acc[8][MA];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int m = 0; m < MA; ++m) acc[x][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- K loop: stages (segment, chunk, tap group) ---------------------------------------------------------------------
+  int sbuf = 0, wb = 0;
+  Seg S = load_seg(0);
+  load_x(S, 0, true);
+  load_w(S.u, true);
+  __syncthreads();                                   // taps
+  store_w(0);
+  stage_pair(0, 0);
+  __syncthreads();
+
+  auto run_segment = [&](auto gc, int sidx) {
+    constexpr int GC = decltype(gc)::value;
+    const bool more_seg = sidx + 1 < nseg;
+    const Seg SN = load_seg(more_seg ? sidx + 1 : sidx);
+    // sample e' = 0 .. 4 GC + 3 of this segment's tiles is slab sample e = (cmax - center) + e'
+    int toff[4 * GC + 4];
+    {
+      const int shift = cmax - S.center;
+#pragma unroll
+      for (int e = 0; e < 4 * GC + 4; ++e) {
+        const int ee = shift + e, q = (ee * 13) >> 6;                   // ee / 5 for ee <= 24
+        toff[e] = ((ee - 5 * q) * 4 * PL + q) * 2;
+      }
+    }
+    for (int c = 0; c < nch; ++c) {
+      const bool last_c = c + 1 == nch;
+      const float* const sl = slab0 + sbuf * F_SLAB_BUF + rd_base;
+      // the next chunk's rows (this segment's, or the next segment's first)
+      const bool nx = !last_c || more_seg;
+      load_x(last_c ? SN : S, last_c ? 0 : c + 1, nx);
+#pragma unroll
+      for (int g = 0; g < GC; ++g) {
+        const bool last_g = g + 1 == GC;
+        // next weight stage
+        const bool nw = !last_g || nx;
+        const float* wnext = (last_g && last_c) ? SN.u : S.u + (size_t)(c * GC + g + 1) * f_wstage<MA>();
+        load_w(wnext, nw);
+        const float* const wl = wbuf0 + wb * f_wstage<MA>();
+        // the tile's 8 samples of this tap group, both channels of the pair (one ds_read_b64 each)
+        f32x2 xr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[e] = *reinterpret_cast<const f32x2*>(sl + toff[4 * g + e]);
+        // B^T d for the 8 points (0, 1, -1, 2, -2, 1/2, -1/2, inf), both channels of the pair at once
+        const f32x2 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3], x4 = xr[4], x5 = xr[5], x6 = xr[6], x7 = xr[7];
+        f32x2 V[8];
+        V[0] = __builtin_elementwise_fma((f32x2)(-5.25f), x4, __builtin_elementwise_fma((f32x2)(5.25f), x2, x6)) - x0;
+        V[7] = __builtin_elementwise_fma((f32x2)(-5.25f), x5, __builtin_elementwise_fma((f32x2)(5.25f), x3, x7)) - x1;
+        {
+          const f32x2 e = __builtin_elementwise_fma((f32x2)(-4.25f), x4, x6 + x2);
+          const f32x2 o = __builtin_elementwise_fma((f32x2)(-4.25f), x3, x1 + x5);
+          V[1] = e + o;
+          V[2] = e - o;
+        }
+        {
+          const f32x2 e = __builtin_elementwise_fma((f32x2)(-1.25f), x4, __builtin_elementwise_fma((f32x2)(0.25f), x2, x6));
+          const f32x2 o = __builtin_elementwise_fma((f32x2)(2.f), x5, __builtin_elementwise_fma((f32x2)(-2.5f), x3, x1 * 0.5f));
+          V[3] = e + o;
+          V[4] = e - o;
+        }
+        {
+          const f32x2 e = __builtin_elementwise_fma((f32x2)(-5.f), x4, __builtin_elementwise_fma((f32x2)(4.f), x2, x6));
+          const f32x2 o = __builtin_elementwise_fma((f32x2)(0.5f), x5, __builtin_elementwise_fma((f32x2)(-2.5f), x3, x1 * 2.f));
+          V[5] = e + o;
+          V[6] = e - o;
+        }
+        // A fragments: [point][lane][row tile pair][2] (+ [point][lane][2] for an odd row tile count), read point by point
+        // (a point's two k-steps accumulate back to back into the same tiles)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          if ((x & 1) == 0) __builtin_amdgcn_sched_barrier(0);        // (at most two points' A fragments in flight)
+          f32x4 a01 = {0.f, 0.f, 0.f, 0.f};
+          f32x2 a2 = {0.f, 0.f};
+          if (MA >= 2) a01 = *reinterpret_cast<const f32x4*>(wl + (x * 64 + lane) * 4);
+          if (MA & 1) a2 = *reinterpret_cast<const f32x2*>(wl + (MA >= 2 ? 2048 : 0) + (x * 64 + lane) * 2);
+#pragma unroll
+          for (int m = 0; m < MA; ++m)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const float a = (MA >= 2 && m < 2) ? a01[2 * m + s] : a2[s];
+              acc[x][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, V[x][s], acc[x][m], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nw) store_w(wb ^ 1);
+        if (last_g && nx) stage_pair(sbuf ^ 1, last_c ? sidx + 1 : sidx);
+        __syncthreads();
+        wb ^= 1;
+      }
+      sbuf ^= 1;
+    }
+    S = SN;
+  };
+  // Segments are sorted by tap-group count, descending (host: make_amp_group): one loop per count, so that the accumulators
+  // do not pass through the merge of a three-way branch (the compiler then keeps two copies of them)
+  int sg = 0;
+  auto run_all = [&](auto gc) {
+    while (sg < nseg && S.ngrp == decltype(gc)::value) {
+      run_segment(gc, sg);
+      ++sg;
+    }
+  };
+  run_all(std::integral_constant<int, 3>{});
+  run_all(std::integral_constant<int, 2>{});
+  run_all(std::integral_constant<int, 1>{});
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------------
+  // (the last stage ended on a barrier: slabs and weight buffers are free; Y rounds alternate between two halves)
+  float* const Y0 = lds;
+  const int nres = uni(G->nres);
+  const float scale = G->scale;
+  const float* const bias = uni(G->bias);
+  const float* const outp = uni((const float*)G->out);
+  const float* const resp[3] = {uni(G->res[0]), uni(G->res[1]), uni(G->res[2])};
+  const size_t oslab = (size_t)bb * channels * (size_t)len;
+  const unsigned slab_bytes = (unsigned)channels * (unsigned)len * 4u;
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(outp + oslab, slab_bytes);
+  const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? resp[0] + oslab : nullptr, nres > 0 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? resp[1] + oslab : nullptr, nres > 1 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? resp[2] + oslab : nullptr, nres > 2 ? slab_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (unsigned)channels * 4u : 0u);
+  // store items of this thread: vectors item = tid + 256 i of a round's 16 rows x TB / 4
+  const int vpr = TB >> 2;
+  int srow[5], scol[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int item = tid + 256 * i;
+    srow[i] = item / vpr;
+    scol[i] = (item - srow[i] * vpr) * 4;
+  }
+  // this lane's tile: outputs q = 0..4 at block-relative position d (5 tit + q) + tp
+  const int ypos = d * 5 * tit + tp;
+#pragma unroll
+  for (int m = 0; m < MA; ++m) {
+    float* const Y = Y0 + (m & 1) * 16 * F_YP;
+    {
+      const f32x4 s1 = acc[1][m] + acc[2][m], d1 = acc[1][m] - acc[2][m], s2 = acc[3][m] + acc[4][m], d2 = acc[3][m] - acc[4][m],
+                  s3 = acc[5][m] + acc[6][m], d3 = acc[5][m] - acc[6][m];
+      f32x4 y[5];
+      y[0] = ((acc[0][m] + s1) + s2) + s3;
+      y[1] = __builtin_elementwise_fma((f32x4)(0.5f), d3, __builtin_elementwise_fma((f32x4)(2.f), d2, d1));
+      y[2] = __builtin_elementwise_fma((f32x4)(0.25f), s3, __builtin_elementwise_fma((f32x4)(4.f), s2, s1));
+      y[3] = __builtin_elementwise_fma((f32x4)(0.125f), d3, __builtin_elementwise_fma((f32x4)(8.f), d2, d1));
+      y[4] = __builtin_elementwise_fma((f32x4)(0.0625f), s3, __builtin_elementwise_fma((f32x4)(16.f), s2, s1)) + acc[7][m];
+      if (tile_ok) {
+        float* yw = Y + (4 * kq) * F_YP + ypos;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 5; ++q) yw[r * F_YP + q * d] = y[q][r];
+      }
+    }
+    // requests of the store phase (before the barrier: their latency hides under it)
+    unsigned soff[5];
+    bool ok[5];
+    float bv[5];
+    u32x4 rs[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int co = 16 * m + srow[i];
+      const int t = t0 + scol[i];
+      ok[i] = srow[i] < 16 && co < channels && t < len;
+      soff[i] = ((unsigned)co * (unsigned)len + (unsigned)t) * 4u;
+      bv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, ok[i] ? (unsigned)co * 4u : 0x80000000u, 0, 0));
+    }
+    if (VEC) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) rs[i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, ok[i] ? soff[i] : 0x80000000u, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(Y + (srow[i] < 16 ? srow[i] : 0) * F_YP + scol[i]);
+      if (VEC) {
+        f32x4 o = {yv[0] + bv[i], yv[1] + bv[i], yv[2] + bv[i], yv[3] + bv[i]};
+        if (nres > 0) o += (f32x4){__uint_as_float(rs[i][0]), __uint_as_float(rs[i][1]), __uint_as_float(rs[i][2]), __uint_as_float(rs[i][3])};
+        if (nres > 1) {            // (the stage-closing group only: requested here)
+          const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rr1, ok[i] ? soff[i] : 0x80000000u, 0, 0);
+          o += (f32x4){__uint_as_float(t1[0]), __uint_as_float(t1[1]), __uint_as_float(t1[2]), __uint_as_float(t1[3])};
+        }
+        if (nres > 2) {
+          const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(rr2, ok[i] ? soff[i] : 0x80000000u, 0, 0);
+          o += (f32x4){__uint_as_float(t2[0]), __uint_as_float(t2[1]), __uint_as_float(t2[2]), __uint_as_float(t2[3])};
+        }
+        o *= scale;
+        const u32x4 ou = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(ou, ro, ok[i] ? soff[i] : 0x80000000u, 0, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned off = (ok[i] && t0 + scol[i] + q < len) ? soff[i] + 4u * q : 0x80000000u;
+          float o = yv[q] + bv[i];
+          if (nres > 0) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));
+          if (nres > 1) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off, 0, 0));
+          if (nres > 2) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o * scale), ro, off, 0, 0);
+        }
+      }
+    }
+    // (the next round writes the other half of the staging; the one after it is behind the next round's barrier)
+  }
+}
+
+template <int MA, bool VEC, bool ACT>
+int launch_amp(const fh_amp_group* groups, int n_groups, int channels, int dilation, int total_tiles, hipStream_t stream) {
+  static std::atomic<bool> lds_opt_in[FH_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) {
+    fh_set_error("fh_amp_actconv_f32: no current HIP device (or ordinal >= %d)", FH_MAX_DEVICES);
+    return FH_E_LAUNCH;
+  }
+  constexpr int bytes = f_lds_floats<MA>() * 4;
+  if (!lds_opt_in[dev].load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute((const void*)amp_actconv_kernel<MA, VEC, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      fh_set_error("fh_amp_actconv_f32: cannot reserve %d bytes of LDS on device %d: %s", bytes, dev, hipGetErrorString(e));
+      return FH_E_LAUNCH;
+    }
+    lds_opt_in[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((amp_actconv_kernel<MA, VEC, ACT>), dim3((unsigned)total_tiles), dim3(F_THREADS), bytes, stream, groups, n_groups,
+                     channels, dilation);
+  FH_CHECK_LAUNCH("fh_amp_actconv_f32");
+  return FH_OK;
+}
+
+}  // namespace
+
+extern "C" int fh_sizeof_amp_group(void) { return (int)sizeof(fh_amp_group); }
+
+extern "C" int fh_amp_tile_len(int dilation) { return dilation >= 1 && dilation <= F_MAX_D ? f_tb(dilation) : -1; }
+
+extern "C" int fh_amp_max_channels(void) { return 48; }
+
+extern "C" int fh_amp_actconv_f32(const fh_amp_group* groups, int n_groups, int channels, int dilation, int total_tiles,
+                                  int flags, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && total_tiles > 0, "fh_amp_actconv_f32: bad sizes");
+  FH_CHECK_ARG(channels >= 8 && channels <= 48 && channels % 8 == 0, "fh_amp_actconv_f32: %d channels (8 .. 48, a multiple of 8)", channels);
+  FH_CHECK_ARG(dilation >= 1 && dilation <= F_MAX_D, "fh_amp_actconv_f32: dilation %d (1 .. %d)", dilation, F_MAX_D);
+  FH_CHECK_ARG(flags >= 0 && flags <= 3, "fh_amp_actconv_f32: flags %d (bit 0: rows 16-byte aligned, bit 1: no activation)", flags);
+  const int ma = (channels + 15) / 16;
+  const bool vec = flags & 1, act = !(flags & 2);
+  hipStream_t st = (hipStream_t)stream;
+#define FH_AMP_CASE(MA)                                                                                          \
+  case MA:                                                                                                       \
+    if (!act) return vec ? launch_amp<MA, true, false>(groups, n_groups, channels, dilation, total_tiles, st)    \
+                         : launch_amp<MA, false, false>(groups, n_groups, channels, dilation, total_tiles, st);  \
+    return vec ? launch_amp<MA, true, true>(groups, n_groups, channels, dilation, total_tiles, st)               \
+               : launch_amp<MA, false, true>(groups, n_groups, channels, dilation, total_tiles, st);
+  switch (ma) {
+    FH_AMP_CASE(1)
+    FH_AMP_CASE(2)
+    FH_AMP_CASE(3)
+  }
+#undef FH_AMP_CASE
+  return FH_E_ARG;
+}

@@ -20,7 +20,7 @@ CONV_MAX_TAPS = 16
 CONV_MAX_SEG = 3
 CONV_MAX_HALO = 64
 
-ABI_VERSION = 2            # FH_ABI_VERSION of include/flowhigh_hip.h
+ABI_VERSION = 3            # FH_ABI_VERSION of include/flowhigh_hip.h
 EPI_LINEAR, EPI_GEGLU, EPI_MAG, EPI_LOGCLAMP = 0, 1, 2, 3
 
 
@@ -51,6 +51,17 @@ class WinoGroup(C.Structure):
 class ActGroup(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("alpha", C.c_void_p), ("inv_beta", C.c_void_p),
                 ("up_taps", C.c_float * 12), ("down_taps", C.c_float * 12), ("len", C.c_int32), ("tile_base", C.c_int32)]
+
+
+class AmpSeg(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("u", C.c_void_p), ("alpha", C.c_void_p), ("inv_beta", C.c_void_p),
+                ("up_taps", C.c_float * 12), ("down_taps", C.c_float * 12), ("ngrp", C.c_int32), ("center", C.c_int32)]
+
+
+class AmpGroup(C.Structure):
+    _fields_ = [("seg", AmpSeg * CONV_MAX_SEG), ("bias", C.c_void_p), ("res", C.c_void_p * CONV_MAX_SEG),
+                ("out", C.c_void_p), ("nseg", C.c_int32), ("nres", C.c_int32), ("len", C.c_int32),
+                ("tile_base", C.c_int32), ("scale", C.c_float), ("pad_", C.c_int32)]
 
 
 class SumJob(C.Structure):
@@ -91,6 +102,10 @@ _SIGS = {
     "fh_act_set_blocks_per_cu": [_I],
     "fh_act_get_blocks_per_cu": [],
     "fh_act1d_ragged_f32": [_P, _I, _I, _I, _I, C.c_longlong, _I, _P],
+    "fh_sizeof_amp_group": [],
+    "fh_amp_tile_len": [_I],
+    "fh_amp_max_channels": [],
+    "fh_amp_actconv_f32": [_P, _I, _I, _I, _I, _I, _P],
     "fh_sizeof_sum_job": [],
     "fh_sum_multi_f32": [_P, _I, C.c_longlong, _P],
     "fh_attention_seg_f32": [_P, _P, _P, _I, _I, _I, _F, _P],
@@ -142,7 +157,8 @@ def lib():
     if L.fh_abi_version() != ABI_VERSION:
         raise HipError("libflowhigh_hip.so ABI version mismatch")
     if L.fh_sizeof_conv_group() != C.sizeof(ConvGroup) or L.fh_sizeof_act_group() != C.sizeof(ActGroup) \
-            or L.fh_sizeof_wino_group() != C.sizeof(WinoGroup) or L.fh_sizeof_sum_job() != C.sizeof(SumJob):
+            or L.fh_sizeof_wino_group() != C.sizeof(WinoGroup) or L.fh_sizeof_sum_job() != C.sizeof(SumJob) \
+            or L.fh_sizeof_amp_group() != C.sizeof(AmpGroup):
         raise HipError("descriptor struct layout mismatch between hip.py and flowhigh_hip.h")
     _lib = L
     return L

@@ -325,6 +325,88 @@ def pack_wino54_weight(w, cout_pad):
     return p.contiguous()
 
 
+def pack_amp_weight(w, channels=None):
+    """Conv1d weight [co, ci, k] (co, ci <= channels <= 48, channels % 8 == 0) -> the narrow-stage kernel's transformed weights
+    (amp_fused.hip, flowhigh_hip.h: fh_amp_seg.u): per (8-channel chunk, group of 4 taps) one stage of 1024 ceil(C / 16) floats
+    = blockA [8 points][64 lanes][4] (row tiles 0, 1) | blockB [8 points][64 lanes][2] (the last row tile of an odd count);
+    lane l = 16 kq + r holds U[g][xi][16 m + r][8 chunk + 2 kq + s], U = G8 w in float64 as pack_wino54_weight."""
+    co, ci, k = w.shape
+    c = max(co, ci) if channels is None else channels
+    if c % 8 or c > 48 or co > c or ci > c:
+        raise ValueError(f"narrow-stage conv: {co} x {ci} channels do not fit {c} (a multiple of 8, <= 48)")
+    ng, ma, nch = -(-k // 4), -(-c // 16), c // 8
+    wp = torch.zeros(16 * ma, c, 4 * ng, dtype=torch.float64)
+    wp[:co, :ci, :k] = w.double()
+    gm = torch.tensor(_WINO54_G, dtype=torch.float64)
+    u = torch.einsum("xj,ocgj->gxoc", gm, wp.view(16 * ma, c, ng, 4))            # [G, 8, 16 ma, c]
+    # -> [chunk, g, xi, kq, r, m, s]
+    u = u.view(ng, 8, ma, 16, nch, 4, 2).permute(4, 0, 1, 5, 3, 2, 6).float()    # [chunk, g, xi, kq, r, m, s]
+    parts = []
+    if ma >= 2:
+        parts.append(u[..., :2, :].reshape(nch, ng, 8 * 64 * 4))
+    if ma % 2:
+        parts.append(u[..., ma - 1, :].reshape(nch, ng, 8 * 64 * 2))
+    return torch.cat(parts, dim=-1).contiguous()
+
+
+def amp_tile_len(d):
+    """Outputs per block and row of the narrow-stage kernel at dilation d (fh_amp_tile_len)."""
+    return 5 * d * 4 * (16 // d)
+
+
+AMP_MAX_D = 6             # F_MAX_D of amp_fused.hip
+
+
+def make_amp_seg(x, u, act, k, center=None):
+    """One K segment of a narrow-stage group: conv weights `u` (pack_amp_weight) applied to Activation1d(x) with the
+    parameters `act` (dict alpha, inv_beta, up, down: Vocoder.act_params), or to x itself when act is None."""
+    s = hip.AmpSeg()
+    s.x, s.u, s.ngrp = _addr(x), _addr(u), -(-k // 4)
+    s.center = (k - 1) // 2 if center is None else center
+    if act is not None:
+        s.alpha, s.inv_beta = hip.ptr(act["alpha"]), hip.ptr(act["inv_beta"])
+        for i in range(12):
+            s.up_taps[i] = act["up"][i]
+            s.down_taps[i] = act["down"][i]
+    return s
+
+
+def make_amp_group(segs, bias, res, out, length, scale=1.0):
+    g = hip.AmpGroup()
+    # the kernel walks the segments in one pass per tap-group count, largest first
+    segs = sorted(segs, key=lambda s: -s.ngrp)
+    cmax = max(s.center for s in segs)
+    if any(cmax - s.center + 4 * s.ngrp + 3 > 16 or s.ngrp > 3 for s in segs):
+        raise NotImplementedError("narrow-stage kernel: kernel sizes of the group's segments are too far apart (or above 12 taps)")
+    for i, s in enumerate(segs):
+        g.seg[i] = s
+    g.nseg, g.nres = len(segs), len(res)
+    g.bias = _addr(bias)
+    for i, r in enumerate(res):
+        g.res[i] = _addr(r)
+    g.out, g.len, g.scale = _addr(out), length, scale
+    return g
+
+
+def set_amp_tile_bases(groups, batch, dilation):
+    """Fill tile_base (prefix of batch * ceil(len / tile)) of a launch's groups; returns the launch's block count."""
+    tb, base = amp_tile_len(dilation), 0
+    for g in groups:
+        g.tile_base = base
+        base += batch * -(-g.len // tb)
+    return base
+
+
+def amp_actconv(groups, batch, channels, dilation, device, act=True):
+    """Upload descriptors and enqueue one narrow-stage launch (test / one-off use)."""
+    total = set_amp_tile_bases(groups, batch, dilation)
+    d = hip.to_device_struct_array(groups, device)
+    flags = int(all(g.len % 4 == 0 for g in groups)) | (0 if act else 2)
+    hip.check(hip.lib().fh_amp_actconv_f32(d.data_ptr(), len(groups), channels, dilation, total, flags, hip.stream()),
+              "fh_amp_actconv_f32")
+    return d
+
+
 WINO_BF16X6 = 16          # FH_WINO_BF16X6 of flowhigh_hip.h: tile_cfg flag, three-piece bf16 weights
 WINO_XCD_RANGES = 32      # FH_WINO_XCD_RANGES: tile_cfg flag, blocks -> XCDs by time range instead of by weight panel
 WINO_NOVL = 64            # FH_WINO_NOVL: tile_cfg flag, some row of the launch is not 16-byte aligned although len % 4 == 0

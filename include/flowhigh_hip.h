@@ -27,7 +27,7 @@ extern "C" {
 #define FH_E_ARG (-1)     /* bad argument / unsupported shape */
 #define FH_E_LAUNCH (-2)  /* HIP launch error */
 
-#define FH_ABI_VERSION 2
+#define FH_ABI_VERSION 3
 
 int fh_abi_version(void);
 const char* fh_last_error(void);
@@ -276,6 +276,59 @@ int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, 
  * FH_ACT_BLOCKS). */
 int fh_act_set_blocks_per_cu(int blocks);
 int fh_act_get_blocks_per_cu(void);
+
+/* ------------------------------------------------------------------------------------
+ * Narrow stages (C <= 48 channels): Activation1d and the Conv1d behind it in ONE launch.
+ * Replaces one `xt = self.activations[i](x); xt = conv(xt)` pair of an AMP block,
+ *   models/bigvgan/models.py:63-72 (AMPBlock1: acts1 -> convs1[dilated] and acts2 -> convs2 "+ x") and :108-117
+ *   (AMPBlock2), Activation1d = alias_free_torch/act.py:23-28, incl. the "xs / num_kernels" average of the stage's
+ *   blocks (:181-187) as K segments of one group:
+ *     out[b, co, t] = scale * ( bias[co] + sum_r res[r][b, co, t]
+ *                               + sum_seg sum_ci sum_{j<k} w_seg[co, ci, j] * act_seg(x_seg)[b, ci, t + (j - center) * dilation] )
+ *   with act_seg(x) read as 0 outside [0, len) (the conv's zero padding) and the activation's own replicate padding at
+ *   the row ends (fh_act_group above).  The activated tensor exists in LDS only; all tensors are plain [B, C, len]
+ *   whatever the dilation.  The conv is evaluated in the Winograd F(5,4) form (fh_conv_wino54_f32): k <= 12 odd,
+ *   dilation <= 6, (max center of the group's segments - center) + 4 ngrp + 3 <= 16.
+ * u = host-transformed weights (flowhigh_amd/packing.py: pack_amp_weight), float
+ *   [C/8 chunks][ngrp][ blockA: [8 points][64 lanes][4]  (ceil(C/16) >= 2)  |  blockB: [8 points][64 lanes][2]  (ceil(C/16) odd) ]
+ *   lane l = 16 kq + r: blockA[xi][l][2 m + s] = U[g][xi][co = 16 m + r][ci = 8 chunk + 2 kq + s] for the row tiles m = 0, 1,
+ *   blockB[xi][l][s] the same for the last row tile of an odd count; U[g][xi] = sum_j G8[xi][j] w[:, :, 4 g + j] (float64 on
+ *   the host, taps past k and rows past C zero): 1024 ceil(C/16) floats per (chunk, tap group) stage.
+ * Groups may have different `len` (ragged batches: batch 1 per group): block b of the launch works on the group with the
+ * largest tile_base <= b; tile_base = sum over the groups before of batch * ceil(len / fh_amp_tile_len(dilation)),
+ * total_tiles = the sum over all groups.  A group's batch items are [batch, C, len] tensors behind its pointers.
+ * flags: bit 0 = every row of every group is 16-byte aligned (len % 4 == 0: vector accesses; same bits without);
+ *        bit 1 = no activation (act_seg = identity: the conv alone; alpha / inv_beta / taps are not read).
+ * --------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x;        /* [B, C, len]: the activation's input */
+  const float* u;        /* transformed weights, layout above */
+  const float* alpha;    /* [C] */
+  const float* inv_beta; /* [C] */
+  float up_taps[12];
+  float down_taps[12];
+  int32_t ngrp;          /* ceil(k / 4) */
+  int32_t center;        /* (k - 1) / 2 */
+} fh_amp_seg;
+
+typedef struct {
+  fh_amp_seg seg[FH_CONV_MAX_SEG];
+  const float* bias;                 /* [C] or NULL */
+  const float* res[FH_CONV_MAX_SEG]; /* each [B, C, len] or NULL */
+  float* out;                        /* [B, C, len] */
+  int32_t nseg;
+  int32_t nres;
+  int32_t len;
+  int32_t tile_base;
+  float scale;
+  int32_t pad_;
+} fh_amp_group;
+
+int fh_sizeof_amp_group(void);
+int fh_amp_tile_len(int dilation);     /* outputs per block and row: 320, 320, 300, 320, 300, 240 for dilation 1 .. 6; -1 beyond */
+int fh_amp_max_channels(void);         /* 48 */
+int fh_amp_actconv_f32(const fh_amp_group* groups, int n_groups, int channels, int dilation, int total_tiles,
+                       int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 MFMA GEMM:  C[M, N] = epilogue( A[M, K] * W[N, K]^T )
