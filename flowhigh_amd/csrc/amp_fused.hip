@@ -49,6 +49,13 @@ constexpr int F_SLAB = 3840;               // floats of a slab (one 8-channel ch
 constexpr int F_SLAB_BUF = F_SLAB + 128;   // + one trash pair per lane
 constexpr int F_YP = 324;                  // row pitch of the output staging
 constexpr int F_MAX_D = 6;
+// tuning switches (A/B builds: tools/build_variant.sh)
+#ifndef F_EPI_EARLY_MA      // row-tile counts up to which the last K step requests round 0's bias / residual (registers)
+#define F_EPI_EARLY_MA 2
+#endif
+#ifndef F_A_AHEAD           // A fragments requested one pair of points ahead of their MFMAs
+#define F_A_AHEAD 1
+#endif
 
 // tiles per dilation phase and plane length (index units) of the slab
 __host__ __device__ constexpr int f_ntp(int d) { return 4 * (16 / d); }
@@ -60,8 +67,10 @@ static_assert(40 * 1 * f_pl(1) <= F_SLAB && 40 * 2 * f_pl(2) <= F_SLAB && 40 * 3
 template <int MA>
 constexpr int f_wstage() { return 1024 * MA; }           // floats of one (chunk, tap group) weight stage
 
+constexpr int F_YBUF = 16 * F_YP > 4 * F_SCR ? 16 * F_YP : 4 * F_SCR;     // output staging | the four waves' activation scratch
+
 template <int MA>
-constexpr int f_lds_floats() { return 2 * F_SLAB_BUF + 2 * f_wstage<MA>() + 4 * F_SCR + 3 * 32; }
+constexpr int f_lds_floats() { return 2 * F_SLAB_BUF + 2 * f_wstage<MA>() + F_YBUF + 2 * 3 * 32; }
 
 // sin^2 of two values (act1d.hip: sin_squared2; |a| >= 32768 is patched by the caller)
 __device__ __forceinline__ f32x2 f_sin_squared2(f32x2 a) {
@@ -82,61 +91,78 @@ __device__ __noinline__ float f_sin_squared_slow(float a) {
 }
 
 // MA: 16-row output tiles (channels <= 16 MA).  VEC: rows are 16-byte aligned (len % 4 == 0 for every group).
-// ACT = false: the activation is skipped (x is staged as it is): conv-only form for tests and measurements.
+// ACT = false: no activation (x is the conv's input): the form the launch plans use -- the activation stays a launch of its own
+// (act1d.hip), see "measured" in the header.
+//
+// Persistent blocks: block b works on tiles b, b + gridDim, ... of the launch's flattened (group, batch item, tile) list, and the
+// chunk pipeline runs across tile boundaries: the last K step of a tile requests and stages the first chunk (rows, weight stage)
+// of the block's NEXT tile and the bias / first residual of its own epilogue, so that no HBM round trip is waited for between
+// tiles.  (One block per tile spent more time outside its K loop than inside at 24 channels: 3-9 K steps of ~0.6 us against
+// ~6 us of descriptor reads, first loads, barriers and store phases.)
 template <int MA, bool VEC, bool ACT>
-__global__ __attribute__((amdgpu_flat_work_group_size(F_THREADS, F_THREADS), amdgpu_waves_per_eu(2, 2)))
-void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, int n_groups, int channels, int d) {
+#ifndef F_WAVES_PER_EU
+#define F_WAVES_PER_EU 2
+#endif
+__global__ __attribute__((amdgpu_flat_work_group_size(F_THREADS, F_THREADS), amdgpu_waves_per_eu(F_WAVES_PER_EU, F_WAVES_PER_EU)))
+void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_tile* __restrict__ tiles, int channels, int d,
+                        int total_tiles, int cmax) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const slab0 = lds;
   float* const wbuf0 = lds + 2 * F_SLAB_BUF;
-  float* const scr0 = wbuf0 + 2 * f_wstage<MA>();
-  f32x2* const taps = reinterpret_cast<f32x2*>(scr0 + 4 * F_SCR);        // [seg][16]: 0..5 up pairs (x 2), 6..11 down pairs
+  float* const ybuf = wbuf0 + 2 * f_wstage<MA>();     // output staging of the epilogue | wave-private scratch of the activation
+  f32x2* const taps = reinterpret_cast<f32x2*>(ybuf + F_YBUF);        // [tile parity][seg][16]: 0..5 up pairs (x 2), 6..11 down pairs
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bid = blockIdx.x;
-
-  // ---- block -> (group, batch item, tile): groups carry the prefix of their tile counts ------------------------------
-  int cnt = 0;
-  for (int base = 0; base < n_groups; base += 64) {
-    const int idx = base + lane;
-    const bool le = idx < n_groups && groups[idx].tile_base <= bid;
-    cnt += __popcll(__ballot(le));
-  }
-  const fh_amp_group* __restrict__ const G = groups + uni(cnt - 1);
-  const int len = uni(G->len);
-  const int NTP = f_ntp(d), TB = 5 * d * NTP, PL = f_pl(d), NT = d * NTP;
-  const int tpr = (len + TB - 1) / TB;
-  const int local = bid - uni(G->tile_base);
-  const int bb = uni(local / tpr);
-  const int t0 = (local - bb * tpr) * TB;
-  const int nseg = uni(G->nseg);
-  int cmax = 0;
-  for (int s = 0; s < nseg; ++s) cmax = max(cmax, uni(G->seg[s].center));
-  const int A = (cmax * d + 3) & ~3;                   // the activation pass starts at tA = t0 - A (16-byte aligned)
-  const int tA = t0 - A;
+  d = uni(d);
+  cmax = uni(cmax);
+  const int NTP = uni(f_ntp(d)), TB = 5 * d * NTP, PL = uni(f_pl(d)), NT = d * NTP;
+  const int A = (cmax * d + 3) & ~3;                   // a tile's staged range starts at tA = t0 - A (16-byte aligned)
   const int nch = channels >> 3;
-  float* const xs = scr0 + wv * F_SCR;
+  float* const xs = ybuf + wv * F_SCR;
   float* const zs = xs + F_XS;
 
-  // taps of every segment -> LDS (read as broadcasts by the activation passes)
-  if (ACT && tid < 12 * nseg) {
-    const int s = tid / 12, e = tid - 12 * s;
-    const bool up = e < 6;
-    const int j = up ? e : e - 6;
-    const float* src = up ? G->seg[s].up_taps : G->seg[s].down_taps;
-    const int i0 = up ? 10 - 2 * j : 2 * j;
-    const float sc = up ? 2.f : 1.f;                  // (the 2x of UpSample1d folded in: exact)
-    taps[s * 16 + e] = (f32x2){sc * src[i0], sc * src[i0 + 1]};
-  }
+  // ---- tile -> (group, batch item, first output): one 16-byte entry of the host-made tile list ---------------------------
+  // (found in the kernel -- prefix search over the groups, two integer divisions -- a tile cost ~150 instructions and a chain
+  // of four dependent loads before its first request could leave)
+  struct Tile {
+    const fh_amp_group* G;
+    int len, bb, t0, nseg;
+    bool valid;
+  };
+  auto locate = [&](int tile) {
+    Tile T;
+    T.valid = tile < total_tiles;
+    const fh_amp_tile* e = tiles + (T.valid ? tile : 0);
+    T.G = groups + uni(e->group);
+    T.bb = uni(e->batch_item);
+    T.t0 = uni(e->t0);
+    T.len = uni(e->len);
+    T.nseg = uni(T.G->nseg);
+    return T;
+  };
+  // taps of every segment of a tile's group -> LDS (read as broadcasts by the activation passes)
+  auto publish_taps = [&](const Tile& T, int par) {
+    if (ACT && tid < 12 * T.nseg) {
+      const int s = tid / 12, e = tid - 12 * s;
+      const bool up = e < 6;
+      const int j = up ? e : e - 6;
+      const float* src = up ? T.G->seg[s].up_taps : T.G->seg[s].down_taps;
+      const int i0 = up ? 10 - 2 * j : 2 * j;
+      const float sc = up ? 2.f : 1.f;                // (the 2x of UpSample1d folded in: exact)
+      taps[(par * 3 + s) * 16 + e] = (f32x2){sc * src[i0], sc * src[i0 + 1]};
+    }
+  };
 
-  // ---- slab geometry of this lane --------------------------------------------------------------------------------
-  // writer: activation output j = 6 lane + r is sample t = tA + j: rel = j - A = d u + p, slab sample w = u + cmax of phase p
-  int wofs[F_PPT];
+  // ---- slab geometry of this lane (the same for every tile: the launch's largest center `cmax` places the samples) ------
+  // writer: sample j of the staged range is t = tA + j: rel = j - A = d u + p, slab sample w = u + cmax of phase p.
+  // With the activation a lane holds outputs j = 6 lane + r; without it the quads j = 4 (lane + 64 v) + e of its two loads.
+  constexpr int NWO = ACT ? F_PPT : 8;
+  int wofs[NWO];
 #pragma unroll
-  for (int r = 0; r < F_PPT; ++r) {
-    const int j = F_PPT * lane + r;
+  for (int r = 0; r < NWO; ++r) {
+    const int j = ACT ? F_PPT * lane + r : 4 * (lane + 64 * (r >> 2)) + (r & 3);
     const int rel = j - A;
     int u = rel / d;
     int p = rel - u * d;
@@ -153,43 +179,60 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, int n_groups, i
   if (!tile_ok) tl = NT - 1;
   const int tp = tl / NTP, tit = tl - tp * NTP;
   const int rd_base = ((tp * 5 * 4 + kq) * PL + tit) * 2;
+  const int ypos = d * 5 * tit + tp;                   // outputs q = 0..4 of the lane's tile at block-relative d (5 tit + q) + tp
+  // store items of this thread: vectors item = tid + 256 i of a round's 16 rows x TB / 4, the same in every round and tile
+  // (row << 16 | first column, unpacked behind an opaque move in the epilogue: left visible, the compiler makes every round's
+  // offsets of every item loop-invariant values and carries ~30 registers of them through the K loop)
+  const int vpr = TB >> 2;
+  int sitem[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int item = tid + 256 * i;
+    const int row = item / vpr;
+    sitem[i] = (row << 16) | ((item - row * vpr) * 4);
+  }
 
   // ---- loads --------------------------------------------------------------------------------------------------------
-  struct Seg {
+  struct Seg {                                         // one K segment of one tile (wave-uniform)
     const float* x;
     const float* u;
     const float* alpha;
     const float* inv_beta;
-    int ngrp, center;
+    int ngrp, center, len, bb, tA, tapi;
   };
-  auto load_seg = [&](int s) {
+  auto load_seg = [&](const Tile& T, int s, int par) {
     Seg S;
-    const fh_amp_seg* P = &G->seg[s];
+    const fh_amp_seg* P = &T.G->seg[s];
     S.x = uni(P->x);
     S.u = uni(P->u);
     S.alpha = uni(P->alpha);
     S.inv_beta = uni(P->inv_beta);
     S.ngrp = uni(P->ngrp);
     S.center = uni(P->center);
+    S.len = uni(T.len);
+    S.bb = uni(T.bb);
+    S.tA = uni(T.t0 - A);
+    S.tapi = (par * 3 + s) * 16;
     return S;
   };
-  u32x4 xq[2][2];                                    // [channel of the pair][vector]: x[tA - 8 + 4 f ..], f = lane, lane + 64
+  u32x4 xq[2][2];                                    // [channel of the pair][vector]: x[tA (- 8) + 4 f ..], f = lane, lane + 64
   float al[2], ib[2];
   auto load_x = [&](const Seg& S, int chunk, bool valid) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int ch = chunk * 8 + 2 * wv + h;
-      const __amdgpu_buffer_rsrc_t r = make_rsrc(S.x + ((size_t)bb * channels + ch) * (size_t)len, valid ? (unsigned)len * 4u : 0u);
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(S.x + ((size_t)S.bb * channels + ch) * (size_t)S.len, valid ? (unsigned)S.len * 4u : 0u);
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const int f = lane + 64 * v;
-        const int t = tA - 8 + 4 * f;
+        const int t = S.tA - (ACT ? 8 : 0) + 4 * f;
+        const bool in = f < (ACT ? F_XS / 4 : F_NOUT / 4);
         if (VEC) {
-          xq[h][v] = __builtin_amdgcn_raw_buffer_load_b128(r, f < F_XS / 4 ? (unsigned)(t * 4) : 0x80000000u, 0, 0);
+          xq[h][v] = __builtin_amdgcn_raw_buffer_load_b128(r, in ? (unsigned)(t * 4) : 0x80000000u, 0, 0);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            xq[h][v][e] = __builtin_amdgcn_raw_buffer_load_b32(r, f < F_XS / 4 ? (unsigned)((t + e) * 4) : 0x80000000u, 0, 0);
+            xq[h][v][e] = __builtin_amdgcn_raw_buffer_load_b32(r, in ? (unsigned)((t + e) * 4) : 0x80000000u, 0, 0);
         }
       }
       if (ACT) {
@@ -210,12 +253,20 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, int n_groups, i
     for (int i = 0; i < MA; ++i) *reinterpret_cast<u32x4*>(dst + (tid + 256 * i) * 4) = wq[i];
   };
 
-  // ---- the activation of this wave's channel pair over the block's samples -> slab --------------------------------
-  const bool edge = tA - 8 < 0 || tA - 8 + F_XS > len;          // the pass touches a row end (block-uniform)
-  auto stage_pair = [&](int sbuf, int seg_idx) {
+  // ---- this wave's channel pair of a chunk (the loaded rows, through the activation) -> slab ----------------------------
+  auto stage_pair = [&](int sbuf, const Seg& SX) {
     float* const sl = slab0 + sbuf * F_SLAB_BUF;
+    if constexpr (!ACT) {
+      // conv-only form: the loaded samples are the conv's input (zero outside the row: the loads' out-of-range value)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        *reinterpret_cast<f32x2*>(sl + wofs[r]) = (f32x2){__uint_as_float(xq[0][r >> 2][r & 3]), __uint_as_float(xq[1][r >> 2][r & 3])};
+      return;
+    }
+    const int len = SX.len, tA = SX.tA;
+    const bool edge = tA - 8 < 0 || tA - 8 + F_XS > len;          // the pass touches a row end (block-uniform)
     float out[2][F_PPT];
-    const f32x2* tp_ = taps + seg_idx * 16;
+    const f32x2* tp_ = taps + SX.tapi;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       __builtin_amdgcn_wave_barrier();
@@ -223,12 +274,6 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, int n_groups, i
       if (lane < F_XS / 4 - 64) *reinterpret_cast<u32x4*>(xs + 4 * (lane + 64)) = xq[h][1];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (!ACT) {
-        // conv-only form: the staged samples are the conv's input (zero outside the row: the loads' out-of-range value)
-#pragma unroll
-        for (int r = 0; r < F_PPT; ++r) out[h][r] = xs[F_PPT * lane + r + 8];
-        continue;
-      }
       if (edge) {                                    // replicate padding at the row ends (act1d.hip)
         const int tb = tA - 8;
         for (int j = lane; j < F_XS; j += 64) {
@@ -305,18 +350,17 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, int n_groups, i
         if (edge) {
           // outputs whose taps leave [0, 2 len - 1] (z index clamped), and the conv's zero padding outside the row
           const int zlast = 2 * len - 1, zbase = 2 * (tA - 4) + 1;           // zs[m - zbase] = z[m]
-          const fh_amp_seg* SG = &G->seg[seg_idx];
 #pragma unroll 1
           for (int r = 0; r < F_PPT; ++r) {
             const int i = tA + F_PPT * lane + r;
             if (i < 0 || i >= len) out[h][r] = 0.f;
             else if (!(2 * i - 5 >= 0 && 2 * i + 6 <= zlast) && F_PPT * lane + r < F_NOUT) {
               float acc = 0.f;
-#pragma unroll
+#pragma unroll 1
               for (int k = 0; k < 12; ++k) {
                 int m = 2 * i + k - 5;
                 m = m < 0 ? 0 : (m > zlast ? zlast : m);
-                acc = fmaf(zs[m - zbase], SG->down_taps[k], acc);
+                acc = fmaf(zs[m - zbase], tp_[6 + (k >> 1)][k & 1], acc);
               }
               out[h][r] = acc;
             }
@@ -325,237 +369,253 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, int n_groups, i
       }
     }
 #pragma unroll
-    for (int r = 0; r < F_PPT; ++r) *reinterpret_cast<f32x2*>(sl + wofs[r]) = (f32x2){out[0][r], out[1][r]};
+    for (int r = 0; r < F_PPT; ++r) *reinterpret_cast<f32x2*>(sl + wofs[ACT ? r : 0]) = (f32x2){out[0][r], out[1][r]};
   };
 
-  // ---- accumulators: [point][row tile]: rows 4 (lane >> 4) .. + 3 of tile column lane & 15 --------------------------
-  f32x4 acc[8][MA];
-#pragma unroll
-  for (int x = 0; x < 8; ++x)
-#pragma unroll
-    for (int m = 0; m < MA; ++m) acc[x][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ---- K loop: stages (segment, chunk, tap group) ---------------------------------------------------------------------
-  int sbuf = 0, wb = 0;
-  Seg S = load_seg(0);
-  load_x(S, 0, true);
+  // ---- first tile: its first chunk and weight stage ------------------------------------------------------------------------
+  int tile = blockIdx.x;
+  Tile T = locate(tile);
+  publish_taps(T, 0);
+  int par = 0, sbuf = 0, wb = 0;
+  Seg S = load_seg(T, 0, 0);
   load_w(S.u, true);
+  load_x(S, 0, true);
   __syncthreads();                                   // taps
   store_w(0);
-  stage_pair(0, 0);
+  stage_pair(0, S);
   __syncthreads();
 
-  auto run_segment = [&](auto gc, int sidx) {
-    constexpr int GC = decltype(gc)::value;
-    const bool more_seg = sidx + 1 < nseg;
-    const Seg SN = load_seg(more_seg ? sidx + 1 : sidx);
-    // sample e' = 0 .. 4 GC + 3 of this segment's tiles is slab sample e = (cmax - center) + e'
-    int toff[4 * GC + 4];
-    {
-      const int shift = cmax - S.center;
+  for (;;) {
+    const Tile TN = locate(tile + (int)gridDim.x);
+    publish_taps(TN, par ^ 1);                       // (read from this tile's last K step on: behind at least one barrier)
+    // ---- epilogue state of this tile (the last K step requests round 0's bias and residual) ----------------------------
+    const fh_amp_group* __restrict__ const G = (const fh_amp_group*)uni((const float*)T.G);
+    const int len = uni(T.len), t0 = uni(T.t0), nseg = uni(T.nseg);
+    const int nres = uni(G->nres);
+    const float scale = G->scale;
+    const size_t oslab = (size_t)uni(T.bb) * channels * (size_t)len;
+    const unsigned slab_bytes = (unsigned)channels * (unsigned)len * 4u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(uni((const float*)G->out) + oslab, slab_bytes);
+    const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? uni(G->res[0]) + oslab : nullptr, nres > 0 ? slab_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? uni(G->res[1]) + oslab : nullptr, nres > 1 ? slab_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? uni(G->res[2]) + oslab : nullptr, nres > 2 ? slab_bytes : 0u);
+    const float* const bias = uni(G->bias);
+    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (unsigned)channels * 4u : 0u);
+    float bv[2][5];
+    u32x4 rs[2][5];
+    auto epi_geom = [&](int m, int i, unsigned& soff) {
+      int it_ = sitem[i];
+      asm volatile("" : "+v"(it_));
+      const int row = it_ >> 16, col = it_ & 0xffff;
+      const int co = 16 * m + row;
+      const int t = t0 + col;
+      soff = ((unsigned)co * (unsigned)len + (unsigned)t) * 4u;
+      return row < 16 && co < channels && t < len;
+    };
+    auto epi_request = [&](int m) {                  // bias and first residual of round m's items
 #pragma unroll
-      for (int e = 0; e < 4 * GC + 4; ++e) {
-        const int ee = shift + e, q = (ee * 13) >> 6;                   // ee / 5 for ee <= 24
-        toff[e] = ((ee - 5 * q) * 4 * PL + q) * 2;
+      for (int i = 0; i < 5; ++i) {
+        unsigned soff;
+        const bool ok = epi_geom(m, i, soff);
+        bv[m & 1][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, ok ? (unsigned)(16 * m + (sitem[i] >> 16)) * 4u : 0x80000000u, 0, 0));
+        if (VEC) rs[m & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, ok ? soff : 0x80000000u, 0, 0);
       }
-    }
-    for (int c = 0; c < nch; ++c) {
-      const bool last_c = c + 1 == nch;
-      const float* const sl = slab0 + sbuf * F_SLAB_BUF + rd_base;
-      // the next chunk's rows (this segment's, or the next segment's first)
-      const bool nx = !last_c || more_seg;
-      load_x(last_c ? SN : S, last_c ? 0 : c + 1, nx);
-#pragma unroll
-      for (int g = 0; g < GC; ++g) {
-        const bool last_g = g + 1 == GC;
-        // next weight stage
-        const bool nw = !last_g || nx;
-        const float* wnext = (last_g && last_c) ? SN.u : S.u + (size_t)(c * GC + g + 1) * f_wstage<MA>();
-        load_w(wnext, nw);
-        const float* const wl = wbuf0 + wb * f_wstage<MA>();
-        // the tile's 8 samples of this tap group, both channels of the pair (one ds_read_b64 each)
-        f32x2 xr[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xr[e] = *reinterpret_cast<const f32x2*>(sl + toff[4 * g + e]);
-        // B^T d for the 8 points (0, 1, -1, 2, -2, 1/2, -1/2, inf), both channels of the pair at once
-        const f32x2 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3], x4 = xr[4], x5 = xr[5], x6 = xr[6], x7 = xr[7];
-        f32x2 V[8];
-        V[0] = __builtin_elementwise_fma((f32x2)(-5.25f), x4, __builtin_elementwise_fma((f32x2)(5.25f), x2, x6)) - x0;
-        V[7] = __builtin_elementwise_fma((f32x2)(-5.25f), x5, __builtin_elementwise_fma((f32x2)(5.25f), x3, x7)) - x1;
-        {
-          const f32x2 e = __builtin_elementwise_fma((f32x2)(-4.25f), x4, x6 + x2);
-          const f32x2 o = __builtin_elementwise_fma((f32x2)(-4.25f), x3, x1 + x5);
-          V[1] = e + o;
-          V[2] = e - o;
-        }
-        {
-          const f32x2 e = __builtin_elementwise_fma((f32x2)(-1.25f), x4, __builtin_elementwise_fma((f32x2)(0.25f), x2, x6));
-          const f32x2 o = __builtin_elementwise_fma((f32x2)(2.f), x5, __builtin_elementwise_fma((f32x2)(-2.5f), x3, x1 * 0.5f));
-          V[3] = e + o;
-          V[4] = e - o;
-        }
-        {
-          const f32x2 e = __builtin_elementwise_fma((f32x2)(-5.f), x4, __builtin_elementwise_fma((f32x2)(4.f), x2, x6));
-          const f32x2 o = __builtin_elementwise_fma((f32x2)(0.5f), x5, __builtin_elementwise_fma((f32x2)(-2.5f), x3, x1 * 2.f));
-          V[5] = e + o;
-          V[6] = e - o;
-        }
-        // A fragments: [point][lane][row tile pair][2] (+ [point][lane][2] for an odd row tile count), read point by point
-        // (a point's two k-steps accumulate back to back into the same tiles)
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          if ((x & 1) == 0) __builtin_amdgcn_sched_barrier(0);        // (at most two points' A fragments in flight)
-          f32x4 a01 = {0.f, 0.f, 0.f, 0.f};
-          f32x2 a2 = {0.f, 0.f};
-          if (MA >= 2) a01 = *reinterpret_cast<const f32x4*>(wl + (x * 64 + lane) * 4);
-          if (MA & 1) a2 = *reinterpret_cast<const f32x2*>(wl + (MA >= 2 ? 2048 : 0) + (x * 64 + lane) * 2);
-#pragma unroll
-          for (int m = 0; m < MA; ++m)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const float a = (MA >= 2 && m < 2) ? a01[2 * m + s] : a2[s];
-              acc[x][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, V[x][s], acc[x][m], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (nw) store_w(wb ^ 1);
-        if (last_g && nx) stage_pair(sbuf ^ 1, last_c ? sidx + 1 : sidx);
-        __syncthreads();
-        wb ^= 1;
-      }
-      sbuf ^= 1;
-    }
-    S = SN;
-  };
-  // Segments are sorted by tap-group count, descending (host: make_amp_group): one loop per count, so that the accumulators
-  // do not pass through the merge of a three-way branch (the compiler then keeps two copies of them)
-  int sg = 0;
-  auto run_all = [&](auto gc) {
-    while (sg < nseg && S.ngrp == decltype(gc)::value) {
-      run_segment(gc, sg);
-      ++sg;
-    }
-  };
-  run_all(std::integral_constant<int, 3>{});
-  run_all(std::integral_constant<int, 2>{});
-  run_all(std::integral_constant<int, 1>{});
+    };
 
-  // ---- epilogue ---------------------------------------------------------------------------------------------------
-  // (the last stage ended on a barrier: slabs and weight buffers are free; Y rounds alternate between two halves)
-  float* const Y0 = lds;
-  const int nres = uni(G->nres);
-  const float scale = G->scale;
-  const float* const bias = uni(G->bias);
-  const float* const outp = uni((const float*)G->out);
-  const float* const resp[3] = {uni(G->res[0]), uni(G->res[1]), uni(G->res[2])};
-  const size_t oslab = (size_t)bb * channels * (size_t)len;
-  const unsigned slab_bytes = (unsigned)channels * (unsigned)len * 4u;
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc(outp + oslab, slab_bytes);
-  const __amdgpu_buffer_rsrc_t rr0 = make_rsrc(nres > 0 ? resp[0] + oslab : nullptr, nres > 0 ? slab_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t rr1 = make_rsrc(nres > 1 ? resp[1] + oslab : nullptr, nres > 1 ? slab_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t rr2 = make_rsrc(nres > 2 ? resp[2] + oslab : nullptr, nres > 2 ? slab_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (unsigned)channels * 4u : 0u);
-  // store items of this thread: vectors item = tid + 256 i of a round's 16 rows x TB / 4
-  const int vpr = TB >> 2;
-  int srow[5], scol[5];
+    // ---- accumulators: [point][row tile]: rows 4 (lane >> 4) .. + 3 of tile column lane & 15 ------------------------
+    f32x4 acc[8][MA];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int item = tid + 256 * i;
-    srow[i] = item / vpr;
-    scol[i] = (item - srow[i] * vpr) * 4;
-  }
-  // this lane's tile: outputs q = 0..4 at block-relative position d (5 tit + q) + tp
-  const int ypos = d * 5 * tit + tp;
+    for (int x = 0; x < 8; ++x)
 #pragma unroll
-  for (int m = 0; m < MA; ++m) {
-    float* const Y = Y0 + (m & 1) * 16 * F_YP;
-    {
-      const f32x4 s1 = acc[1][m] + acc[2][m], d1 = acc[1][m] - acc[2][m], s2 = acc[3][m] + acc[4][m], d2 = acc[3][m] - acc[4][m],
-                  s3 = acc[5][m] + acc[6][m], d3 = acc[5][m] - acc[6][m];
+      for (int m = 0; m < MA; ++m) acc[x][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- K loop: stages (segment, chunk, tap group) -------------------------------------------------------------------
+    // One code path for every tap-group count (run-time loop over the groups: with one instantiation per count the
+    // accumulators passed through three loops in a row and the compiler kept up to three copies of them)
+    for (int sidx = 0; sidx < nseg; ++sidx) {
+      const int GC = S.ngrp;
+      const bool more_seg = sidx + 1 < nseg;
+      const bool more = more_seg || TN.valid;        // there is a chunk behind this segment's last (next segment's / next tile's first)
+      const Seg SN = more_seg ? load_seg(T, sidx + 1, par) : load_seg(TN, 0, par ^ 1);
+      const int shift = cmax - S.center;             // sample e' of this segment's tiles is slab sample (cmax - center) + e'
+      for (int c = 0; c < nch; ++c) {
+        const bool last_c = c + 1 == nch;
+        const float* const sl = slab0 + sbuf * F_SLAB_BUF + rd_base;
+        const bool nx = !last_c || more;
+        for (int g = 0; g < GC; ++g) {
+          const bool last_g = g + 1 == GC;
+          // requests: the next weight stage first, then (first tap group) the next chunk's rows: the wait for the weights at the
+          // end of this step must not wait for the rows, which come from HBM and are needed one chunk later (vmcnt is in order)
+          const bool nw = !last_g || nx;
+          const float* wnext = (last_g && last_c) ? SN.u : S.u + (size_t)(c * GC + g + 1) * f_wstage<MA>();
+          load_w(wnext, nw);
+          if (g == 0) load_x(last_c ? SN : S, last_c ? 0 : c + 1, nx);
+          // last step of the tile: round 0's bias / residual under its MFMAs
+          if (MA <= F_EPI_EARLY_MA && last_g && last_c && !more_seg) epi_request(0);
+          const float* const wl = wbuf0 + wb * f_wstage<MA>();
+          // the tile's 8 samples of this tap group, both channels of the pair (one ds_read_b64 each)
+          f32x2 xr[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ee = shift + 4 * g + e, q = (ee * 13) >> 6;            // ee / 5 for ee <= 24 (scalar arithmetic)
+            xr[e] = *reinterpret_cast<const f32x2*>(sl + ((ee - 5 * q) * 4 * PL + q) * 2);
+          }
+          // B^T d for the 8 points (0, 1, -1, 2, -2, 1/2, -1/2, inf), both channels of the pair at once
+          const f32x2 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3], x4 = xr[4], x5 = xr[5], x6 = xr[6], x7 = xr[7];
+          f32x2 V[8];
+          V[0] = __builtin_elementwise_fma((f32x2)(-5.25f), x4, __builtin_elementwise_fma((f32x2)(5.25f), x2, x6)) - x0;
+          V[7] = __builtin_elementwise_fma((f32x2)(-5.25f), x5, __builtin_elementwise_fma((f32x2)(5.25f), x3, x7)) - x1;
+          {
+            const f32x2 e = __builtin_elementwise_fma((f32x2)(-4.25f), x4, x6 + x2);
+            const f32x2 o = __builtin_elementwise_fma((f32x2)(-4.25f), x3, x1 + x5);
+            V[1] = e + o;
+            V[2] = e - o;
+          }
+          {
+            const f32x2 e = __builtin_elementwise_fma((f32x2)(-1.25f), x4, __builtin_elementwise_fma((f32x2)(0.25f), x2, x6));
+            const f32x2 o = __builtin_elementwise_fma((f32x2)(2.f), x5, __builtin_elementwise_fma((f32x2)(-2.5f), x3, x1 * 0.5f));
+            V[3] = e + o;
+            V[4] = e - o;
+          }
+          {
+            const f32x2 e = __builtin_elementwise_fma((f32x2)(-5.f), x4, __builtin_elementwise_fma((f32x2)(4.f), x2, x6));
+            const f32x2 o = __builtin_elementwise_fma((f32x2)(0.5f), x5, __builtin_elementwise_fma((f32x2)(-2.5f), x3, x1 * 2.f));
+            V[5] = e + o;
+            V[6] = e - o;
+          }
+          // A fragments: [point][lane][row tile pair][2] (+ [point][lane][2] for an odd row tile count), requested one pair of
+          // points ahead of the MFMAs that take them (a point's two k-steps accumulate back to back into the same tiles)
+          f32x4 a01[2][2];
+          f32x2 a2[2][2];
+          auto read_a = [&](int pp, int set) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int x = 2 * pp + i;
+              if (MA >= 2) a01[set][i] = *reinterpret_cast<const f32x4*>(wl + (x * 64 + lane) * 4);
+              if (MA & 1) a2[set][i] = *reinterpret_cast<const f32x2*>(wl + (MA >= 2 ? 2048 : 0) + (x * 64 + lane) * 2);
+            }
+          };
+          read_a(0, 0);
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (F_A_AHEAD && pp < 3) read_a(pp + 1, (pp + 1) & 1);
+            if (!F_A_AHEAD && pp > 0) read_a(pp, pp & 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int x = 2 * pp + i;
+#pragma unroll
+              for (int m = 0; m < MA; ++m)
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                  const float a = (MA >= 2 && m < 2) ? a01[pp & 1][i][2 * m + s_] : a2[pp & 1][i][s_];
+                  acc[x][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, V[x][s_], acc[x][m], 0, 0, 0);
+                }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (nw) store_w(wb ^ 1);
+          if (last_g && nx) stage_pair(sbuf ^ 1, last_c ? SN : S);
+          __syncthreads();
+          wb ^= 1;
+        }
+        sbuf ^= 1;
+      }
+      S = SN;
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------------------------
+    // (the last step ended on a barrier; the staging is not the slab: the next tile's first chunk is already there)
+    if (MA > F_EPI_EARLY_MA) epi_request(0);
+#pragma unroll
+    for (int m = 0; m < MA; ++m) {
       f32x4 y[5];
-      y[0] = ((acc[0][m] + s1) + s2) + s3;
-      y[1] = __builtin_elementwise_fma((f32x4)(0.5f), d3, __builtin_elementwise_fma((f32x4)(2.f), d2, d1));
-      y[2] = __builtin_elementwise_fma((f32x4)(0.25f), s3, __builtin_elementwise_fma((f32x4)(4.f), s2, s1));
-      y[3] = __builtin_elementwise_fma((f32x4)(0.125f), d3, __builtin_elementwise_fma((f32x4)(8.f), d2, d1));
-      y[4] = __builtin_elementwise_fma((f32x4)(0.0625f), s3, __builtin_elementwise_fma((f32x4)(16.f), s2, s1)) + acc[7][m];
+      {
+        const f32x4 s1 = acc[1][m] + acc[2][m], d1 = acc[1][m] - acc[2][m], s2 = acc[3][m] + acc[4][m], d2 = acc[3][m] - acc[4][m],
+                    s3 = acc[5][m] + acc[6][m], d3 = acc[5][m] - acc[6][m];
+        y[0] = ((acc[0][m] + s1) + s2) + s3;
+        y[1] = __builtin_elementwise_fma((f32x4)(0.5f), d3, __builtin_elementwise_fma((f32x4)(2.f), d2, d1));
+        y[2] = __builtin_elementwise_fma((f32x4)(0.25f), s3, __builtin_elementwise_fma((f32x4)(4.f), s2, s1));
+        y[3] = __builtin_elementwise_fma((f32x4)(0.125f), d3, __builtin_elementwise_fma((f32x4)(8.f), d2, d1));
+        y[4] = __builtin_elementwise_fma((f32x4)(0.0625f), s3, __builtin_elementwise_fma((f32x4)(16.f), s2, s1)) + acc[7][m];
+      }
+      if (m > 0) __syncthreads();                    // the previous round's readers are done with the staging
       if (tile_ok) {
-        float* yw = Y + (4 * kq) * F_YP + ypos;
+        float* yw = ybuf + (4 * kq) * F_YP + ypos;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int q = 0; q < 5; ++q) yw[r * F_YP + q * d] = y[q][r];
       }
-    }
-    // requests of the store phase (before the barrier: their latency hides under it)
-    unsigned soff[5];
-    bool ok[5];
-    float bv[5];
-    u32x4 rs[5];
+      // the next round's requests in front of this round's stores (vmcnt counts loads and stores in order)
+      if (m + 1 < MA) epi_request(m + 1);
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int co = 16 * m + srow[i];
-      const int t = t0 + scol[i];
-      ok[i] = srow[i] < 16 && co < channels && t < len;
-      soff[i] = ((unsigned)co * (unsigned)len + (unsigned)t) * 4u;
-      bv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, ok[i] ? (unsigned)co * 4u : 0x80000000u, 0, 0));
-    }
-    if (VEC) {
+      for (int i = 0; i < 5; ++i) {
+        unsigned soff;
+        const bool ok = epi_geom(m, i, soff);
+        const float b_ = bv[m & 1][i];
+        const int yrow = sitem[i] >> 16, ycol = sitem[i] & 0xffff;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(ybuf + (yrow < 16 ? yrow : 0) * F_YP + ycol);
+        if (VEC) {
+          f32x4 o = {yv[0] + b_, yv[1] + b_, yv[2] + b_, yv[3] + b_};
+          const u32x4 r0 = rs[m & 1][i];
+          if (nres > 0) o += (f32x4){__uint_as_float(r0[0]), __uint_as_float(r0[1]), __uint_as_float(r0[2]), __uint_as_float(r0[3])};
+          if (nres > 1) {            // (the stage-closing group only: requested here)
+            const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rr1, ok ? soff : 0x80000000u, 0, 0);
+            o += (f32x4){__uint_as_float(t1[0]), __uint_as_float(t1[1]), __uint_as_float(t1[2]), __uint_as_float(t1[3])};
+          }
+          if (nres > 2) {
+            const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(rr2, ok ? soff : 0x80000000u, 0, 0);
+            o += (f32x4){__uint_as_float(t2[0]), __uint_as_float(t2[1]), __uint_as_float(t2[2]), __uint_as_float(t2[3])};
+          }
+          o *= scale;
+          const u32x4 ou = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(ou, ro, ok ? soff : 0x80000000u, 0, 0);
+        } else {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) rs[i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, ok[i] ? soff[i] : 0x80000000u, 0, 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(Y + (srow[i] < 16 ? srow[i] : 0) * F_YP + scol[i]);
-      if (VEC) {
-        f32x4 o = {yv[0] + bv[i], yv[1] + bv[i], yv[2] + bv[i], yv[3] + bv[i]};
-        if (nres > 0) o += (f32x4){__uint_as_float(rs[i][0]), __uint_as_float(rs[i][1]), __uint_as_float(rs[i][2]), __uint_as_float(rs[i][3])};
-        if (nres > 1) {            // (the stage-closing group only: requested here)
-          const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rr1, ok[i] ? soff[i] : 0x80000000u, 0, 0);
-          o += (f32x4){__uint_as_float(t1[0]), __uint_as_float(t1[1]), __uint_as_float(t1[2]), __uint_as_float(t1[3])};
-        }
-        if (nres > 2) {
-          const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(rr2, ok[i] ? soff[i] : 0x80000000u, 0, 0);
-          o += (f32x4){__uint_as_float(t2[0]), __uint_as_float(t2[1]), __uint_as_float(t2[2]), __uint_as_float(t2[3])};
-        }
-        o *= scale;
-        const u32x4 ou = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(ou, ro, ok[i] ? soff[i] : 0x80000000u, 0, 0);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned off = (ok[i] && t0 + scol[i] + q < len) ? soff[i] + 4u * q : 0x80000000u;
-          float o = yv[q] + bv[i];
-          if (nres > 0) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));
-          if (nres > 1) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off, 0, 0));
-          if (nres > 2) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off, 0, 0));
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o * scale), ro, off, 0, 0);
+          for (int q = 0; q < 4; ++q) {
+            const unsigned off = (ok && t0 + ycol + q < len) ? soff + 4u * q : 0x80000000u;
+            float o = yv[q] + b_;
+            if (nres > 0) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr0, off, 0, 0));
+            if (nres > 1) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr1, off, 0, 0));
+            if (nres > 2) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr2, off, 0, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o * scale), ro, off, 0, 0);
+          }
         }
       }
     }
-    // (the next round writes the other half of the staging; the one after it is behind the next round's barrier)
+    if (!TN.valid) break;
+    T = TN;
+    tile += (int)gridDim.x;
+    par ^= 1;
   }
 }
 
 template <int MA, bool VEC, bool ACT>
-int launch_amp(const fh_amp_group* groups, int n_groups, int channels, int dilation, int total_tiles, hipStream_t stream) {
-  static std::atomic<bool> lds_opt_in[FH_MAX_DEVICES];
+int launch_amp(const fh_amp_group* groups, const fh_amp_tile* tiles, int channels, int dilation, int total_tiles, int cmax, hipStream_t stream) {
+  static std::atomic<int> blocks_per_launch[FH_MAX_DEVICES];      // 0 = LDS opt-in not done yet; else 2 x the device's CUs
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FH_MAX_DEVICES) {
     fh_set_error("fh_amp_actconv_f32: no current HIP device (or ordinal >= %d)", FH_MAX_DEVICES);
     return FH_E_LAUNCH;
   }
   constexpr int bytes = f_lds_floats<MA>() * 4;
-  if (!lds_opt_in[dev].load(std::memory_order_acquire)) {
+  int resident = blocks_per_launch[dev].load(std::memory_order_acquire);
+  if (!resident) {
     hipError_t e = hipFuncSetAttribute((const void*)amp_actconv_kernel<MA, VEC, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) {
+    int cus = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cus <= 0) {
       fh_set_error("fh_amp_actconv_f32: cannot reserve %d bytes of LDS on device %d: %s", bytes, dev, hipGetErrorString(e));
       return FH_E_LAUNCH;
     }
-    lds_opt_in[dev].store(true, std::memory_order_release);
+    resident = 2 * cus;                                            // two 4-wave blocks per CU (LDS, registers)
+    blocks_per_launch[dev].store(resident, std::memory_order_release);
   }
-  hipLaunchKernelGGL((amp_actconv_kernel<MA, VEC, ACT>), dim3((unsigned)total_tiles), dim3(F_THREADS), bytes, stream, groups, n_groups,
-                     channels, dilation);
+  const int grid = total_tiles < resident ? total_tiles : resident;
+  hipLaunchKernelGGL((amp_actconv_kernel<MA, VEC, ACT>), dim3((unsigned)grid), dim3(F_THREADS), bytes, stream, groups, tiles,
+                     channels, dilation, total_tiles, cmax);
   FH_CHECK_LAUNCH("fh_amp_actconv_f32");
   return FH_OK;
 }
@@ -563,26 +623,28 @@ int launch_amp(const fh_amp_group* groups, int n_groups, int channels, int dilat
 }  // namespace
 
 extern "C" int fh_sizeof_amp_group(void) { return (int)sizeof(fh_amp_group); }
+extern "C" int fh_sizeof_amp_tile(void) { return (int)sizeof(fh_amp_tile); }
 
 extern "C" int fh_amp_tile_len(int dilation) { return dilation >= 1 && dilation <= F_MAX_D ? f_tb(dilation) : -1; }
 
 extern "C" int fh_amp_max_channels(void) { return 48; }
 
-extern "C" int fh_amp_actconv_f32(const fh_amp_group* groups, int n_groups, int channels, int dilation, int total_tiles,
-                                  int flags, void* stream) {
-  FH_CHECK_ARG(groups && n_groups > 0 && total_tiles > 0, "fh_amp_actconv_f32: bad sizes");
+extern "C" int fh_amp_actconv_f32(const fh_amp_group* groups, int n_groups, const fh_amp_tile* tiles, int total_tiles, int channels,
+                                  int dilation, int max_center, int flags, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && tiles && total_tiles > 0, "fh_amp_actconv_f32: bad sizes");
   FH_CHECK_ARG(channels >= 8 && channels <= 48 && channels % 8 == 0, "fh_amp_actconv_f32: %d channels (8 .. 48, a multiple of 8)", channels);
   FH_CHECK_ARG(dilation >= 1 && dilation <= F_MAX_D, "fh_amp_actconv_f32: dilation %d (1 .. %d)", dilation, F_MAX_D);
+  FH_CHECK_ARG(max_center >= 0 && max_center <= 5, "fh_amp_actconv_f32: max_center %d (0 .. 5: kernels of at most 11 taps)", max_center);
   FH_CHECK_ARG(flags >= 0 && flags <= 3, "fh_amp_actconv_f32: flags %d (bit 0: rows 16-byte aligned, bit 1: no activation)", flags);
   const int ma = (channels + 15) / 16;
   const bool vec = flags & 1, act = !(flags & 2);
   hipStream_t st = (hipStream_t)stream;
 #define FH_AMP_CASE(MA)                                                                                          \
   case MA:                                                                                                       \
-    if (!act) return vec ? launch_amp<MA, true, false>(groups, n_groups, channels, dilation, total_tiles, st)    \
-                         : launch_amp<MA, false, false>(groups, n_groups, channels, dilation, total_tiles, st);  \
-    return vec ? launch_amp<MA, true, true>(groups, n_groups, channels, dilation, total_tiles, st)               \
-               : launch_amp<MA, false, true>(groups, n_groups, channels, dilation, total_tiles, st);
+    if (!act) return vec ? launch_amp<MA, true, false>(groups, tiles, channels, dilation, total_tiles, max_center, st)    \
+                         : launch_amp<MA, false, false>(groups, tiles, channels, dilation, total_tiles, max_center, st);  \
+    return vec ? launch_amp<MA, true, true>(groups, tiles, channels, dilation, total_tiles, max_center, st)               \
+               : launch_amp<MA, false, true>(groups, tiles, channels, dilation, total_tiles, max_center, st);
   switch (ma) {
     FH_AMP_CASE(1)
     FH_AMP_CASE(2)

@@ -61,7 +61,7 @@ class AmpSeg(C.Structure):
 class AmpGroup(C.Structure):
     _fields_ = [("seg", AmpSeg * CONV_MAX_SEG), ("bias", C.c_void_p), ("res", C.c_void_p * CONV_MAX_SEG),
                 ("out", C.c_void_p), ("nseg", C.c_int32), ("nres", C.c_int32), ("len", C.c_int32),
-                ("tile_base", C.c_int32), ("scale", C.c_float), ("pad_", C.c_int32)]
+                ("pad0_", C.c_int32), ("scale", C.c_float), ("pad1_", C.c_int32)]
 
 
 class SumJob(C.Structure):
@@ -105,7 +105,8 @@ _SIGS = {
     "fh_sizeof_amp_group": [],
     "fh_amp_tile_len": [_I],
     "fh_amp_max_channels": [],
-    "fh_amp_actconv_f32": [_P, _I, _I, _I, _I, _I, _P],
+    "fh_sizeof_amp_tile": [],
+    "fh_amp_actconv_f32": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "fh_sizeof_sum_job": [],
     "fh_sum_multi_f32": [_P, _I, C.c_longlong, _P],
     "fh_attention_seg_f32": [_P, _P, _P, _I, _I, _I, _F, _P],

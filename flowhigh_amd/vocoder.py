@@ -375,9 +375,8 @@ def make_amp_group(segs, bias, res, out, length, scale=1.0):
     g = hip.AmpGroup()
     # the kernel walks the segments in one pass per tap-group count, largest first
     segs = sorted(segs, key=lambda s: -s.ngrp)
-    cmax = max(s.center for s in segs)
-    if any(cmax - s.center + 4 * s.ngrp + 3 > 16 or s.ngrp > 3 for s in segs):
-        raise NotImplementedError("narrow-stage kernel: kernel sizes of the group's segments are too far apart (or above 12 taps)")
+    if any(s.ngrp > 3 or s.center > 5 for s in segs):
+        raise NotImplementedError("narrow-stage kernel: kernels of at most 11 taps")
     for i, s in enumerate(segs):
         g.seg[i] = s
     g.nseg, g.nres = len(segs), len(res)
@@ -388,23 +387,37 @@ def make_amp_group(segs, bias, res, out, length, scale=1.0):
     return g
 
 
-def set_amp_tile_bases(groups, batch, dilation):
-    """Fill tile_base (prefix of batch * ceil(len / tile)) of a launch's groups; returns the launch's block count."""
-    tb, base = amp_tile_len(dilation), 0
-    for g in groups:
-        g.tile_base = base
-        base += batch * -(-g.len // tb)
-    return base
+def amp_tile_list(lens, batch, dilation):
+    """The work list of a narrow-stage launch (fh_amp_tile: group, batch item, first output, len): int32 tensor [tiles, 4],
+    groups in the given order (heavy first), a group's tiles in (batch item, time) order."""
+    tb = amp_tile_len(dilation)
+    rows = []
+    for gi, length in enumerate(lens):
+        t0 = torch.arange(0, length, tb, dtype=torch.int32)
+        for b in range(batch):
+            e = torch.empty(len(t0), 4, dtype=torch.int32)
+            e[:, 0], e[:, 1], e[:, 2], e[:, 3] = gi, b, t0, length
+            rows.append(e)
+    return torch.cat(rows, dim=0).contiguous()
+
+
+def amp_max_center(groups):
+    """max_center of a narrow-stage launch; raises if some segment's taps do not fit the slab it implies."""
+    segs = [g.seg[i] for g in groups for i in range(g.nseg)]
+    cmax = max(s.center for s in segs)
+    if any(cmax - s.center + 4 * s.ngrp + 3 > 16 for s in segs):
+        raise NotImplementedError("narrow-stage kernel: the kernel sizes of one launch are too far apart")
+    return cmax
 
 
 def amp_actconv(groups, batch, channels, dilation, device, act=True):
     """Upload descriptors and enqueue one narrow-stage launch (test / one-off use)."""
-    total = set_amp_tile_bases(groups, batch, dilation)
+    tiles = amp_tile_list([g.len for g in groups], batch, dilation).to(device)
     d = hip.to_device_struct_array(groups, device)
     flags = int(all(g.len % 4 == 0 for g in groups)) | (0 if act else 2)
-    hip.check(hip.lib().fh_amp_actconv_f32(d.data_ptr(), len(groups), channels, dilation, total, flags, hip.stream()),
-              "fh_amp_actconv_f32")
-    return d
+    hip.check(hip.lib().fh_amp_actconv_f32(d.data_ptr(), len(groups), tiles.data_ptr(), tiles.shape[0], channels, dilation,
+                                           amp_max_center(groups), flags, hip.stream()), "fh_amp_actconv_f32")
+    return d, tiles
 
 
 WINO_BF16X6 = 16          # FH_WINO_BF16X6 of flowhigh_hip.h: tile_cfg flag, three-piece bf16 weights

@@ -288,15 +288,17 @@ int fh_act_get_blocks_per_cu(void);
  *   with act_seg(x) read as 0 outside [0, len) (the conv's zero padding) and the activation's own replicate padding at
  *   the row ends (fh_act_group above).  The activated tensor exists in LDS only; all tensors are plain [B, C, len]
  *   whatever the dilation.  The conv is evaluated in the Winograd F(5,4) form (fh_conv_wino54_f32): k <= 12 odd,
- *   dilation <= 6, (max center of the group's segments - center) + 4 ngrp + 3 <= 16.
+ *   dilation <= 6, (max_center - center) + 4 ngrp + 3 <= 16 for every segment.
  * u = host-transformed weights (flowhigh_amd/packing.py: pack_amp_weight), float
  *   [C/8 chunks][ngrp][ blockA: [8 points][64 lanes][4]  (ceil(C/16) >= 2)  |  blockB: [8 points][64 lanes][2]  (ceil(C/16) odd) ]
  *   lane l = 16 kq + r: blockA[xi][l][2 m + s] = U[g][xi][co = 16 m + r][ci = 8 chunk + 2 kq + s] for the row tiles m = 0, 1,
  *   blockB[xi][l][s] the same for the last row tile of an odd count; U[g][xi] = sum_j G8[xi][j] w[:, :, 4 g + j] (float64 on
  *   the host, taps past k and rows past C zero): 1024 ceil(C/16) floats per (chunk, tap group) stage.
- * Groups may have different `len` (ragged batches: batch 1 per group): block b of the launch works on the group with the
- * largest tile_base <= b; tile_base = sum over the groups before of batch * ceil(len / fh_amp_tile_len(dilation)),
- * total_tiles = the sum over all groups.  A group's batch items are [batch, C, len] tensors behind its pointers.
+ * Groups may have different `len` (ragged batches).  The work list is a device array of `total_tiles` fh_amp_tile entries, one
+ * per (group, batch item, tile of fh_amp_tile_len(dilation) outputs starting at t0), heavy groups first; a group's batch items
+ * are [batch, C, len] tensors behind its pointers.
+ * max_center: the largest `center` of any segment of the launch (<= 5): it places the samples in the kernel's LDS slabs, the same
+ *        for every block.  The launch runs 2 x (CUs of the device) persistent blocks that walk the tile list with stride gridDim.
  * flags: bit 0 = every row of every group is 16-byte aligned (len % 4 == 0: vector accesses; same bits without);
  *        bit 1 = no activation (act_seg = identity: the conv alone; alpha / inv_beta / taps are not read).
  * --------------------------------------------------------------------------------- */
@@ -319,16 +321,24 @@ typedef struct {
   int32_t nseg;
   int32_t nres;
   int32_t len;
-  int32_t tile_base;
+  int32_t pad0_;
   float scale;
-  int32_t pad_;
+  int32_t pad1_;
 } fh_amp_group;
 
+typedef struct {
+  int32_t group;       /* index into the launch's groups */
+  int32_t batch_item;
+  int32_t t0;          /* first output of the tile: a multiple of fh_amp_tile_len(dilation) */
+  int32_t len;         /* = groups[group].len */
+} fh_amp_tile;
+
 int fh_sizeof_amp_group(void);
+int fh_sizeof_amp_tile(void);
 int fh_amp_tile_len(int dilation);     /* outputs per block and row: 320, 320, 300, 320, 300, 240 for dilation 1 .. 6; -1 beyond */
 int fh_amp_max_channels(void);         /* 48 */
-int fh_amp_actconv_f32(const fh_amp_group* groups, int n_groups, int channels, int dilation, int total_tiles,
-                       int flags, void* stream);
+int fh_amp_actconv_f32(const fh_amp_group* groups, int n_groups, const fh_amp_tile* tiles, int total_tiles, int channels,
+                       int dilation, int max_center, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 MFMA GEMM:  C[M, N] = epilogue( A[M, K] * W[N, K]^T )
