@@ -1,4 +1,4 @@
-"""BigVGAN generator on the HIP kernels: weight packing, launch plan, forward.
+"""BigVGAN generator on the HIP kernels: device-resident weights, per-shape launch plans, forward / chunked / ragged runs.
 
 Mirrors /root/reference/src/flowhigh/models/bigvgan/models.py:124-194 (BigVGAN, AMPBlock1 :21-78)
 and init_vocoder.py:8-23 (JSON config -> generator), parametric in the JSON keys
@@ -11,1063 +11,36 @@ Launch structure per stage (13 launches instead of the reference's ~1700 aten ca
                      conv2 (+ residual; nk groups)   [models.py:63-72]
   the last conv2 of the stage is ONE group with nk K-segments: it sums the three AMP blocks in
   the accumulator and applies "/ num_kernels" (models.py:181-187) in its epilogue.
+
+Round 5 split this file: weight layouts live in packing.py, kernel / tile selection, the launch-time model and the plan builder
+in planner.py, launchers and the step dispatch in runtime.py.  Every name they define is re-exported here (tests and tools use
+`vocoder.<name>`; the mutable module-level tables are the same objects).
 """
 import json
-import ctypes as C
-import functools
 import math
 import os
 
 import torch
 
 from . import hip
+from .packing import (  # noqa: F401
+    _WINO54_G, _WINO_G, fold_weight_norm, from_phase_major, pack_amp_weight, pack_conv_weight,
+    pack_wino54_weight, pack_wino_weight, pack_wino_weight_any, phase_len, pick_ck, split_bf3, to_phase_major,
+    transposed_conv_extra, transposed_conv_phases, wino_phase_weight)
+from .planner import (  # noqa: F401
+    AMP_MAX_D, WINO54_MIN_C, WINO_BF16X6, WINO_BM, WINO_F54, WINO_MAX_K, WINO_MIN_C, WINO_NARROW, WINO_NOVL,
+    WINO_UPS_MIN_CIN, WINO_XCD_RANGES, _PlanBuilder, _TILE_PREF, _WINO_BF_SPEED, _WINO_COST, _WINO_RUN,
+    _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_max_center, amp_tile_len,
+    amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,
+    make_conv_seg, make_wino_group, make_wino_seg, merge_ragged, pick_tile_cfg, pick_wino54_tile,
+    pick_wino_tile, use_bf16x6, use_wino, use_wino54, wino_block_mapping, wino_conv_ok, wino_launch_cost,
+    wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
+from .runtime import (  # noqa: F401
+    ACT_BLOCKS_CHOICES, _act_blocks, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped,
+    conv_wino, decide_act_blocks, launch_step, measure_act_conv_pair, parse_act_blocks, pick_act_blocks,
+    run_ragged_steps, run_steps)
 
 VOC = "flowhigh.audio_enc_dec.vocoder."
-# preference order among equal padded heights: tiles that keep 3 blocks per CU resident first
-_TILE_PREF = [(0, 128), (6, 96), (3, 64), (1, 192), (2, 96), (4, 32)]
-
-# Residual-stack convs run as Winograd F(4,3) from this many channels on, and at the narrower widths where it measured
-# faster (tools/wino_bench.py, B = 1; the dilated ones work on phase-major tensors)
-WINO_MIN_C = 192
-WINO_NARROW = (96, 48)
-# transposed convs run as Winograd phase groups from this many INPUT channels on (366 -> 207 us for 1536 -> 768
-# channels at B = 1, a wash at 768 -> 384, slower below: one-tap-group blocks pay the per-chunk slab cost every step)
-WINO_UPS_MIN_CIN = 768
-
-
-def use_wino(c, d):
-    """Residual-stack convs [c -> c, dilation d] that run as Winograd F(4,3) (conv_wino.hip) instead of the direct
-    implicit GEMM: c a multiple of 16 and >= WINO_MIN_C or one of WINO_NARROW, at every dilation (a dilated conv works
-    on phase-major tensors written / read by the neighbouring activation launches: contiguous runs instead of stride-d
-    access).  FH_WINO=0 switches the path off (direct kernel everywhere: parity debugging)."""
-    return os.environ.get("FH_WINO", "1") != "0" and c % 16 == 0 and (c >= WINO_MIN_C or c in WINO_NARROW)
-
-
-def wino_conv_ok(c, d, k):
-    """use_wino for a k-tap conv: kernels longer than 4 tap groups run on the direct kernel."""
-    return use_wino(c, d) and k <= WINO_MAX_K
-
-
-def pick_tile_cfg(cout):
-    best = None
-    for cfg, bm in _TILE_PREF:
-        cost = -(-cout // bm) * bm
-        if best is None or cost < best[0]:
-            best = (cost, cfg, bm)
-    return best[1], best[2], best[0]
-
-
-def fold_weight_norm(sd):
-    """weight_g / weight_v -> weight (remove_weight_norm, bigvgan/models.py:196-204;
-    norm over all dims but 0, for Conv1d and ConvTranspose1d alike)."""
-    out = {}
-    for k, v in sd.items():
-        if k.endswith("weight_g"):
-            base = k[:-len("weight_g")]
-            vv = sd[base + "weight_v"]
-            norm = vv.flatten(1).norm(dim=1).view(-1, *([1] * (vv.ndim - 1)))
-            out[base + "weight"] = v * vv / norm
-        elif k.endswith("weight_v"):
-            continue
-        else:
-            out[k] = v
-    return out
-
-
-def pick_ck(*cins):
-    """Channel chunk of the K loop: 16 when every segment allows it, else 8."""
-    return 16 if all(c % 16 == 0 for c in cins) else 8
-
-
-def pack_conv_weight(w, cout_pad, ck=8):
-    """Conv1d weight [co, ci, k] -> [ci/ck, k, cout_pad, ck] (zero padded rows)."""
-    co, ci, k = w.shape
-    if ci % ck:
-        raise ValueError(f"input channels {ci} must be a multiple of {ck}")
-    p = torch.zeros(ci // ck, k, cout_pad, ck, dtype=torch.float32)
-    p[:, :, :co, :] = w.float().reshape(co, ci // ck, ck, k).permute(1, 3, 0, 2)
-    return p.contiguous()
-
-
-def transposed_conv_phases(k, u):
-    """ConvTranspose1d(k, stride u, padding (k-u)//2) as u output phases (SURVEY.md 8a; models.py:141-146 builds it for
-    ANY (u, k)):
-    out[co, u*n + r] = sum over taps j with (r + p - j) % u == 0 of x[ci, n + (r + p - j)//u] w[ci, co, j].
-    With k - u odd the output has u * L + 1 samples (transposed_conv_extra): phase 0 then has L + 1 positions, the
-    others L; the tap lists are the same formula."""
-    p = (k - u) // 2
-    phases = []
-    for r in range(u):
-        taps = [(j, (r + p - j) // u) for j in range(k) if (r + p - j) % u == 0]
-        phases.append(taps)
-    return phases
-
-
-def transposed_conv_extra(k, u):
-    """Samples a ConvTranspose1d(k, u, padding (k - u) // 2) returns beyond u * L: (L - 1) u - 2 ((k - u) // 2) + k - u L."""
-    if k < u:
-        raise NotImplementedError(f"upsample kernel {k} shorter than its stride {u}")
-    return (k - u) % 2
-
-
-def make_conv_seg(x, w, cin, offs):
-    s = hip.ConvSeg()
-    s.x, s.w, s.cin, s.ntaps = hip.ptr(x), hip.ptr(w), cin, len(offs)
-    if len(offs) > hip.CONV_MAX_TAPS or max(offs) - min(offs) > hip.CONV_MAX_HALO:
-        raise NotImplementedError(f"tap list {offs} exceeds kernel limits")
-    s.off_min, s.off_max = min(offs), max(offs)
-    for i, o in enumerate(offs):
-        s.tap_off[i] = o
-    return s
-
-def make_conv_group(segs, bias, res, out, cout, cpad, lin, lout, n_len, stride=1, phase=0, scale=1.0):
-    g = hip.ConvGroup()
-    for i, s in enumerate(segs):
-        g.seg[i] = s
-    g.nseg, g.nres = len(segs), len(res)
-    g.bias = hip.ptr(bias)
-    for i, r in enumerate(res):
-        g.res[i] = hip.ptr(r)
-    g.out = hip.ptr(out)
-    if cout * lout * 4 >= 2 ** 31 or lin * 4 >= 2 ** 31:
-        raise NotImplementedError("per-clip tensor exceeds the 2 GiB range of a buffer descriptor")
-    g.cout, g.cout_pad, g.lin, g.lout, g.n_len = cout, cpad, lin, lout, n_len
-    g.out_stride, g.out_phase, g.scale = stride, phase, scale
-    return g
-
-def make_act_group(x, y, p):
-    g = hip.ActGroup()
-    g.x, g.y, g.alpha, g.inv_beta = hip.ptr(x), hip.ptr(y), hip.ptr(p["alpha"]), hip.ptr(p["inv_beta"])
-    for i in range(12):
-        g.up_taps[i] = p["up"][i]
-        g.down_taps[i] = p["down"][i]
-    return g
-
-
-
-# Winograd tiles (tile_cfg -> rows x outputs) and their measured block time on one CU: _WINO_COST[cfg] = (a, b),
-# a us per K step (16 input channels x one tap group), b us of prologue + epilogue (tools/wino_cfg_sweep.py)
-# | WINO_F54: the F(5,4) kernel (conv_wino54.hip: 8-wave blocks of 128 / 96 / 64 co x 320 outputs; K steps = 16 input
-# channels x one group of FOUR taps; constants from tools/wino54_bench.py fit)
-WINO_F54 = 256            # flag in a plan's tile id: the launch runs fh_conv_wino54_f32 with tile_cfg = id & 15
-_WINO_TILES = {0: (64, 512), 1: (96, 256), 4: (64, 256), 5: (32, 256), 6: (128, 256),
-               WINO_F54 | 0: (128, 320), WINO_F54 | 1: (96, 320), WINO_F54 | 2: (64, 320), WINO_F54 | 3: (48, 320)}
-_WINO_COST = {0: (2.98, 20.0), 1: (2.21, 16.0), 4: (1.564, 14.7), 5: (0.917, 17.0), 6: (2.75, 20.0),
-              # (tools/wino54_cost_fit.py: 4.4 / 3.1-3.6 / 2.5 us per step = 0.78 / 0.71-0.83 / 0.68 of the matrix-pipe time; b: ~10 us
-              # reproduces both closing-conv forms of the C = 96 stage: 3 groups, 1 125 blocks: 232 us; fused, 375 blocks: 308 us)
-              # Chosen among five constant sets by the measured total of the 43 conv launches of a 10 s clip (13.25 ms; the others
-              # 13.35-13.41): the launch model is a ranking device, not a clock.
-              # (| 3: the 48-row block, three 16-row MFMA tiles: 3/4 of the 64-row block's matrix instructions)
-              WINO_F54 | 0: (4.4, 12.0), WINO_F54 | 1: (3.3, 10.0), WINO_F54 | 2: (2.52, 9.0), WINO_F54 | 3: (1.95, 9.0)}
-# 128-row tiles halve the LDS reads and transform instructions per MFMA (one B fragment feeds 4 MFMAs) but
-# double the weight bytes a block streams: beyond this panel size (6 x 128 rows x K, bytes) a chip full of
-# such blocks thrashes the 4 MB L2s (C = 768: 857 us against 732 us with 64 x 512 tiles)
-_WINO_WIDE_PANEL_MAX = 6 * 2 ** 20
-_WINO_TILES_OFF = set()            # (A/B experiments: tools add tile ids here before the first plan)
-_WINO_RUN = 8                      # W_RUN of conv_wino.hip
-
-
-# K-loop time per step of the bf16 x 6 form relative to the fp32 form, per tile shape (tools/wino_cost_fit.py:
-# 2.47 / 1.72 / 1.34 / 1.08 / 2.43 us against 3.28 / 2.27 / 1.86 / 1.14 / 3.22): the matrix pipe needs 0.375 of the
-# cycles, but the B split (36 VALU instructions per 8 values), 1.5 x the weight bytes and the unchanged slab / transform
-# work keep the loop issue-bound (ablations: no weight loads -10 %, no split -10 %, neither and no slab -35 %)
-_WINO_BF_SPEED = {0: 0.75, 1: 0.76, 4: 0.72, 5: 0.94, 6: 0.75}
-
-
-def wino_n_tiles(cfg, length, dil, pm):
-    """Output tiles per (group, batch, co tile) panel of a Winograd launch (the kernels' launchers compute the same): per phase in
-    general; the F(5,4) kernel tiles phase-major rows as one sequence of 5-output tile slots (conv_wino54.hip: v_tile_slots)."""
-    bm, bt = _WINO_TILES[cfg & (15 | WINO_F54)]
-    if cfg & WINO_F54 and pm:
-        slots = ((-(-length // dil) + 4) // 5 + 3 + 3) & ~3
-        return -(-dil * slots // 64)
-    return -(-(-(-length // dil)) // bt) * dil
-
-
-def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=False):
-    """Estimated duration (us) of one fh_conv_wino_f32 launch: the kernel's block -> (panel, tile) map replayed
-    on 8 XCDs x 32 CUs with in-order dispatch per XCD (block i goes to XCD i % 8).  ksteps: K steps
-    (sum over segments of cin / 16 x tap groups) of each group, launch order.  Blocks of a launch differ up to
-    4 x in length (k = 11 / 7 / 3) and a 10 s clip is only 1-6 blocks per CU, so the block count per tile
-    shape, not the per-tile efficiency, decides between the tile shapes (measured +-10 % at batch 1)."""
-    import heapq
-    bm, bt = _WINO_TILES[cfg]
-    a, b = _WINO_COST[cfg]
-    if bf:
-        a *= _WINO_BF_SPEED[cfg]              # (the F(5,4) kernel has no bf16 x 6 form: never asked for)
-    n_tiles = wino_n_tiles(cfg, length, dil, dil > 1)       # (dilated Winograd launches of the model are phase-major)
-    cot = wpad // bm
-    panel_w = [a * k + b for k in ksteps for _ in range(batch * cot)]
-    run_len = -(-n_tiles // -(-n_tiles // _WINO_RUN))
-    rpp = -(-n_tiles // run_len)
-    real = len(panel_w) * n_tiles
-    load = 1.12 if real > 200 else 1.0 + 0.12 * real / 200        # blocks run ~12 % slower on a full chip
-    if cfg == 6 and real > 8 * cus_per_xcd and max(ksteps) * 16 * 6 * bm * 4 > _WINO_WIDE_PANEL_MAX:
-        load *= 1.4
-    if cfg == WINO_F54 and real > 8 * cus_per_xcd and max(ksteps) * 16 * 8 * bm * 4 > _WINO_WIDE_PANEL_MAX:
-        load *= 1.15          # (C = 768, dilation 3: 625-635 us with 324 128-row blocks against 580 us with 864 96-row half-depth ones)
-    if real > 16384:                                                  # many blocks per CU: throughput bound
-        return load * sum(panel_w) * n_tiles / (8 * cus_per_xcd)
-    total_runs = len(panel_w) * rpp
-    end = 0.0
-    for x in range(8):
-        cu = [0.0] * cus_per_xcd
-        for run in range(x, total_runs, 8):
-            w = panel_w[run // rpp] * load
-            first = (run % rpp) * run_len
-            for _ in range(min(run_len, n_tiles - first)):
-                heapq.heapreplace(cu, cu[0] + w)
-        end = max(end, max(cu))
-    return end
-
-
-def choose_wino_cfg(ksteps, batch, wpad, length, dil, default=None, bf=False):
-    return _choose_wino_cfg(tuple(ksteps), batch, wpad, length, dil, default, bool(bf))
-
-
-@functools.lru_cache(maxsize=4096)
-def _choose_wino_cfg(ksteps, batch, wpad, length, dil, default, bf=False):
-    """Tile shape with the smallest estimated launch time among those the packed weights (cout_pad) allow;
-    the default shape stays unless another one is estimated at least 3 % faster (the model is good to a few
-    per cent; at large batch every shape is within that and the default has the best steady state)."""
-    fam = WINO_F54 if (default is not None and default & WINO_F54) else 0             # tiles of the default's kernel only
-    # (the 48-row F(5,4) block sums a chunk's channels in another order than the 32-row-tile blocks: it is the shape of the
-    # weights it alone divides, never an alternative to the 96-row block)
-    cands = [cfg for cfg, (bm, _) in _WINO_TILES.items()
-             if wpad % bm == 0 and cfg not in _WINO_TILES_OFF and (cfg & WINO_F54) == fam
-             and not (cfg == WINO_F54 | 3 and wpad % 96 == 0)]
-    cost = {cfg: wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, bf=bf) for cfg in cands}
-    best = min(cands, key=lambda cfg: cost[cfg])
-    if default in cost and cost[best] > 0.97 * cost[default]:
-        best = default
-    return best, cost[best]
-
-
-# Winograd F(4,3) weight transform G (6 x 3); interpolation points 0, +-1, +-2, inf
-_WINO_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
-           [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
-WINO_BM = 64
-
-
-def pick_wino_tile(c):
-    """Default (tile_cfg, cout_pad) of the Winograd kernel: 96-row tiles where they divide c and 64-row tiles do
-    not (the launch plan may pick another shape that divides cout_pad: choose_wino_cfg)."""
-    if c % 64 and c % 96 == 0:
-        return 1, c
-    return 0, -(-c // WINO_BM) * WINO_BM
-
-
-def pick_wino54_tile(c):
-    """(plan tile id, cout_pad) of the F(5,4) kernel: 128-row blocks where they divide c, else 96, else 48 (three 16-row MFMA
-    tiles), else 64 (padded)."""
-    if c % 128 == 0:
-        return WINO_F54 | 0, c
-    if c % 96 == 0:
-        return WINO_F54 | 1, c
-    if c % 48 == 0:
-        return WINO_F54 | 3, c
-    return WINO_F54 | 2, -(-c // 64) * 64
-
-
-# Residual-stack convs run in the F(5,4) form (conv_wino54.hip) from this many channels on: 20 % fewer matrix
-# instructions and fewer vector / LDS instructions per MFMA than F(4,3) (tools/wino54_bench.py: x 1.15-1.3 per launch at
-# 192-768 channels, x 1.1-1.2 at 96).  FH_WINO54=0 switches it off (every Winograd conv in the F(4,3) form).  The choice
-# is per STAGE (channel count), never per length or batch: a clip gets the same bits alone, batched, ragged, chunked.
-WINO54_MIN_C = 96
-
-
-def use_wino54(c):
-    """... and at the odd multiples of 48 channels below it (C = 48: the 48-row block has no padding rows, the F(4,3) kernel's
-    64-row tile a quarter; FH_WINO54_H16=0: not there)."""
-    if os.environ.get("FH_WINO54", "1") == "0" or not use_wino(c, 1):
-        return False
-    return c >= int(os.environ.get("FH_WINO54_MIN_C", WINO54_MIN_C)) or (c % 48 == 0 and os.environ.get("FH_WINO54_H16", "1") != "0")
-
-
-def pack_wino_weight(w, cout_pad):
-    """Conv1d weight [co, ci, k] -> transformed [ci/16, G, 6, cout_pad, 16], G = ceil(k/3):
-    u[c, g, xi, co, :] = sum_j G[xi][j] w[co, 16c:16c+16, 3g + j] (float64 on the host, taps past k = 0)."""
-    co, ci, k = w.shape
-    if ci % 16:
-        raise ValueError(f"input channels {ci} must be a multiple of 16")
-    ng = -(-k // 3)
-    wp = torch.zeros(co, ci, 3 * ng, dtype=torch.float64)
-    wp[:, :, :k] = w.double()
-    gm = torch.tensor(_WINO_G, dtype=torch.float64)
-    u = torch.einsum("xj,ocgj->gxoc", gm, wp.view(co, ci, ng, 3))                 # [G, 6, co, ci]
-    u = u.reshape(ng, 6, co, ci // 16, 16).permute(3, 0, 1, 2, 4)                # [ci/16, G, 6, co, 16]
-    p = torch.zeros(ci // 16, ng, 6, cout_pad, 16, dtype=torch.float32)
-    p[:, :, :, :co, :] = u.float()
-    return p.contiguous()
-
-
-# Winograd F(5,4) weight transform G (8 x 4); points 0, 1, -1, 2, -2, 1/2, -1/2, inf with the scaling of
-# tests/tools/winograd_numerics.py: toom_cook (B^T then has the small constants of conv_wino54.hip: kB8Coef)
-_WINO54_G = [[-1, 0, 0, 0], [-2 / 9, -2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9, 2 / 9],
-             [1 / 90, 1 / 45, 2 / 45, 4 / 45], [1 / 90, -1 / 45, 2 / 45, -4 / 45],
-             [32 / 45, 16 / 45, 8 / 45, 4 / 45], [32 / 45, -16 / 45, 8 / 45, -4 / 45], [0, 0, 0, 1]]
-
-
-def pack_wino54_weight(w, cout_pad):
-    """Conv1d weight [co, ci, k] -> transformed [ci/16, G, 8, cout_pad, 16], G = ceil(k/4):
-    u[c, g, xi, co, :] = sum_j G8[xi][j] w[co, 16c:16c+16, 4g + j] (float64 on the host, taps past k = 0)."""
-    co, ci, k = w.shape
-    if ci % 16:
-        raise ValueError(f"input channels {ci} must be a multiple of 16")
-    ng = -(-k // 4)
-    wp = torch.zeros(co, ci, 4 * ng, dtype=torch.float64)
-    wp[:, :, :k] = w.double()
-    gm = torch.tensor(_WINO54_G, dtype=torch.float64)
-    u = torch.einsum("xj,ocgj->gxoc", gm, wp.view(co, ci, ng, 4))                 # [G, 8, co, ci]
-    u = u.reshape(ng, 8, co, ci // 16, 16).permute(3, 0, 1, 2, 4)                # [ci/16, G, 8, co, 16]
-    p = torch.zeros(ci // 16, ng, 8, cout_pad, 16, dtype=torch.float32)
-    p[:, :, :, :co, :] = u.float()
-    return p.contiguous()
-
-
-def pack_amp_weight(w, channels=None):
-    """Conv1d weight [co, ci, k] (co, ci <= channels <= 48, channels % 8 == 0) -> the narrow-stage kernel's transformed weights
-    (amp_fused.hip, flowhigh_hip.h: fh_amp_seg.u): per (8-channel chunk, group of 4 taps) one stage of 1024 ceil(C / 16) floats
-    = blockA [8 points][64 lanes][4] (row tiles 0, 1) | blockB [8 points][64 lanes][2] (the last row tile of an odd count);
-    lane l = 16 kq + r holds U[g][xi][16 m + r][8 chunk + 2 kq + s], U = G8 w in float64 as pack_wino54_weight."""
-    co, ci, k = w.shape
-    c = max(co, ci) if channels is None else channels
-    if c % 8 or c > 48 or co > c or ci > c:
-        raise ValueError(f"narrow-stage conv: {co} x {ci} channels do not fit {c} (a multiple of 8, <= 48)")
-    ng, ma, nch = -(-k // 4), -(-c // 16), c // 8
-    wp = torch.zeros(16 * ma, c, 4 * ng, dtype=torch.float64)
-    wp[:co, :ci, :k] = w.double()
-    gm = torch.tensor(_WINO54_G, dtype=torch.float64)
-    u = torch.einsum("xj,ocgj->gxoc", gm, wp.view(16 * ma, c, ng, 4))            # [G, 8, 16 ma, c]
-    # -> [chunk, g, xi, kq, r, m, s]
-    u = u.view(ng, 8, ma, 16, nch, 4, 2).permute(4, 0, 1, 5, 3, 2, 6).float()    # [chunk, g, xi, kq, r, m, s]
-    parts = []
-    if ma >= 2:
-        parts.append(u[..., :2, :].reshape(nch, ng, 8 * 64 * 4))
-    if ma % 2:
-        parts.append(u[..., ma - 1, :].reshape(nch, ng, 8 * 64 * 2))
-    return torch.cat(parts, dim=-1).contiguous()
-
-
-def amp_tile_len(d):
-    """Outputs per block and row of the narrow-stage kernel at dilation d (fh_amp_tile_len)."""
-    return 5 * d * 4 * (16 // d)
-
-
-AMP_MAX_D = 6             # F_MAX_D of amp_fused.hip
-
-
-def make_amp_seg(x, u, act, k, center=None):
-    """One K segment of a narrow-stage group: conv weights `u` (pack_amp_weight) applied to Activation1d(x) with the
-    parameters `act` (dict alpha, inv_beta, up, down: Vocoder.act_params), or to x itself when act is None."""
-    s = hip.AmpSeg()
-    s.x, s.u, s.ngrp = _addr(x), _addr(u), -(-k // 4)
-    s.center = (k - 1) // 2 if center is None else center
-    if act is not None:
-        s.alpha, s.inv_beta = hip.ptr(act["alpha"]), hip.ptr(act["inv_beta"])
-        for i in range(12):
-            s.up_taps[i] = act["up"][i]
-            s.down_taps[i] = act["down"][i]
-    return s
-
-
-def make_amp_group(segs, bias, res, out, length, scale=1.0):
-    g = hip.AmpGroup()
-    # the kernel walks the segments in one pass per tap-group count, largest first
-    segs = sorted(segs, key=lambda s: -s.ngrp)
-    if any(s.ngrp > 3 or s.center > 5 for s in segs):
-        raise NotImplementedError("narrow-stage kernel: kernels of at most 11 taps")
-    for i, s in enumerate(segs):
-        g.seg[i] = s
-    g.nseg, g.nres = len(segs), len(res)
-    g.bias = _addr(bias)
-    for i, r in enumerate(res):
-        g.res[i] = _addr(r)
-    g.out, g.len, g.scale = _addr(out), length, scale
-    return g
-
-
-def amp_tile_list(lens, batch, dilation):
-    """The work list of a narrow-stage launch (fh_amp_tile: group, batch item, first output, len): int32 tensor [tiles, 4],
-    groups in the given order (heavy first), a group's tiles in (batch item, time) order."""
-    tb = amp_tile_len(dilation)
-    rows = []
-    for gi, length in enumerate(lens):
-        t0 = torch.arange(0, length, tb, dtype=torch.int32)
-        for b in range(batch):
-            e = torch.empty(len(t0), 4, dtype=torch.int32)
-            e[:, 0], e[:, 1], e[:, 2], e[:, 3] = gi, b, t0, length
-            rows.append(e)
-    return torch.cat(rows, dim=0).contiguous()
-
-
-def amp_max_center(groups):
-    """max_center of a narrow-stage launch; raises if some segment's taps do not fit the slab it implies."""
-    segs = [g.seg[i] for g in groups for i in range(g.nseg)]
-    cmax = max(s.center for s in segs)
-    if any(cmax - s.center + 4 * s.ngrp + 3 > 16 for s in segs):
-        raise NotImplementedError("narrow-stage kernel: the kernel sizes of one launch are too far apart")
-    return cmax
-
-
-def amp_actconv(groups, batch, channels, dilation, device, act=True):
-    """Upload descriptors and enqueue one narrow-stage launch (test / one-off use)."""
-    tiles = amp_tile_list([g.len for g in groups], batch, dilation).to(device)
-    d = hip.to_device_struct_array(groups, device)
-    flags = int(all(g.len % 4 == 0 for g in groups)) | (0 if act else 2)
-    hip.check(hip.lib().fh_amp_actconv_f32(d.data_ptr(), len(groups), tiles.data_ptr(), tiles.shape[0], channels, dilation,
-                                           amp_max_center(groups), flags, hip.stream()), "fh_amp_actconv_f32")
-    return d, tiles
-
-
-WINO_BF16X6 = 16          # FH_WINO_BF16X6 of flowhigh_hip.h: tile_cfg flag, three-piece bf16 weights
-WINO_XCD_RANGES = 32      # FH_WINO_XCD_RANGES: tile_cfg flag, blocks -> XCDs by time range instead of by weight panel
-WINO_NOVL = 64            # FH_WINO_NOVL: tile_cfg flag, some row of the launch is not 16-byte aligned although len % 4 == 0
-WINO_MAX_K = 12           # the kernel instantiates 1..4 tap groups of 3
-
-
-def use_bf16x6():
-    """FH_CONV_BF16X6=1: the Winograd convs contract on the BF16 matrix cores with every fp32 operand split exactly into
-    three bf16 pieces (6 bf16 MFMAs per 16-channel k-block, fp32 accumulation): fp32-grade products at 0.375 of the
-    matrix-pipe cycles.  Off by default: the headline numbers are measured on the fp32 MFMA form."""
-    return os.environ.get("FH_CONV_BF16X6", "0") == "1"
-
-
-def split_bf3(u):
-    """fp32 tensor [..., 16] -> int16 tensor [..., 3, 16] of bf16 bit patterns: x = h + m + l with h = bf16(x),
-    m = bf16(x - h), l = bf16(x - h - m) (round to nearest even; the subtractions are exact in fp32)."""
-    u = u.float()
-    h = u.to(torch.bfloat16)
-    r = u - h.float()
-    m = r.to(torch.bfloat16)
-    l = (r - m.float()).to(torch.bfloat16)
-    return torch.stack([h, m, l], dim=-2).contiguous().view(torch.int16)
-
-
-def pack_wino_weight_any(w, cout_pad, bf):
-    """pack_wino_weight, in the three-piece bf16 form when bf."""
-    u = pack_wino_weight(w, cout_pad)
-    return split_bf3(u) if bf else u
-
-
-def _addr(t):
-    """Device address of a tensor, or an address computed by the caller (a channel slice of a batch item)."""
-    return t if isinstance(t, int) else hip.ptr(t)
-
-
-def wino_taps(cfg):
-    """Taps per group of the kernel a plan tile id names: 4 (F(5,4)) or 3 (F(4,3))."""
-    return 4 if cfg & WINO_F54 else 3
-
-
-def wino_split_k(ks, c, wpad, length, dil, default_cfg, bf=False):
-    """Number of input-channel slices (1, 2 or 3) of a residual-stack launch (one group per kernel size in ks)."""
-    t = wino_taps(default_cfg)
-    return wino_split_steps([c // 16 * -(-k // t) for k in ks], c, wpad, length, dil, default_cfg, bf)
-
-
-def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg, bf=False):
-    """Number of input-channel slices (1, 2 or 3) of a Winograd launch whose groups have `ksteps` K steps
-    (cin / 16 x tap groups) each: more than one only where the batch-1 launch model says the blocks are too few and
-    too long (clips under ~2 s); never a function of the batch size, so a clip gives the same bits alone and inside a
-    batch.  FH_WINO_SPLITK=0 switches it off."""
-    if os.environ.get("FH_WINO_SPLITK", "1") == "0":
-        return 1
-    base = choose_wino_cfg(ksteps, 1, wpad, length, dil, default_cfg, bf)[1]
-    best, n = base, 1
-    for ns in (2, 3):
-        if cin % (16 * ns):
-            continue
-        cost = choose_wino_cfg([k // ns for k in ksteps for _ in range(ns)], 1, wpad, length, dil,
-                               default_cfg, bf)[1] + 7.0 * len(ksteps)      # + the adds of the partial outputs
-        if cost < 0.95 * base and cost < best:     # (a slice must be estimated >= 5 % faster)
-            best, n = cost, ns
-    return n
-
-
-def wino_block_mapping(groups, batch, wpad, length, dil, wcfg):
-    """WINO_XCD_RANGES or 0: which block -> XCD mapping reads less from HBM (tools/traffic_per_launch.py: at batch 1 the
-    launches of the 768 / 384 / 192-channel stages read 2.2-5.6 x their algorithmic bytes).  By weight panel (default):
-    a panel's weights are fetched ~once, but the co tiles of a group sit on up to 8 XCDs and each reads the group's
-    whole input: input x min(co tiles, 8), weights x min(runs per panel, 8).  By time range: the input is read once,
-    every XCD fetches all weights once per rectangle of time tiles: weights x 8 x rectangles.  Same bits either way; transposed-conv phase groups (strided outputs) keep the default."""
-    if wcfg & WINO_F54:
-        return 0
-    bm, bt = _WINO_TILES[wcfg]
-    n_tiles = -(-(-(-length // dil)) // bt) * dil
-    # (batch 1 only: with more batch items the by-panel blocks of different items already share a panel's weights through
-    # the L2, and the time-range order measured 4-6 % SLOWER at B = 8 and 32; at B = 1 it is neutral in time)
-    if batch > 1 or n_tiles < 16 or any(g.out_stride > 1 for g in groups):
-        return 0
-    weights = sum(g.seg[i].cin * g.seg[i].ngrp * 6 * wpad * 4.0 for g in groups for i in range(g.nseg))
-    inputs = sum(g.seg[i].cin * length * 4.0 * batch for g in groups for i in range(g.nseg))
-    co_tiles = wpad // bm
-    run_len = -(-n_tiles // -(-n_tiles // _WINO_RUN))
-    runs_per_panel = -(-n_tiles // run_len)             # (a panel's runs are dealt to different XCDs)
-    by_panel = weights * min(runs_per_panel, 8) + inputs * min(co_tiles, 8)
-    tpx = -(-n_tiles // 8)
-    rect = max(1, 32 // co_tiles)                       # time tiles of a rectangle (conv_wino.hip, xcd_ranges branch)
-    by_range = 8.0 * weights * -(-tpx // rect) + inputs
-    return WINO_XCD_RANGES if by_range < 0.9 * by_panel else 0
-
-
-def make_wino_seg(x, u, cin, k, center=None, xlen=0, taps=3):
-    """taps: 3 for the F(4,3) kernel's weights (pack_wino_weight), 4 for F(5,4) (pack_wino54_weight)."""
-    s = hip.WinoSeg()
-    s.x, s.u, s.cin, s.ngrp = _addr(x), _addr(u), cin, -(-k // taps)
-    s.center = (k - 1) // 2 if center is None else center
-    s.xlen = xlen
-    return s
-
-
-def make_wino_group(segs, bias, res, out, cout, cpad, length, scale=1.0, stride=1, phase=0, out_len=0):
-    g = hip.WinoGroup()
-    # the kernel walks the segments in one pass per tap-group count, largest first
-    for i, s in enumerate(sorted(segs, key=lambda s: -s.ngrp)):
-        g.seg[i] = s
-    g.nseg, g.nres = len(segs), len(res)
-    g.bias = _addr(bias)
-    for i, r in enumerate(res):
-        g.res[i] = _addr(r)
-    g.out = _addr(out)
-    if max(cout * stride, max(s.cin for s in segs)) * length * 4 >= 2 ** 31:
-        raise NotImplementedError("per-clip tensor exceeds the 2 GiB range of a buffer descriptor")
-    g.cout, g.cout_pad, g.len, g.scale = cout, cpad, length, scale
-    g.out_stride, g.out_phase, g.out_len = stride, phase, out_len
-    return g
-
-
-def wino_phase_weight(wt, taps):
-    """ConvTranspose1d weight [cin, cout, k] + the taps [(j, offset)] of one output phase (transposed_conv_phases)
-    -> (Conv1d-style weight [cout, cin, k_r] with taps ordered by input offset, center = -smallest offset)."""
-    taps = sorted(taps, key=lambda t: t[1])
-    offs = [o for _, o in taps]
-    if offs != list(range(offs[0], offs[0] + len(offs))):
-        raise NotImplementedError(f"phase offsets {offs} are not contiguous")
-    w = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1).permute(1, 0, 2).contiguous()
-    return w, -offs[0]
-
-
-def phase_len(length, d):
-    """Per-phase row length of the phase-major layout (fh_phase_len)."""
-    return ((length + d - 1) // d + 3) & ~3
-
-
-def to_phase_major(x, d):
-    """[B, C, L] -> [B, C, d * phase_len]: x[..., p + d u] at [..., p * lp + u] (host helper for tests / tools)."""
-    B, C, L = x.shape
-    lp = phase_len(L, d)
-    out = torch.zeros(B, C, d, lp, dtype=x.dtype, device=x.device)
-    for p_ in range(d):
-        v = x[..., p_::d]
-        out[:, :, p_, :v.shape[-1]] = v
-    return out.reshape(B, C, d * lp)
-
-
-def from_phase_major(xp, d, length):
-    B, C, _ = xp.shape
-    lp = phase_len(length, d)
-    v = xp.reshape(B, C, d, lp)
-    out = torch.empty(B, C, length, dtype=xp.dtype, device=xp.device)
-    for p_ in range(d):
-        n = len(range(p_, length, d))
-        out[..., p_::d] = v[:, :, p_, :n]
-    return out
-
-
-def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0, phase_major=False):
-    """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
-    d = hip.to_device_struct_array(groups, device)
-    if tile_cfg & WINO_F54:            # (F(5,4) kernel: the groups' weights are pack_wino54_weight, ngrp = ceil(k / 4))
-        hip.check(hip.lib().fh_conv_wino54_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
-                                               int(phase_major), tile_cfg & 15, hip.stream()), "fh_conv_wino54_f32")
-        return d
-    hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
-                                         int(phase_major), tile_cfg, hip.stream()), "fh_conv_wino_f32")
-    return d
-
-
-def conv_grouped(groups, batch, cout_pad, n_len, tile_cfg, device, ck=8):
-    """Upload descriptors and enqueue one grouped conv launch (test / one-off use)."""
-    d = hip.to_device_struct_array(groups, device)
-    hip.check(hip.lib().fh_conv_grouped_f32(d.data_ptr(), len(groups), batch, cout_pad, n_len, tile_cfg, ck,
-                                            hip.stream()), "fh_conv_grouped_f32")
-    return d
-
-
-def act1d_grouped(groups, batch, channels, length, device, din=1, dout=1):
-    d = hip.to_device_struct_array(groups, device)
-    hip.check(hip.lib().fh_act1d_grouped_pm_f32(d.data_ptr(), len(groups), batch, channels, length, din, dout,
-                                                hip.stream()), "fh_act1d_grouped_pm_f32")
-    return d
-
-
-# ---- occupancy of the activation launches (fh_act_set_blocks_per_cu) --------------------------------------------------
-# On some MI355X boxes an uncapped activation launch (7 blocks = 28 waves per CU: vector ALUs, LDS and HBM busy at once)
-# makes the power management drop the shader clock for the duration of the NEXT launch: a Winograd launch that follows
-# one runs at 2.11 instead of 2.38 GHz (tools/clock_dip_probe.py, tools/box_probe.sh; a device copy of the same bytes does
-# not do it).  With 3 blocks per CU the dip is mostly gone (on such a box the capped activation is 10-15 % slower, the convs
-# 10 % faster); on boxes without the dip the cap would only cost the activation 25 %.  So the setting is measured once per device and process.
-# (tools/exp/occ_ab.sh on both kinds of affected boxes: 4 blocks help on one kind only (bench 500 -> 527) and do nothing on the
-# other (the clock is clamped as before); 3 blocks help on both (488 -> 522, 500 -> 524); 2 blocks: the activation itself
-# is too slow then (512))
-ACT_BLOCKS_CHOICES = (0, 3, 4)          # 0 = no cap; 4 is enough on one kind of affected box (and costs the activation less), 3 on both
-_act_blocks = {}                        # device ordinal -> setting in force
-
-
-def pick_act_blocks(pair_us, slack=0.98):
-    """The decision rule: no cap unless a capped setting makes the (activation + conv) pair at least 2 % faster -- in EVERY
-    measurement pass (pair_us: one {blocks: us} dict, or a list of them, one per pass): a single noisy pass on a shared
-    or busy GPU must not flip the setting."""
-    passes = [pair_us] if isinstance(pair_us, dict) else list(pair_us)
-    wins = [b for b in passes[0] if b != 0 and all(p[b] < slack * p[0] for p in passes)]
-    if not wins:
-        return 0
-    return min(wins, key=lambda b: sorted(p[b] for p in passes)[len(passes) // 2])
-
-
-def parse_act_blocks(value):
-    """FH_ACT_BLOCKS / Vocoder(act_blocks=): None, '' or 'auto' -> None (measure); 0 or 2..5 -> that setting."""
-    if value is None or str(value).strip().lower() in ("", "auto"):
-        return None
-    try:
-        v = int(str(value).strip())
-    except ValueError:
-        v = -1
-    if v != 0 and not 2 <= v <= 5:
-        raise ValueError(f"FH_ACT_BLOCKS / act_blocks must be 'auto', 0 (no cap) or 2..5 blocks per CU, got {value!r}")
-    return v
-
-
-def decide_act_blocks(measure, group=None):
-    """The node-wide choice: with an initialised torch.distributed process group of more than one rank, rank 0 alone runs
-    `measure()` (-> list of per-pass {blocks: us}) and broadcasts its choice -- eight ranks timing launch pairs while
-    their neighbours load models under one power budget would each measure something else.  Returns (choice, passes)."""
-    import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    if not multi:
-        passes = measure()
-        return pick_act_blocks(passes), passes
-    box = [None]
-    if dist.get_rank(group) == 0:
-        passes = measure()
-        box[0] = (pick_act_blocks(passes), passes)
-    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    return box[0]
-
-
-def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100):
-    """Average us of one (activation launch, Winograd launch) pair of a mid-network stage's size with the activation capped
-    at `blocks` per CU (synthetic tensors; the launches are the model's: 3 groups, k = 11 / 7 / 3)."""
-    dev = hip.norm_device(device)
-    with hip.device_guard(dev):
-        g = torch.Generator().manual_seed(0)
-        ks = (11, 7, 3)
-        xs = [torch.randn(1, c, length, generator=g).to(dev) for _ in ks]
-        ys = [torch.empty(1, c, length, device=dev) for _ in ks]
-        outs = [torch.empty(1, c, length, device=dev) for _ in ks]
-        bias = torch.zeros(c, device=dev)
-        # (the conv launch of the model at this width: the F(5,4) kernel unless it is switched off)
-        f54 = use_wino54(c)
-        wcfg, wpad = pick_wino54_tile(c) if f54 else pick_wino_tile(c)
-        pack = pack_wino54_weight if f54 else pack_wino_weight
-        us = [pack(torch.randn(c, c, k, generator=g) * 0.02, wpad).to(dev) for k in ks]
-        gw = hip.to_device_struct_array([make_wino_group([make_wino_seg(ys[i], us[i], c, k, taps=4 if f54 else 3)], bias, [],
-                                                         outs[i], c, wpad, length) for i, k in enumerate(ks)], dev)
-        filt = [0.0] * 5 + [0.5, 0.5] + [0.0] * 5
-        p = dict(alpha=torch.ones(c, device=dev), inv_beta=torch.ones(c, device=dev), up=filt, down=filt)
-        ga = hip.to_device_struct_array([make_act_group(xs[i], ys[i], p) for i in range(len(ks))], dev)
-        lib, st = hip.lib(), hip.stream()
-        before = lib.fh_act_get_blocks_per_cu()
-        hip.check(lib.fh_act_set_blocks_per_cu(blocks), "fh_act_set_blocks_per_cu")
-        try:
-            def pair():
-                hip.check(lib.fh_act1d_grouped_pm_f32(ga.data_ptr(), len(ks), 1, c, length, 1, 1, st), "fh_act1d_grouped_pm_f32")
-                if f54:
-                    hip.check(lib.fh_conv_wino54_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg & 15, st), "fh_conv_wino54_f32")
-                else:
-                    hip.check(lib.fh_conv_wino_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg, st), "fh_conv_wino_f32")
-            for _ in range(warm):
-                pair()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                pair()
-            e1.record()
-            torch.cuda.synchronize(dev)
-        finally:
-            hip.check(lib.fh_act_set_blocks_per_cu(before), "fh_act_set_blocks_per_cu")
-        return e0.elapsed_time(e1) * 1e3 / reps
-
-
-def calibrate_act_occupancy(device, force=False, act_blocks=None):
-    """Choose and set the activation launches' blocks per CU on `device` (once per device and process).
-    act_blocks (Vocoder(act_blocks=)) or FH_ACT_BLOCKS = auto | 0 | 2..5 override the measurement -- a deployment that
-    knows its boxes, or a launcher that wants every rank alike, passes the number.  With torch.distributed initialised
-    rank 0 measures and every rank takes its choice (decide_act_blocks).  The measured pair times are logged
-    (logger 'flowhigh_amd').  Returns the setting.  Results do not depend on it, only launch times."""
-    dev = hip.norm_device(device)
-    if dev.type != "cuda" or not torch.cuda.is_available():
-        return 0
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    fixed = parse_act_blocks(act_blocks)
-    if fixed is None:
-        fixed = parse_act_blocks(os.environ.get("FH_ACT_BLOCKS"))
-    if idx in _act_blocks and not force and (fixed is None or fixed == _act_blocks[idx]):
-        return _act_blocks[idx]
-    if fixed is not None:
-        choice = fixed
-    else:
-        def measure():                               # two alternating passes: the chip's state drifts over the first 100 ms
-            return [{b: measure_act_conv_pair(dev, b) for b in ACT_BLOCKS_CHOICES} for _ in range(2)]
-        choice, passes = decide_act_blocks(measure)
-        calibrate_act_occupancy.last_measurement = passes
-        import logging
-        logging.getLogger("flowhigh_amd").info("activation occupancy on cuda:%d: %s blocks per CU; (activation, conv) pair us per pass: %s",
-                                               idx, choice or "uncapped (7)", passes)
-    with hip.device_guard(dev):
-        hip.check(hip.lib().fh_act_set_blocks_per_cu(choice), "fh_act_set_blocks_per_cu")
-    _act_blocks[idx] = choice
-    return choice
-
-
-calibrate_act_occupancy.last_measurement = None
-
-
-class _PlanBuilder:
-    """Builds the launch plan of one [batch, num_mels, n_frames] shape (Vocoder.plan): workspace pool, descriptor
-    arrays and the ordered list of launch steps.
-    steps[i] = (kind, ...) is what Vocoder._launch runs; meta[i] = (position key, host descriptor structs): the position
-    key names the step's place in the model -- (stage, sub-block, slot, index) -- so that the plans of different clips
-    can be merged launch by launch (Vocoder.plan_ragged) although their optional steps differ."""
-
-    def __init__(self, voc, batch, n_frames, ref_frames):
-        self.v, self.B, self.N = voc, batch, n_frames
-        self.f32 = dict(dtype=torch.float32, device=voc.device)
-        self.steps, self.meta, self.keep = [], [], []         # keep: tensors the descriptors point into
-        self.key = None                                       # position key of the steps being added
-        self.executed = 0.0     # FLOPs issued to the matrix cores by all conv launches (Winograd: 1.5 G / k of the algorithmic)
-        self.direct = 0.0       # ... of which by the direct-kernel launches
-        self.L = n_frames                                     # current stage length
-        self.Lref = ref_frames                                # ... of the whole clip (== L unless this plan is a chunk)
-        self.parts = None                                     # split-K partial outputs, allocated on first use
-        v = voc
-        dils = sorted({d for dl in v.dil for d in dl})
-        # (phase-major intermediates of the dilated convs are padded to d * phase_len >= L floats per row)
-        lens = v.stage_lengths(n_frames)
-        self.max_elems = max(st["c"] * max(d * phase_len(lens[i], d) for d in dils + [1]) for i, st in enumerate(v.stages))
-        # (rows past the checkpoint's num_mels -- channel padding to a multiple of 8 -- stay zero)
-        self.mel_in = torch.zeros(batch, v.num_mels, n_frames, **self.f32)
-        self.pool = torch.empty(2 + 4 * v.nk, batch * self.max_elems, **self.f32)
-        self.keep.append(self.pool)
-
-    # ---- step bookkeeping -------------------------------------------------------------------------------------
-    def at(self, *key):
-        self.key = key
-
-    def add(self, step, structs=None, key=None):
-        self.meta.append((key if key is not None else self.key, structs))
-        self.steps.append(step)
-
-    def parts_buffer(self):
-        if self.parts is None:
-            self.parts = torch.empty(2 * self.v.nk, self.B * self.max_elems, **self.f32)
-            self.keep.append(self.parts)
-        return self.parts
-
-    # ---- one launch each ----------------------------------------------------------------------------------------
-    def conv(self, groups, cpad, n_len, tcfg, ck):
-        """Direct-kernel launch.  Few-block launches (first-stage upsampler, fused stage-closing conv at short
-        sequence lengths) switch from the 128 x 128 to the 128 x 64 tile to fill the 256 CUs."""
-        if tcfg == 0 and len(groups) * self.B * (cpad // 128) * -(-n_len // 128) < 512:
-            tcfg = 5
-        d = hip.to_device_struct_array(groups, self.v.device)
-        self.keep.append(d)
-        flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * self.B for g in groups for i in range(g.nseg))
-        self.executed += flops
-        self.direct += flops
-        self.add(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops), groups)
-
-    def wino(self, groups, wpad, length, dil, wcfg, pm=False, flops=None, batch=None, novl=False):
-        """Winograd launch; the tile shape is the launch model's (choose_wino_cfg).  batch: launches whose groups are
-        per batch item (input-channel slices) pass 1.  novl: some row of the launch is not 16-byte aligned although
-        `length` may be a multiple of 4 (segments with xlen)."""
-        B = self.B if batch is None else batch
-        wcfg, _ = choose_wino_cfg([sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg)) for g in groups],
-                                  B, wpad, length, dil, default=wcfg, bf=self.v.bf)
-        wcfg |= wino_block_mapping(groups, B, wpad, length, dil, wcfg)
-        if wcfg & WINO_F54 and any(g.out_stride > 1 or g.out_len or g.seg[i].ngrp > 3 or g.seg[i].xlen
-                                   for g in groups for i in range(g.nseg)):
-            raise NotImplementedError("the F(5,4) kernel takes plain convs of at most 12 taps (no strided outputs, xlen, out_len)")
-        if novl:
-            if wcfg & WINO_F54:
-                raise NotImplementedError("the F(5,4) kernel takes no segments with xlen")
-            wcfg |= WINO_NOVL
-        d = hip.to_device_struct_array(groups, self.v.device)
-        self.keep.append(d)
-        if flops is None:
-            flops = sum(2.0 * g.cout * g.seg[i].cin * (2 * g.seg[i].center + 1) * length * B
-                        for g in groups for i in range(g.nseg))
-        # multiply-adds the matrix cores actually execute: 6 per 4 outputs per group of 3 taps, or 8 per 5 per group of 4
-        per_out = 1.6 if wcfg & WINO_F54 else 1.5
-        self.executed += sum(2.0 * g.cout * g.seg[i].cin * per_out * g.seg[i].ngrp * length * B
-                             for g in groups for i in range(g.nseg))
-        self.add(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B), groups)
-
-    def act(self, groups, c, length, din=1, dout=1):
-        d = hip.to_device_struct_array(groups, self.v.device)
-        self.keep.append(d)
-        self.add(("act", d, len(groups), c, length, din, dout), groups)
-
-    def res_conv(self, st, ents, xs_in, ks, dil, outs, res, pm=False, defer_sum=False):
-        """One launch of the same conv position in the nk AMP blocks (one group per block) at the current stage
-        length.  Returns, per block, the tensors whose sum is the conv's output (more than one: input-channel slices
-        whose partial outputs the caller adds, defer_sum)."""
-        c, cpad, wpad, L, B = st["c"], st["cpad"], st["wpad"], self.L, self.B
-        biases = [e["b"] for e in ents]
-        all_wino = all("u" in e for e in ents)
-        nsplit = wino_split_k(ks, c, wpad, self.Lref, dil, st["wcfg"], self.v.bf) if all_wino else 1
-        if nsplit > 1:
-            # Short clips: a launch of a few dozen blocks is bound by the K loop of ONE block.  The input channels
-            # are cut into nsplit slices, one group each (first slice: bias and residual), and the partial
-            # outputs are added in a fixed order.  Decided from the clip length alone, so a clip gives the same
-            # bits alone and inside a batch; one group per batch item (a slice is not a whole [B, C, L] tensor).
-            parts = self.parts_buffer()
-            pitch = dil * phase_len(L, dil) if pm else L
-            cs = c // nsplit
-            addr = lambda t, b, ch: t.data_ptr() + 4 * (b * c + ch) * pitch
-            groups = []
-            for i, e in enumerate(ents):
-                for sl in range(nsplit):
-                    dst = outs[i] if sl == 0 else parts[2 * i + sl - 1]
-                    for b in range(B):
-                        seg = make_wino_seg(addr(xs_in[i], b, sl * cs), e["u"][sl * cs // 16:], cs, ks[i], taps=st["taps"])
-                        groups.append(make_wino_group([seg], biases[i] if sl == 0 else None,
-                                                      [addr(r, b, 0) for r in res[i]] if sl == 0 else [],
-                                                      addr(dst, b, 0), c, wpad, L))
-            self.wino(groups, wpad, L, dil, st["wcfg"], pm, batch=1, flops=sum(2.0 * c * c * k * L * B for k in ks))
-            pieces = [[outs[i]] + [parts[2 * i + sl] for sl in range(nsplit - 1)] for i in range(len(ents))]
-            if not defer_sum:
-                for i in range(len(ents)):
-                    self.add(("sum", pieces[i], outs[i], B * c * pitch, 1.0), key=self.key[:2] + (self.key[2] + 1, i))
-            return pieces
-        if all_wino:
-            self.wino([make_wino_group([make_wino_seg(xs_in[i], ents[i]["u"], c, ks[i], taps=st["taps"])], biases[i], res[i],
-                                       outs[i], c, wpad, L) for i in range(len(ents))], wpad, L, dil, st["wcfg"], pm)
-        else:
-            groups = []
-            for i, e in enumerate(ents):
-                offs = [(t - (ks[i] - 1) // 2) * dil for t in range(ks[i])]
-                groups.append(make_conv_group([make_conv_seg(xs_in[i], e["w"], c, offs)], biases[i], res[i], outs[i],
-                                              c, cpad, L, L, L))
-            self.conv(groups, cpad, L, st["tile_cfg"], st["ck"])
-        return [[o] for o in outs]
-
-    def mixed_dilation_conv(self, st, order, ents, ks, ds, xs_in, outs, res):
-        """The nk convs of one position with DIFFERENT dilations: one direct launch, per-group tap offsets."""
-        c, cpad, L = st["c"], st["cpad"], self.L
-        self.conv([make_conv_group([make_conv_seg(xs_in[n], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])],
-                                   e["b"], res[n], outs[n], c, cpad, L, L, L)
-                   for n, (e, k, d) in enumerate(zip(ents, ks, ds))], cpad, L, st["tile_cfg"], st["ck"])
-
-    # ---- model sections -------------------------------------------------------------------------------------------
-    def conv_pre(self):
-        v, N = self.v, self.N
-        pre = torch.empty(self.B, v.c0, N, **self.f32)
-        self.keep.append(pre)       # descriptors hold raw pointers: every buffer they name must outlive the plan
-        self.at(-1, 0, 0, 0)
-        if v.pre_u is not None:
-            self.wino([make_wino_group([make_wino_seg(self.mel_in, v.pre_u, v.num_mels, 7)], v.pre_b, [], pre, v.c0,
-                                       v.pre_wpad, N)], v.pre_wpad, N, 1, v.pre_wcfg)
-        else:
-            k7 = [j - 3 for j in range(7)]
-            self.conv([make_conv_group([make_conv_seg(self.mel_in, v.pre_w, v.num_mels, k7)], v.pre_b, [], pre, v.c0,
-                                       v.pre_cpad, N, N, N)], v.pre_cpad, N, v.pre_cfg, v.pre_ck)
-        return pre
-
-    def average(self, ys, out, n, scale, key):
-        """out = scale * (((ys[0] + ys[1]) + ys[2]) + ...): the `xs += resblock(x)` / `xs / num_kernels` of
-        models.py:181-187 in the reference's block order, for stages whose closing conv is not fused."""
-        if len(ys) in (2, 3):
-            self.add(("mean", ys[0], ys[1], ys[2] if len(ys) == 3 else None, out, n, scale), key=key)
-        elif len(ys) <= 12:
-            self.add(("sum", list(ys), out, n, scale), key=key)
-        else:
-            raise NotImplementedError("more than 12 resblock kernel sizes")
-
-    def enter_stage(self, i):
-        """Stage i: lengths and the views of the workspace pool (slot 0 = X: upsampled input, 1 = S: stage output,
-        then per AMP block j: 2 + 4 j = T1, 3 + 4 j = T2, 4 / 5 + 4 j = Y ping-pong)."""
-        v, st = self.v, self.v.stages[i]
-        # (ConvTranspose1d with an odd k - u returns u * L + 1 samples: models.py:141-146)
-        self.lin, self.L = self.L, self.L * st["u"] + st["extra"]
-        self.lin_ref, self.Lref = self.Lref, self.Lref * st["u"] + st["extra"]
-        c, B, L = st["c"], self.B, self.L
-        view = lambda idx: self.pool[idx, :B * c * L].view(B, c, L)
-        self.X, self.S = view(0), view(1)
-        self.T1 = [view(2 + 4 * j) for j in range(v.nk)]
-        self.T2 = [view(3 + 4 * j) for j in range(v.nk)]
-        self.Y = [[view(4 + 4 * j), view(5 + 4 * j)] for j in range(v.nk)]
-        # heavy kernel sizes first (dispatch order == launch order of the panels)
-        self.order = sorted(range(v.nk), key=lambda j: -st["blocks"][j]["k"])
-
-    def upsampler(self, i, cur):
-        """ConvTranspose1d(cin -> c, stride u) as u output-phase groups: Winograd groups with strided stores for the
-        wide stages, direct-kernel groups otherwise."""
-        v, st, B = self.v, self.v.stages[i], self.B
-        c, u, lin, L, X = st["c"], st["u"], self.lin, self.L, self.X
-        # k - u odd: L = u * lin + 1; phase 0 has lin + 1 output positions, the other phases lin
-        extra = st["extra"]
-        npos = lin + extra
-        self.at(i, -1, 0, 0)
-        if st["up_wino"] is None:
-            self.conv([make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X, c,
-                                       st["cpad"], lin, L, npos if r == 0 else lin, stride=u, phase=r)
-                       for r, ph in enumerate(st["up_phases"])], st["cpad"], npos, st["tile_cfg"], st["up_ck"])
-            return
-        # (Winograd phase groups: all have `npos` positions, writes at u * n + r >= L are masked: fh_wino_group.out_len)
-        xlen, olen = (lin, L) if extra else (0, 0)
-        up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
-        nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"], st["up_wpad"],
-                                  self.lin_ref + extra, 1, st["up_wcfg"], v.bf)
-        if nsplit == 1:
-            self.wino([make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"], xlen=xlen)], st["up_b"],
-                                       [], X, c, st["up_wpad"], npos, stride=u, phase=r, out_len=olen)
-                       for r, ph in enumerate(st["up_wino"])],
-                      st["up_wpad"], npos, 1, st["up_wcfg"], flops=up_flops, novl=bool(extra))
-            return
-        parts = self.parts_buffer()             # short clips: input channels in slices, as in res_conv
-        cs = st["cin"] // nsplit
-        dsts = [X] + [parts[sl] for sl in range(nsplit - 1)]
-        groups = [make_wino_group([make_wino_seg(cur.data_ptr() + 4 * (b * st["cin"] + sl * cs) * lin,
-                                                 ph["u"][sl * cs // 16:], cs, ph["k"], ph["center"], xlen=xlen)],
-                                  st["up_b"] if sl == 0 else None, [], dsts[sl].data_ptr() + 4 * b * c * L,
-                                  c, st["up_wpad"], npos, stride=u, phase=r, out_len=olen)
-                  for r, ph in enumerate(st["up_wino"]) for sl in range(nsplit) for b in range(B)]
-        self.wino(groups, st["up_wpad"], npos, 1, st["up_wcfg"], flops=up_flops, batch=1, novl=bool(extra))
-        self.add(("sum", dsts, X, B * c * L, 1.0), key=(i, -1, 1, 0))
-
-    def amp1_stack(self, i):
-        """The nk AMPBlock1 of stage i (models.py:21-78), position by position: act -> conv1 (dilated) -> act -> conv2
-        (+ x) per dilation; the last conv2 closes the stage (closing_conv)."""
-        v, st = self.v, self.v.stages[i]
-        c, L, order = st["c"], self.L, self.order
-        T1, T2, Y = self.T1, self.T2, self.Y
-        xin = [self.X] * v.nk
-        blks = [st["blocks"][j] for j in order]
-        ks = [b_["k"] for b_ in blks]
-        for m in range(v.nm):
-            d1 = blks[0]["dil"][m]
-            same_d = all(b_["dil"][m] == d1 for b_ in blks)
-            # dilated Winograd conv: the activations on both sides write / read phase-major tensors
-            pm = same_d and 1 < d1 <= 16 and all("u" in b_["c1"][m] for b_ in blks)
-            dpm = d1 if pm else 1
-            self.at(i, m, 0, 0)
-            self.act([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L, dout=dpm)
-            self.at(i, m, 1, 0)
-            ents = [b_["c1"][m] for b_ in blks]
-            if same_d:
-                self.res_conv(st, ents, [T1[j] for j in order], ks, d1, [T2[j] for j in order], [[] for _ in blks], pm=pm)
-            else:
-                self.mixed_dilation_conv(st, order, ents, ks, [b_["dil"][m] for b_ in blks], [T1[j] for j in order],
-                                         [T2[j] for j in order], [[] for _ in blks])
-            self.at(i, m, 3, 0)
-            self.act([make_act_group(T2[j], T1[j], st["blocks"][j]["acts"][2 * m + 1]) for j in order], c, L, din=dpm)
-            self.at(i, m, 4, 0)
-            ents = [b_["c2"][m] for b_ in blks]
-            if m < v.nm - 1:
-                self.res_conv(st, ents, [T1[j] for j in order], ks, 1, [Y[j][m % 2] for j in order],
-                              [[xin[j]] for j in order])
-                xin = [Y[j][m % 2] for j in range(v.nk)]
-            else:
-                self.closing_conv(i, m, ents, ks, [1] * v.nk, xin)
-
-    def amp2_stack(self, i):
-        """The nk AMPBlock2 of stage i (models.py:81-121): one activation + one conv (+ x) per dilation; the last one
-        closes the stage."""
-        v, st = self.v, self.v.stages[i]
-        c, L, order = st["c"], self.L, self.order
-        T1, Y = self.T1, self.Y
-        xin = [self.X] * v.nk
-        blks = [st["blocks"][j] for j in order]
-        ks = [b_["k"] for b_ in blks]
-        for m in range(v.nm):
-            ents = [b_["c1"][m] for b_ in blks]
-            ds = [b_["dil"][m] for b_ in blks]
-            self.at(i, m, 0, 0)
-            self.act([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][m]) for j in order], c, L)
-            self.at(i, m, 1, 0)
-            if m == v.nm - 1 and all("w" in e for e in ents):
-                self.closing_conv(i, m, ents, ks, ds, xin)          # direct kernel: K segments of one group
-                continue
-            outs = [Y[j][m % 2] for j in order]
-            if all(d == ds[0] for d in ds):
-                self.res_conv(st, ents, [T1[j] for j in order], ks, ds[0], outs, [[xin[j]] for j in order])
-            else:
-                self.mixed_dilation_conv(st, order, ents, ks, ds, [T1[j] for j in order], outs, [[xin[j]] for j in order])
-            xin = [Y[j][m % 2] for j in range(v.nk)]
-            if m == v.nm - 1:            # xs / num_kernels, block order = the reference's xs += order
-                self.average(xin, self.S, self.B * c * L, 1.0 / v.nk, key=(i, m, 6, 0))
-
-    def closing_conv(self, i, m, ents, ks, ds, xin):
-        """The stage-closing conv position: xs = sum over blocks of (conv(T1_j) + x_j); S = xs / num_kernels
-        (models.py:181-187).  Fused form: ONE group with nk K segments, the blocks are summed in the accumulator and
-        / nk is the epilogue scale.  Unfused form: nk groups (more blocks for the 256 CUs) + one averaging pass; whichever
-        the launch model says is faster for ONE clip of the whole clip's length (the two forms round differently, and a
-        clip must give the same bits alone, inside a batch and in chunks)."""
-        v, st = self.v, self.v.stages[i]
-        c, cpad, wpad, L, B, order = st["c"], st["cpad"], st["wpad"], self.L, self.B, self.order
-        T1, Y, S = self.T1, self.Y, self.S
-        scale = 1.0 / v.nk
-        fusable = v.nk <= hip.CONV_MAX_SEG          # (K segments of one group; more blocks: one group each + one averaging pass)
-        if all("u" in e for e in ents):
-            ksteps = [c // 16 * -(-k // st["taps"]) for k in ks]
-            Lr = self.Lref
-            # (averaging pass: 16 bytes per element that the conv launch has just written -- measured 19 us for 184 MB, i.e. it
-            # runs out of the last-level cache, ~8 bytes per ns)
-            unfuse = not fusable or (v.nk in (2, 3) and (choose_wino_cfg(ksteps, 1, wpad, Lr, 1, st["wcfg"], v.bf)[1] + 4.0 + c * Lr * 16 / 8.0e6
-                                                         < choose_wino_cfg([sum(ksteps)], 1, wpad, Lr, 1, st["wcfg"], v.bf)[1]))
-            if not unfuse:
-                segs = [make_wino_seg(T1[j], e["u"], c, k, taps=st["taps"]) for j, e, k in zip(order, ents, ks)]
-                self.wino([make_wino_group(segs, st["last_bias"], [xin[j] for j in order], S, c, wpad, L, scale=scale)],
-                          wpad, L, 1, st["wcfg"])
-                return
-            one_pass = 3 * v.nk <= 12                           # (a sum pass takes 12 sources: up to 3 slices per block)
-            pieces = self.res_conv(st, ents, [T1[j] for j in order], ks, 1, [Y[j][m % 2] for j in order],
-                                   [[xin[j]] for j in order], defer_sum=one_pass)
-            if len(pieces[0]) > 1 and one_pass:                 # input-channel slices: all partial outputs in one pass
-                by_block = {j: pieces[n_] for n_, j in enumerate(order)}
-                self.add(("sum", [t for j in range(v.nk) for t in by_block[j]], S, B * c * L, scale), key=(i, m, 6, 0))
-            else:
-                self.average([Y[j][m % 2] for j in range(v.nk)], S, B * c * L, scale, key=(i, m, 6, 0))
-            return
-        if not fusable:
-            outs, res = [Y[j][m % 2] for j in order], [[xin[j]] for j in order]
-            if all(d == ds[0] for d in ds):
-                self.res_conv(st, ents, [T1[j] for j in order], ks, ds[0], outs, res)
-            else:
-                self.mixed_dilation_conv(st, order, ents, ks, ds, [T1[j] for j in order], outs, res)
-            self.average([Y[j][m % 2] for j in range(v.nk)], S, B * c * L, scale, key=(i, m, 6, 0))
-            return
-        segs = [make_conv_seg(T1[j], e["w"], c, [(t - (k - 1) // 2) * d for t in range(k)])
-                for j, e, k, d in zip(order, ents, ks, ds)]
-        self.conv([make_conv_group(segs, st["last_bias"], [xin[j] for j in order], S, c, cpad, L, L, L, scale=scale)],
-                  cpad, L, st["tile_cfg"], st["ck"])
-
-    def finish(self, cur):
-        """activation_post + conv_post + tanh, and the plan record."""
-        v, B, L = self.v, self.B, self.L
-        c_last = v.stages[-1]["c"]
-        post_t = self.pool[2, :B * c_last * L].view(B, c_last, L)
-        self.at(99, 0, 0, 0)
-        self.act([make_act_group(cur, post_t, v.post_act)], c_last, L)
-        wav = torch.empty(B, L, **self.f32)
-        self.add(("post", post_t, wav, c_last, L), key=(99, 0, 1, 0))
-        # algorithmic HBM bytes of the Activation1d launches: every site reads and writes its [B, C, L] tensor once
-        act_bytes = sum(8.0 * s_[2] * B * s_[3] * s_[4] for s_ in self.steps if s_[0] == "act")
-        return dict(steps=self.steps, meta=self.meta, keep=self.keep, mel_in=self.mel_in, wav=wav, B=B, N=self.N, L=L,
-                    conv_executed_flops=self.executed, conv_direct_flops=self.direct, act_bytes=act_bytes,
-                    n_act=sum(s_[0] == "act" for s_ in self.steps))
 
 
 class Vocoder:
@@ -1311,167 +284,12 @@ class Vocoder:
     # ---- ragged batches (clips of different lengths in ONE launch sequence) ------------------------
     @hip.on_device
     def plan_ragged(self, frames):
-        """Merged launch plan for clips of frame counts `frames` (any mix of lengths, batch 1 each).
-        Every clip keeps the plan it has alone (`plan(1, N)`: its own buffers, the same groups, K segments,
-        input-channel slices and partial-sum steps -- so the same bits); steps that sit at the same position of the
-        model are then launched together: one conv / activation launch carries the groups of all clips (the kernels
-        take a length per group; the grid is sized for the longest and blocks past a group's end exit), the partial-sum
-        / averaging passes become one multi-job launch.  A mix of 24 clips runs ~120 launches instead of ~2 900."""
-        frames = tuple(int(n) for n in frames)
-        key = ("ragged",) + frames
-        if key in self._ragged:
-            return self._ragged[key]
-        seen, subs = {}, []
-        for n in frames:
-            k = seen.get(n, 0)
-            seen[n] = k + 1
-            subs.append(self.plan(1, n, inst=k))
-        by_key = {}
-        for ci, sp in enumerate(subs):
-            ks = [m[0] for m in sp["meta"]]
-            if len(set(ks)) != len(ks):
-                raise NotImplementedError("this vocoder configuration has launch positions that cannot be merged")
-            for step, (k, structs) in zip(sp["steps"], sp["meta"]):
-                by_key.setdefault(k, []).append((ci, step, structs))
-        blobs, merged = [], []          # host bytes of every descriptor array (one upload), merged steps
-
-        def blob(structs):
-            arr = (type(structs[0]) * len(structs))(*structs)
-            off = sum(len(b) for b in blobs)
-            raw = bytes(arr)
-            blobs.append(raw + bytes(-len(raw) % 16))
-            return off
-
-        tt = hip.lib().fh_act_tile_len()
-        for k in sorted(by_key):
-            items = by_key[k]
-            kinds = {"sum" if it[1][0] == "mean" else it[1][0] for it in items}     # (a mean is a 2-3 term sum job)
-            if len(kinds) != 1:
-                raise NotImplementedError(f"launch position {k}: kinds {kinds} cannot be merged")
-            kind = kinds.pop()
-            if kind == "wino":
-                classes = {}
-                for ci, st_, groups in items:
-                    _, _d, ng, wpad, length, dil, _fl, wcfg, pm, bb = st_
-                    assert bb == 1 and ng == len(groups)
-                    classes.setdefault((wpad, dil, pm, wcfg & WINO_F54), []).append((length, wcfg, groups))
-                for (wpad, dil, pm, fam), lst in classes.items():
-                    allg = [(sum(g.seg[i].cin // 16 * g.seg[i].ngrp for i in range(g.nseg)), length, g)
-                            for length, _, groups in lst for g in groups]
-                    allg.sort(key=lambda t: (-t[0], -t[1]))                 # heavy groups first (dispatch order)
-                    maxlen = max(t[1] for t in allg)
-                    default = max(lst, key=lambda t: t[0])[1] & (15 | WINO_F54)          # the longest clip's tile shape
-                    wcfg = default
-                    if default in (0, 1, 4, 5) or fam:
-                        # the launch model takes one length: the mean one keeps the block count honest
-                        mean_len = max(1, sum(t[1] for t in allg) // len(allg))
-                        wcfg, _ = choose_wino_cfg([t[0] for t in allg], 1, wpad, mean_len, dil, default=default, bf=self.bf)
-                    novl = 0 if (pm or all(t[1] % 4 == 0 for t in allg)) else 2
-                    if any(w & WINO_NOVL for _, w, _ in lst):               # (segments with xlen: odd-(k - u) upsamplers)
-                        novl = 2
-                    # runs (consecutive tiles of one (group, co tile) panel, dealt to one XCD) that hold real tiles
-                    bm, bt = _WINO_TILES[wcfg]
-                    cot = wpad // bm
-                    n_tiles = wino_n_tiles(wcfg, maxlen, dil, pm)
-                    run_len = (hip.lib().fh_wino54_run_len if fam else hip.lib().fh_wino_run_len)(n_tiles)
-                    rpp = -(-n_tiles // run_len)
-                    runs = []
-                    for gi, (_, length, _) in enumerate(allg):
-                        # tile index = (block of bt outputs within the phase) * dil + phase: real while its first
-                        # output (phase + dil * bt * block) lies inside the row
-                        # (blocks per phase differ by at most one, so the real tiles are 0 .. t_last without holes)
-                        if fam and pm:                  # (the F(5,4) kernel's concatenated tiling: a group's real tiles are the first ones)
-                            t_last = wino_n_tiles(wcfg, length, dil, pm) - 1
-                        else:
-                            nb = [max(0, -(-(length - ph) // (dil * bt))) for ph in range(dil)]
-                            t_last = dil * (nb[0] - 1) + sum(1 for v in nb if v == nb[0]) - 1
-                        own = range(t_last // run_len + 1)
-                        for ct in range(cot):
-                            runs += [(gi * cot + ct) * rpp + r for r in own]
-                    rmap = (C.c_int32 * len(runs))(*runs)
-                    off_map = sum(len(b) for b in blobs)
-                    raw = bytes(rmap)
-                    blobs.append(raw + bytes(-len(raw) % 16))
-                    merged.append(("rwino", blob([t[2] for t in allg]), len(allg), wpad, maxlen, dil, wcfg,
-                                   int(pm) | novl, off_map, len(runs)))
-            elif kind == "conv":
-                classes = {}
-                for ci, st_, groups in items:
-                    _, _d, ng, cpad, n_len, tcfg, ck, _fl = st_
-                    classes.setdefault((cpad, ck), []).append((n_len, tcfg, groups))
-                for (cpad, ck), lst in classes.items():
-                    allg = [(sum(g.seg[i].cin * g.seg[i].ntaps for i in range(g.nseg)), n_len, g)
-                            for n_len, _, groups in lst for g in groups]
-                    allg.sort(key=lambda t: (-t[0], -t[1]))
-                    tcfg = max(lst, key=lambda t: t[0])[1]
-                    merged.append(("rconv", blob([t[2] for t in allg]), len(allg), cpad, max(t[1] for t in allg), tcfg, ck))
-            elif kind == "act":
-                classes = {}
-                for ci, st_, groups in items:
-                    _, _d, ng, c, length, din, dout = st_
-                    classes.setdefault((c, din, dout), []).append((length, groups))
-                for (c, din, dout), lst in classes.items():
-                    out, base = [], 0
-                    for length, groups in sorted(lst, key=lambda t: -t[0]):
-                        for g in groups:
-                            g2 = hip.ActGroup.from_buffer_copy(g)
-                            g2.len, g2.tile_base = length, base
-                            base += c * -(-length // tt)
-                            out.append(g2)
-                    merged.append(("ract", blob(out), len(out), c, din, dout, base, int(all(g.len % 4 == 0 for g in out))))
-            elif kind == "sum":
-                jobs = []
-                for ci, st_, _ in items:
-                    if st_[0] == "sum":
-                        _, srcs, out, n, scale = st_
-                    else:
-                        _, a, b_, c_, out, n, scale = st_
-                        srcs = [a, b_] + ([c_] if c_ is not None else [])
-                    j = hip.SumJob()
-                    for i, t in enumerate(srcs):
-                        j.src[i] = t.data_ptr()
-                    j.out, j.n, j.n_src, j.scale = out.data_ptr(), n, len(srcs), scale
-                    if n % 4 or len(srcs) > 12:
-                        raise NotImplementedError("partial-sum job shape")
-                    jobs.append(j)
-                merged.append(("rsum", blob(jobs), len(jobs), max(j.n for j in jobs)))
-            elif kind == "post":
-                for ci, st_, _ in items:
-                    merged.append(st_)
-            else:
-                raise NotImplementedError(kind)
-        host = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8)
-        desc = host.to(self.device)
-        rp = dict(subs=subs, steps=merged, desc=desc, frames=frames)
-        # The merged descriptors hold raw pointers into the clips' plans, so the entry keeps them alive -- and is
-        # accounted with everything it keeps alive (the sub-plans' workspaces, ~65 MB per second of audio), so that
-        # FH_CACHE_GB bounds what the ragged cache can pin whatever self._plans has evicted meanwhile.
-        self._ragged[key] = rp
-        return rp
+        """Merged launch plan for clips of frame counts `frames` (any mix of lengths, batch 1 each): planner.merge_ragged."""
+        return merge_ragged(self, frames)
 
     @hip.on_device
     def run_ragged(self, rp):
-        L, st, base = hip.lib(), hip.stream(), rp["desc"].data_ptr()
-        for s in rp["steps"]:
-            if s[0] == "rwino":
-                _, off, ng, wpad, maxlen, dil, wcfg, pmflag, off_map, n_runs = s
-                if wcfg & WINO_F54:
-                    hip.check(L.fh_conv_wino54_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, wcfg & 15, base + off_map,
-                                                          n_runs, st), "fh_conv_wino54_ragged_f32")
-                else:
-                    hip.check(L.fh_conv_wino_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, wcfg | self.wino_flag,
-                                                        base + off_map, n_runs, st), "fh_conv_wino_ragged_f32")
-            elif s[0] == "rconv":
-                _, off, ng, cpad, maxlen, tcfg, ck = s
-                hip.check(L.fh_conv_grouped_f32(base + off, ng, 1, cpad, maxlen, tcfg, ck, st), "fh_conv_grouped_f32")
-            elif s[0] == "ract":
-                _, off, ng, c, din, dout, tiles, mult4 = s
-                hip.check(L.fh_act1d_ragged_f32(base + off, ng, c, din, dout, tiles, mult4, st), "fh_act1d_ragged_f32")
-            elif s[0] == "rsum":
-                _, off, nj, max_n = s
-                hip.check(L.fh_sum_multi_f32(base + off, nj, max_n, st), "fh_sum_multi_f32")
-            else:
-                self._launch(s, 1, st)
+        run_ragged_steps(self, rp)
 
     @hip.on_device
     def forward_ragged(self, mels):
@@ -1569,56 +387,4 @@ class Vocoder:
 
     @hip.on_device
     def run(self, p):
-        self._run_steps(p["steps"], p["B"], hip.stream())
-
-    def _launch(self, s, B, st):
-        L = hip.lib()
-        if s[0] == "conv":
-            _, d, ng, cpad, n_len, tcfg, ck, _flops = s
-            timing = self.conv_timing          # optional list of (start, end) events around conv launches
-            if timing is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            hip.check(L.fh_conv_grouped_f32(d.data_ptr(), ng, B, cpad, n_len, tcfg, ck, st), "fh_conv_grouped_f32")
-            if timing is not None:
-                e1.record()
-                timing.append((e0, e1))
-        elif s[0] == "wino":
-            _, d, ng, wpad, length, dil, _flops, wcfg, pm, bb = s
-            timing = self.conv_timing
-            if timing is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if wcfg & WINO_F54:
-                hip.check(L.fh_conv_wino54_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, wcfg & 15, st), "fh_conv_wino54_f32")
-            else:
-                hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, wcfg | self.wino_flag, st), "fh_conv_wino_f32")
-            if timing is not None:
-                e1.record()
-                timing.append((e0, e1))
-        elif s[0] == "mean":
-            _, a, b_, c_, out, n, scale = s
-            hip.check(L.fh_mean_f32(a.data_ptr(), b_.data_ptr(), c_.data_ptr() if c_ is not None else None,
-                                    out.data_ptr(), n, scale, st), "fh_mean_f32")
-        elif s[0] == "sum":
-            _, srcs, out, n, scale = s
-            arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
-            hip.check(L.fh_sum_f32(arr, len(srcs), out.data_ptr(), n, scale, st), "fh_sum_f32")
-        elif s[0] == "act":
-            _, d, ng, c, length, din, dout = s
-            timing = self.act_timing           # optional list of (start, end) events around activation launches
-            if timing is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            hip.check(L.fh_act1d_grouped_pm_f32(d.data_ptr(), ng, B, c, length, din, dout, st), "fh_act1d_grouped_pm_f32")
-            if timing is not None:
-                e1.record()
-                timing.append((e0, e1))
-        else:
-            _, x, wav, c, length = s
-            hip.check(L.fh_conv_post_tanh_f32(x.data_ptr(), self.post_w.data_ptr(), self.post_b.data_ptr(),
-                                              wav.data_ptr(), B, c, length, self.post_k, st), "fh_conv_post_tanh_f32")
-
-    def _run_steps(self, steps, B, st):
-        for s in steps:
-            self._launch(s, B, st)
+        run_steps(self, p["steps"], p["B"], hip.stream())
