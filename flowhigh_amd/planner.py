@@ -217,6 +217,26 @@ def use_wino54(c):
     return c >= int(os.environ.get("FH_WINO54_MIN_C", WINO54_MIN_C)) or (c % 48 == 0 and os.environ.get("FH_WINO54_H16", "1") != "0")
 
 
+def use_amp(c, ks, dils):
+    """Residual-stack convs of a stage that run on the narrow-stage kernel (amp_fused.hip, conv-only form: the activation stays
+    a launch of its own): at most 48 channels (a multiple of 8), odd kernels of at most 11 taps, dilations of at most 6.
+    A property of the STAGE (channel count and checkpoint configuration), never of the length or the batch.  FH_AMP=0 switches
+    it off (those stages then run as in round 4: F(5,4) 48-row blocks / the direct kernel)."""
+    if os.environ.get("FH_AMP", "1") == "0" or os.environ.get("FH_WINO", "1") == "0":
+        return False
+    cmax = max((k - 1) // 2 for k in ks)
+    return (c % 8 == 0 and 8 <= c <= 48 and all(k % 2 == 1 and k <= 11 for k in ks)
+            and all(1 <= d <= AMP_MAX_D for dl in dils for d in dl)
+            and all(cmax - (k - 1) // 2 + 4 * -(-k // 4) + 3 <= 16 for k in ks))
+
+
+def amp_fuses_act():
+    """FH_AMP_FUSE_ACT=1: the narrow-stage launches also run the Activation1d in front of their conv (one launch per
+    act -> conv pair, the activated tensor never leaves LDS).  Off by default: measured slower than the two launches
+    (both are bound by the fp32 ALUs, which the matrix and the vector instructions share)."""
+    return os.environ.get("FH_AMP_FUSE_ACT", "0") == "1"
+
+
 def amp_tile_len(d):
     """Outputs per block and row of the narrow-stage kernel at dilation d (fh_amp_tile_len)."""
     return 5 * d * 4 * (16 // d)
@@ -458,6 +478,17 @@ class _PlanBuilder:
                              for g in groups for i in range(g.nseg))
         self.add(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B), groups)
 
+    def amp(self, groups, c, length, dil, fused_act):
+        """Narrow-stage launch (fh_amp_actconv_f32): the groups' convs, with their activation in front when fused_act."""
+        B = self.B
+        tiles = amp_tile_list([g.len for g in groups], B, dil).to(self.v.device)
+        d = hip.to_device_struct_array(groups, self.v.device)
+        self.keep += [d, tiles]
+        flops = sum(2.0 * c * c * (2 * g.seg[i].center + 1) * length * B for g in groups for i in range(g.nseg))
+        self.executed += sum(2.0 * c * c * 1.6 * g.seg[i].ngrp * length * B for g in groups for i in range(g.nseg))
+        flags = int(all(g.len % 4 == 0 for g in groups)) | (0 if fused_act else 2)
+        self.add(("amp", d, len(groups), tiles, tiles.shape[0], c, dil, amp_max_center(groups), flags, flops), groups)
+
     def act(self, groups, c, length, din=1, dout=1):
         d = hip.to_device_struct_array(groups, self.v.device)
         self.keep.append(d)
@@ -469,6 +500,10 @@ class _PlanBuilder:
         whose partial outputs the caller adds, defer_sum)."""
         c, cpad, wpad, L, B = st["c"], st["cpad"], st["wpad"], self.L, self.B
         biases = [e["b"] for e in ents]
+        if all("ua" in e for e in ents):               # narrow stage: plain tensors whatever the dilation
+            self.amp([make_amp_group([make_amp_seg(xs_in[i], ents[i]["ua"], None, ks[i])], biases[i], res[i], outs[i], L)
+                      for i in range(len(ents))], c, L, dil, False)
+            return [[o] for o in outs]
         all_wino = all("u" in e for e in ents)
         nsplit = wino_split_k(ks, c, wpad, self.Lref, dil, st["wcfg"], self.v.bf) if all_wino else 1
         if nsplit > 1:
@@ -641,8 +676,8 @@ class _PlanBuilder:
             self.at(i, m, 0, 0)
             self.act([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][m]) for j in order], c, L)
             self.at(i, m, 1, 0)
-            if m == v.nm - 1 and all("w" in e for e in ents):
-                self.closing_conv(i, m, ents, ks, ds, xin)          # direct kernel: K segments of one group
+            if m == v.nm - 1 and (all("w" in e for e in ents) or (all("ua" in e for e in ents) and all(d == ds[0] for d in ds))):
+                self.closing_conv(i, m, ents, ks, ds, xin)          # direct / narrow-stage kernel: K segments of one group
                 continue
             outs = [Y[j][m % 2] for j in order]
             if all(d == ds[0] for d in ds):
@@ -664,6 +699,11 @@ class _PlanBuilder:
         T1, Y, S = self.T1, self.Y, self.S
         scale = 1.0 / v.nk
         fusable = v.nk <= hip.CONV_MAX_SEG          # (K segments of one group; more blocks: one group each + one averaging pass)
+        if all("ua" in e for e in ents) and fusable and all(d == ds[0] for d in ds):
+            # narrow stage: always the fused form (its blocks are short whatever the length: nothing to decide per clip)
+            segs = [make_amp_seg(T1[j], e["ua"], None, k) for j, e, k in zip(order, ents, ks)]
+            self.amp([make_amp_group(segs, st["last_bias"], [xin[j] for j in order], S, L, scale=scale)], c, L, ds[0], False)
+            return
         if all("u" in e for e in ents):
             ksteps = [c // 16 * -(-k // st["taps"]) for k in ks]
             Lr = self.Lref
@@ -685,7 +725,7 @@ class _PlanBuilder:
             else:
                 self.average([Y[j][m % 2] for j in range(v.nk)], S, B * c * L, scale, key=(i, m, 6, 0))
             return
-        if not fusable:
+        if not fusable or all("ua" in e for e in ents):
             outs, res = [Y[j][m % 2] for j in order], [[xin[j]] for j in order]
             if all(d == ds[0] for d in ds):
                 self.res_conv(st, ents, [T1[j] for j in order], ks, ds[0], outs, res)
@@ -809,6 +849,21 @@ def merge_ragged(voc, frames):
                 allg.sort(key=lambda t: (-t[0], -t[1]))
                 tcfg = max(lst, key=lambda t: t[0])[1]
                 merged.append(("rconv", blob([t[2] for t in allg]), len(allg), cpad, max(t[1] for t in allg), tcfg, ck))
+        elif kind == "amp":
+            classes = {}
+            for ci, st_, groups in items:
+                _, _d, ng, _t, _nt, c, dil, _cm, flags, _fl = st_
+                classes.setdefault((c, dil, flags & 2), []).append(groups)
+            for (c, dil, noact), lst in classes.items():
+                allg = [g for groups in lst for g in groups]
+                # heavy groups first (the persistent blocks walk the tile list in order), then long ones
+                allg.sort(key=lambda g: (-sum(g.seg[i].ngrp for i in range(g.nseg)), -g.len))
+                tl = amp_tile_list([g.len for g in allg], 1, dil)
+                off_t = sum(len(b) for b in blobs)
+                raw = tl.numpy().tobytes()
+                blobs.append(raw + bytes(-len(raw) % 16))
+                merged.append(("ramp", blob(allg), len(allg), off_t, tl.shape[0], c, dil, amp_max_center(allg),
+                               int(all(g.len % 4 == 0 for g in allg)) | noact))
         elif kind == "act":
             classes = {}
             for ci, st_, groups in items:

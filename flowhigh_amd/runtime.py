@@ -206,6 +206,16 @@ def launch_step(voc, s, B, st):
         if timing is not None:
             e1.record()
             timing.append((e0, e1))
+    elif s[0] == "amp":
+        _, d, ng, tiles, nt, c, dil, cmax, flags, _flops = s
+        timing = voc.conv_timing
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hip.check(L.fh_amp_actconv_f32(d.data_ptr(), ng, tiles.data_ptr(), nt, c, dil, cmax, flags, st), "fh_amp_actconv_f32")
+        if timing is not None:
+            e1.record()
+            timing.append((e0, e1))
     elif s[0] == "mean":
         _, a, b_, c_, out, n, scale = s
         hip.check(L.fh_mean_f32(a.data_ptr(), b_.data_ptr(), c_.data_ptr() if c_ is not None else None,
@@ -252,6 +262,9 @@ def run_ragged_steps(voc, rp):
         elif s[0] == "ract":
             _, off, ng, c, din, dout, tiles, mult4 = s
             hip.check(L.fh_act1d_ragged_f32(base + off, ng, c, din, dout, tiles, mult4, st), "fh_act1d_ragged_f32")
+        elif s[0] == "ramp":
+            _, off, ng, off_t, nt, c, dil, cmax, flags = s
+            hip.check(L.fh_amp_actconv_f32(base + off, ng, base + off_t, nt, c, dil, cmax, flags, st), "fh_amp_actconv_f32")
         elif s[0] == "rsum":
             _, off, nj, max_n = s
             hip.check(L.fh_sum_multi_f32(base + off, nj, max_n, st), "fh_sum_multi_f32")

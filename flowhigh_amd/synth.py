@@ -111,8 +111,12 @@ def vocoder_channels(cfg):
     return [c0 // (2 ** (i + 1)) for i in range(len(cfg["upsample_rates"]))]
 
 
-def make_vocoder_state_dict(cfg, seed=0, prefix=VOC):
+def make_vocoder_state_dict(cfg, seed=0, prefix=VOC, convs2_gain=0.2, snake_bound=0.5, post_gain=0.3):
     """BigVGAN generator tensors (weight-norm already folded, as in the wrapper checkpoint).
+
+    convs2_gain / snake_bound / post_gain: the knobs of the regime sweep (tests/tools/regime_sweep.py: how much error
+    headroom the Winograd forms keep as the residual stack's gain, the spread of the snake parameters and the output scale
+    grow towards what trained weights may have); the defaults are the regime every other test and the benchmark use.
 
     Weight regime (SURVEY.md 8c regime iii, chosen so that end-to-end parity is *sensitive*:
     with the reference's N(0, 0.01) init the output barely depends on the mel): conv_pre,
@@ -131,10 +135,10 @@ def make_vocoder_state_dict(cfg, seed=0, prefix=VOC):
 
     def act(name, c):
         # log-scale params in +-0.5 (alpha, beta in [0.6, 1.65]); linear-scale in [0.6, 1.6]
-        lo = _uniform(prefix + name + "act.alpha", (c,), 0.5, seed)
+        lo = _uniform(prefix + name + "act.alpha", (c,), snake_bound, seed)
         sd[prefix + name + "act.alpha"] = lo if logscale else lo + 1.1
         if is_beta:
-            lb = _uniform(prefix + name + "act.beta", (c,), 0.5, seed)
+            lb = _uniform(prefix + name + "act.beta", (c,), snake_bound, seed)
             sd[prefix + name + "act.beta"] = lb if logscale else lb + 1.1
         sd[prefix + name + "upsample.filter"] = filt.clone()
         sd[prefix + name + "downsample.lowpass.filter"] = filt.clone()
@@ -158,11 +162,11 @@ def make_vocoder_state_dict(cfg, seed=0, prefix=VOC):
                 continue
             for m in range(len(cfg["resblock_dilation_sizes"][j])):
                 conv(f"resblocks.{r}.convs1.{m}", chans[i], chans[i], ks, 1.0)
-                conv(f"resblocks.{r}.convs2.{m}", chans[i], chans[i], ks, 0.2)
+                conv(f"resblocks.{r}.convs2.{m}", chans[i], chans[i], ks, convs2_gain)
             for a in range(2 * len(cfg["resblock_dilation_sizes"][j])):
                 act(f"resblocks.{r}.activations.{a}.", chans[i])
     act("activation_post.", chans[-1])
-    conv("conv_post", 1, chans[-1], 7, 0.3)
+    conv("conv_post", 1, chans[-1], 7, post_gain)
     return sd
 
 

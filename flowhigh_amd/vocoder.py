@@ -30,11 +30,11 @@ from .packing import (  # noqa: F401
 from .planner import (  # noqa: F401
     AMP_MAX_D, WINO54_MIN_C, WINO_BF16X6, WINO_BM, WINO_F54, WINO_MAX_K, WINO_MIN_C, WINO_NARROW, WINO_NOVL,
     WINO_UPS_MIN_CIN, WINO_XCD_RANGES, _PlanBuilder, _TILE_PREF, _WINO_BF_SPEED, _WINO_COST, _WINO_RUN,
-    _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_max_center, amp_tile_len,
-    amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,
+    _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_fuses_act, amp_max_center,
+    amp_tile_len, amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,
     make_conv_seg, make_wino_group, make_wino_seg, merge_ragged, pick_tile_cfg, pick_wino54_tile,
-    pick_wino_tile, use_bf16x6, use_wino, use_wino54, wino_block_mapping, wino_conv_ok, wino_launch_cost,
-    wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
+    pick_wino_tile, use_amp, use_bf16x6, use_wino, use_wino54, wino_block_mapping, wino_conv_ok,
+    wino_launch_cost, wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
 from .runtime import (  # noqa: F401
     ACT_BLOCKS_CHOICES, _act_blocks, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped,
     conv_wino, decide_act_blocks, launch_step, measure_act_conv_pair, parse_act_blocks, pick_act_blocks,
@@ -165,6 +165,8 @@ class Vocoder:
             st["w54"] = use_wino54(c) and not self.bf and max(self.ks) <= WINO_MAX_K
             st["wcfg"], st["wpad"] = pick_wino54_tile(c) if st["w54"] else (st["up_wcfg"], st["up_wpad"])
             st["taps"] = 4 if st["w54"] else 3
+            # narrow stages (<= 48 channels): the residual-stack convs run on the narrow-stage kernel (planner.use_amp)
+            st["amp"] = use_amp(c, self.ks, self.dil) and not self.bf
             pack_res = (lambda w_: pack_wino54_weight(w_, st["wpad"])) if st["w54"] else \
                 (lambda w_: pack_wino_weight_any(w_, st["wpad"], self.bf))
             wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
@@ -190,7 +192,9 @@ class Vocoder:
                         d = self.dil[j][m]
                         ent = dict(b=g(f"resblocks.{r}.convs.{m}.bias").to(dev))
                         w = g(f"resblocks.{r}.convs.{m}.weight")
-                        if wino_k and use_wino(c, d) and all(self.dil[jj][m] == d for jj in range(self.nk)):
+                        if st["amp"] and all(self.dil[jj][m] == d for jj in range(self.nk)):
+                            ent["ua"] = pack_amp_weight(w, c).to(dev)
+                        elif wino_k and use_wino(c, d) and all(self.dil[jj][m] == d for jj in range(self.nk)):
                             ent["u"] = pack_res(w).to(dev)
                         else:
                             ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
@@ -204,7 +208,9 @@ class Vocoder:
                         ent = dict(b=g(f"resblocks.{r}.{tag}.{m}.bias").to(dev))
                         # convs1[m] of the nk blocks share one launch: Winograd only if they share the dilation
                         same_d = tag == "convs2" or all(self.dil[jj][m] == d for jj in range(self.nk))
-                        if wino_k and use_wino(c, d) and same_d:
+                        if st["amp"] and same_d:
+                            ent["ua"] = pack_amp_weight(w, c).to(dev)
+                        elif wino_k and use_wino(c, d) and same_d:
                             ent["u"] = pack_res(w).to(dev)
                         else:
                             ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
@@ -326,7 +332,7 @@ class Vocoder:
         reach1 = sum((d + 1) if self.resblock == "1" else d for d in dmax)
         h = 3.0 + 6.0                                   # conv_post (7 taps) + activation_post, in output samples
         for i in reversed(range(len(self.rates))):
-            h += per_stage + (4 if self.stages[i]["w54"] else 3) * reach1      # residual stack at this stage's rate
+            h += per_stage + (4 if self.stages[i]["w54"] or self.stages[i]["amp"] else 3) * reach1      # residual stack at this stage's rate
             h = h / self.rates[i] + self.up_k[i] / self.rates[i] + 1.0 + 3.0     # ... seen from the transposed conv's input
         h += 3.0 + 3.0                                  # conv_pre
         align, rate = 4, 1
@@ -338,7 +344,7 @@ class Vocoder:
         for i, u in enumerate(self.rates):
             align = lcm(align, 4 // math.gcd(4, rate))                      # Winograd transposed conv reads at `rate`
             rate *= u
-            m = 5 if self.stages[i]["w54"] else 4                           # outputs per tile of the stage's Winograd kernel
+            m = 5 if self.stages[i]["w54"] or self.stages[i]["amp"] else 4  # outputs per tile of the stage's Winograd kernel
             align = lcm(align, m * dl // math.gcd(m * dl, rate))            # residual stack at `rate` samples per frame
         halo = -(-int(math.ceil(h)) // align) * align
         return halo, align

@@ -64,7 +64,7 @@ def test_plan_steps_have_unique_sorted_position_keys(cfgname):
         keys = [m[0] for m in p["meta"]]
         assert len(keys) == len(p["steps"]) and len(set(keys)) == len(keys) and keys == sorted(keys)
         for step, (_, structs) in zip(p["steps"], p["meta"]):
-            assert (structs is not None) == (step[0] in ("conv", "wino", "act"))
+            assert (structs is not None) == (step[0] in ("conv", "wino", "act", "amp"))
             if structs is not None:
                 assert len(structs) == step[2]
 
