@@ -1,13 +1,17 @@
 // Winograd F(5,4) form of the wide residual-stack Conv1d sites of BigVGAN on the fp32 matrix cores.
 //
 // Replaces the AMPBlock convs (/root/reference/src/flowhigh/models/bigvgan/models.py:36-72: kernel 3 / 7 / 11,
-// dilation 1 / 3 / 5, "same" padding) of the stages with >= 192 channels, where the K loop is what a launch takes.
+// dilation 1 / 3 / 5, "same" padding) of the stages with >= 96 channels (vocoder.WINO54_MIN_C; an odd multiple of 48 channels
+// below that runs the 48-row block of this kernel unless FH_WINO54_H16=0; 24 / 48 channels run amp_fused.hip since round 5).
 //
 // Minimal filtering F(5,4): 5 outputs of a 4-tap correlation from 8 inputs with 8 multiplies (points 0, +-1, +-2,
 // +-1/2, inf), y = A^T [ (G g) .* (B^T d) ].  The k taps are walked in ceil(k/4) groups of 4, so a conv executes
 // 1.6 ceil(k/4) multiply-adds per output and channel pair: 1.6 / 3.2 / 4.8 for k = 3 / 7 / 11 against 1.5 / 4.5 / 6.0 of
-// the F(4,3) kernel (conv_wino.hip): 20 % fewer matrix instructions over the stack.  fp32 error against float64: the
-// same as F(4,3) per conv and end to end (tests/tools/winograd_numerics.py, profiles/r04_winograd_numerics.txt).
+// the F(4,3) kernel (conv_wino.hip): 20 % fewer matrix instructions over the stack.  fp32 error against float64: 0.8-1.1e-5 per
+// conv on unit-scale data (F(4,3): 0.6-1.1e-5, direct: 4e-7) and the same as F(4,3) end to end in the synthetic regime
+// (tests/tools/winograd_numerics.py, profiles/r04_winograd_numerics.txt); worst cases of the kernel fuzz are about a third above
+// F(4,3)'s (tests/tools/wino_fuzz.py: 4e-5 at |out| ~ 3, x 1.5 above 192 channels); how the headroom to the 1e-4 bar shrinks with
+// the weights' gain: profiles/r05_regime_sweep.txt.
 //
 // Eight transform points = eight waves: block = 8 waves = 2 per SIMD with up to 256 registers each, wave xi owns
 // M_xi for (32 MT) output channels x 64 tiles (2 columns of 32) = 320 outputs.  With MT = 4 one B fragment feeds
@@ -442,6 +446,9 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   run_all(std::integral_constant<int, 3>{});
   run_all(std::integral_constant<int, 2>{});
   run_all(std::integral_constant<int, 1>{});
+  // (a segment of 4 or more tap groups matches no pass above: a caller that bypassed the host's checks would get
+  // bias + residual back with FH_OK.  Fail loudly instead.)
+  if (sg < nseg) __builtin_trap();
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
   const size_t oslab = (size_t)b * cout * pitch;

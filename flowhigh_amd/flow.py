@@ -52,54 +52,69 @@ def pack_geglu(w, b):
 
 
 class FlowNet:
-    def __init__(self, sd, device, depth=2, heads=16, dim_head=64):
+    def __init__(self, sd, device, depth=2, heads=16, dim_head=64, store=None):
         if dim_head != 64:
             raise NotImplementedError("dim_head must be 64")
         self.device = hip.norm_device(device)
         dev = self.device
+        # (device tensors come through the weight store: packed from `sd`, or taken from an uploaded weight blob: weights.py)
+        from .weights import WeightStore
+        W = store if store is not None else WeightStore(dev)
         g = lambda name: sd[FH + name].detach().float().cpu()
         self.depth, self.heads = depth, heads
-        w_embed = g("to_embed.weight")
-        self.dim = w_embed.shape[0]
-        self.dim_in = w_embed.shape[1] // 2
+        w_embed = lambda: g("to_embed.weight")
+        dims = W.host("f.dims", lambda: torch.tensor([w_embed().shape[0], w_embed().shape[1] // 2,
+                                                      g("conv_embed.dw_conv1d.0.weight").shape[-1]], dtype=torch.int32)).tolist()
+        self.dim, self.dim_in, self.dw_k = dims
         if self.dim % 256 or self.dim_in % 32 or heads * dim_head != self.dim:
             raise NotImplementedError("unsupported transformer dims")
-        self.w_x = _pad_rows(w_embed[:, :self.dim_in]).to(dev)
-        self.w_c = _pad_rows(w_embed[:, self.dim_in:]).to(dev)
-        self.b_embed = g("to_embed.bias").to(dev)
-        self.null_cond = g("null_cond").reshape(1, -1).contiguous().to(dev)
+        self.w_x = W.dev("f.w_x", lambda: _pad_rows(w_embed()[:, :self.dim_in]))
+        self.w_c = W.dev("f.w_c", lambda: _pad_rows(w_embed()[:, self.dim_in:]))
+        self.b_embed = W.dev("f.b_embed", lambda: g("to_embed.bias"))
+        self.null_cond = W.dev("f.null_cond", lambda: g("null_cond").reshape(1, -1))
         self._e_null = None
-        dw = g("conv_embed.dw_conv1d.0.weight")
-        self.dw_k = dw.shape[-1]
-        self.dw_w = dw.reshape(self.dim, self.dw_k).t().contiguous().to(dev)       # [ksz, dim], tap-major
-        self.dw_b = g("conv_embed.dw_conv1d.0.bias").to(dev)
-        self.sinu_w = g("sinu_pos_emb.0.weights").to(dev)
-        self.t_w = g("sinu_pos_emb.1.weight").contiguous().to(dev)
-        self.t_b = g("sinu_pos_emb.1.bias").to(dev)
-        gb_w, gb_b = [], []
+        self.dw_w = W.dev("f.dw_w", lambda: g("conv_embed.dw_conv1d.0.weight").reshape(self.dim, self.dw_k).t())   # [ksz, dim], tap-major
+        self.dw_b = W.dev("f.dw_b", lambda: g("conv_embed.dw_conv1d.0.bias"))
+        self.sinu_w = W.dev("f.sinu_w", lambda: g("sinu_pos_emb.0.weights"))
+        self.t_w = W.dev("f.t_w", lambda: g("sinu_pos_emb.1.weight"))
+        self.t_b = W.dev("f.t_b", lambda: g("sinu_pos_emb.1.bias"))
         self.layers = []
         for layer in range(depth):
             p = f"transformer.layers.{layer}."
-            for nidx in ("2", "4"):
-                for which in ("to_gamma", "to_beta"):
-                    gb_w.append(g(p + f"{nidx}.{which}.weight"))
-                    gb_b.append(g(p + f"{nidx}.{which}.bias"))
-            w1, b1, inner_pad = pack_geglu(g(p + "5.0.weight"), g(p + "5.0.bias"))
-            w2 = g(p + "5.3.weight")
-            w2p = torch.zeros(w2.shape[0], inner_pad)
-            w2p[:, :w2.shape[1]] = w2
+            ff = {}
+
+            def ff1(p=p, ff=ff):
+                if not ff:
+                    ff["w1"], ff["b1"], ff["inner_pad"] = pack_geglu(g(p + "5.0.weight"), g(p + "5.0.bias"))
+                return ff
+
+            def w2_padded(p=p):
+                w2 = g(p + "5.3.weight")
+                w2p = torch.zeros(w2.shape[0], ff1()["inner_pad"])
+                w2p[:, :w2.shape[1]] = w2
+                return _pad_rows(w2p)
+            k = f"f.layer{layer}."
             self.layers.append(dict(
-                gq=g(p + "3.q_norm.gamma").reshape(heads, 64).contiguous().to(dev),
-                gk=g(p + "3.k_norm.gamma").reshape(heads, 64).contiguous().to(dev),
-                w_qkv=_pad_rows(g(p + "3.to_qkv.weight")).to(dev),
-                w_out=_pad_rows(g(p + "3.to_out.weight")).to(dev),
-                w1=w1.to(dev), b1=b1.to(dev),
-                w2=_pad_rows(w2p).to(dev), b2=g(p + "5.3.bias").to(dev), inner_pad=inner_pad))
-        self.gb_w = torch.cat(gb_w, 0).contiguous().to(dev)      # [depth*4*dim, dim]
-        self.gb_b = torch.cat(gb_b, 0).contiguous().to(dev)
-        self.final_gamma = g("transformer.final_norm.gamma").to(dev)
-        self.w_pred = _pad_rows(g("to_pred.weight")).to(dev)
-        self.inv_freq = g("transformer.rotary_emb.inv_freq")
+                gq=W.dev(k + "gq", lambda: g(p + "3.q_norm.gamma").reshape(heads, 64)),
+                gk=W.dev(k + "gk", lambda: g(p + "3.k_norm.gamma").reshape(heads, 64)),
+                w_qkv=W.dev(k + "w_qkv", lambda: _pad_rows(g(p + "3.to_qkv.weight"))),
+                w_out=W.dev(k + "w_out", lambda: _pad_rows(g(p + "3.to_out.weight"))),
+                w1=W.dev(k + "w1", lambda: ff1()["w1"]), b1=W.dev(k + "b1", lambda: ff1()["b1"]),
+                w2=W.dev(k + "w2", w2_padded), b2=W.dev(k + "b2", lambda: g(p + "5.3.bias")),
+                inner_pad=int(W.host(k + "inner_pad", lambda: torch.tensor([ff1()["inner_pad"]], dtype=torch.int32))[0])))
+
+        def gamma_beta(which_tensor):
+            out = []
+            for layer in range(depth):
+                for nidx in ("2", "4"):
+                    for which in ("to_gamma", "to_beta"):
+                        out.append(g(f"transformer.layers.{layer}.{nidx}.{which}.{which_tensor}"))
+            return torch.cat(out, 0)
+        self.gb_w = W.dev("f.gb_w", lambda: gamma_beta("weight"))      # [depth*4*dim, dim]
+        self.gb_b = W.dev("f.gb_b", lambda: gamma_beta("bias"))
+        self.final_gamma = W.dev("f.final_gamma", lambda: g("transformer.final_norm.gamma"))
+        self.w_pred = W.dev("f.w_pred", lambda: _pad_rows(g("to_pred.weight")))
+        self.inv_freq = W.host("f.inv_freq", lambda: g("transformer.rotary_emb.inv_freq"))
         self._ws = hip.ShapeCache()
 
     @hip.on_device

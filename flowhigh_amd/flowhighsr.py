@@ -31,6 +31,27 @@ from .tables import HOP
 from .vocoder import VOC, Vocoder, fold_weight_norm
 
 REPO_ID = "ResembleAI/FlowHigh"
+# the checkpoint files from_local reads (flowhighsr.py:110-137 of the reference); a weight blob records their digests
+CKPT_FILES = ("bigvgan_48khz_256band.json", "bigvgan_48khz_256band.pt", "FLowHigh_basic_400k.pt")
+
+
+def weights_bf16x6():
+    from .vocoder import use_bf16x6
+    return use_bf16x6()
+
+
+def read_checkpoints(ckpt_dir):
+    """(state dict with the wrapper's keys, vocoder JSON) from the reference's three checkpoint files: weight norm folded
+    (init_vocoder.py:13-17), key sets checked as load_state_dict(strict=True) would (flowhighsr.py:135)."""
+    ckpt_dir = Path(ckpt_dir)
+    cfg = json.loads((ckpt_dir / "bigvgan_48khz_256band.json").read_text())
+    gen = _load_checkpoint(ckpt_dir / "bigvgan_48khz_256band.pt")['generator']
+    sd = {VOC + k: v for k, v in fold_weight_norm(gen).items()}            # init_vocoder.py:13-17
+    model = _load_checkpoint(ckpt_dir / "FLowHigh_basic_400k.pt")['model']
+    check_state_dict_keys(sd, cfg, only_prefix=VOC)                        # vocoder.load_state_dict (init_vocoder.py:16)
+    check_state_dict_keys(model, cfg)                                      # load_state_dict(strict=True), flowhighsr.py:135
+    sd.update(model)                                                       # wrapper checkpoint wins
+    return sd, cfg
 _CFM_METHODS = ("basic_cfm", "independent_cfm_adaptive", "independent_cfm_constant", "independent_cfm_mix")
 
 
@@ -144,8 +165,10 @@ class GraphedGenerate:
         # drops the cache's reference and replay() never touches memory that went back to the allocator.
         fh = model.flowhigh
         n = t48 // 480
+        # (PostProcessor keys its workspace on the vocoder's output length: hop * n, or a few samples more when some
+        # upsampler has an odd k - u: Vocoder.out_len)
         self._keep = [c.get(k) for c, k in ((fh.net._ws, (batch, n)), (fh.logmel._ws, (batch, t48)),
-                                            (model.postproc._ws, (batch, 480 * n, t48, t48)))]
+                                            (model.postproc._ws, (batch, fh.vocoder.out_len(n), t48, t48)))]
         # vocoder: the plan of the clip, or the plans of its time chunks (key (batch, chunk frames, clip frames))
         voc_plans = [v for k, v in dict.items(fh.vocoder._plans) if k[0] == batch and k[-1] == n]
         self._keep += voc_plans if voc_plans else [None]
@@ -164,7 +187,7 @@ class FLowHigh:
     """Device-resident weights of the vector-field net + its mel codec (the reference's
     `FLowHigh` with `audio_enc_dec = MelVoco`, models/flow.py:54-142, models/melvoco.py:16-46)."""
 
-    def __init__(self, state_dict, vocoder_config, device="cuda", depth=2, conv_bf16x6=None):
+    def __init__(self, state_dict, vocoder_config, device="cuda", depth=2, conv_bf16x6=None, store=None):
         device = torch.device(device)
         if device.type != "cuda":
             raise hip.HipError(f"flowhigh_amd runs on MI355X only (got device '{device}'); there is no CPU path")
@@ -176,14 +199,16 @@ class FLowHigh:
         # flowhighsr.py:110-137)
         self.device = device = hip.norm_device(device)
         self.vocoder_config = dict(vocoder_config)
-        missing = [k for k in ("flowhigh.to_embed.weight", VOC + "conv_pre.weight") if k not in state_dict]
-        if missing:
-            raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
+        # store: a weights.WeightStore opened on a weight blob (state_dict may then be None), or a recording one (convert.py)
+        if store is None or state_dict is not None:
+            missing = [k for k in ("flowhigh.to_embed.weight", VOC + "conv_pre.weight") if k not in state_dict]
+            if missing:
+                raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
         with hip.device_guard(device):
-            self.net = FlowNet(state_dict, device, depth=depth)
+            self.net = FlowNet(state_dict, device, depth=depth, store=store)
             # conv_bf16x6 (None: FH_CONV_BF16X6, default off): the vocoder's Winograd convs on the BF16 matrix cores
             # with every fp32 operand split exactly into three bf16 pieces (vocoder.use_bf16x6)
-            self.vocoder = Vocoder(self.vocoder_config, state_dict, device, bf16x6=conv_bf16x6)
+            self.vocoder = Vocoder(self.vocoder_config, state_dict, device, bf16x6=conv_bf16x6, store=store)
             self.logmel = LogMel(device)
         self.n_mels = self.net.dim_in
 
@@ -240,14 +265,20 @@ class FlowHighSR:
     @classmethod
     def from_local(cls, ckpt_dir, device='cuda', **kwargs) -> 'FlowHighSR':
         ckpt_dir = Path(ckpt_dir)
-        cfg = json.loads((ckpt_dir / "bigvgan_48khz_256band.json").read_text())
-        gen = _load_checkpoint(ckpt_dir / "bigvgan_48khz_256band.pt")['generator']
-        sd = {VOC + k: v for k, v in fold_weight_norm(gen).items()}            # init_vocoder.py:13-17
-        model = _load_checkpoint(ckpt_dir / "FLowHigh_basic_400k.pt")['model']
-        check_state_dict_keys(sd, cfg, only_prefix=VOC)                        # vocoder.load_state_dict (init_vocoder.py:16)
-        check_state_dict_keys(model, cfg)                                      # load_state_dict(strict=True), flowhighsr.py:135
-        sd.update(model)                                                       # wrapper checkpoint wins
         dev = device if torch.device(device).type == 'cuda' else 'cuda'        # the reference always .cuda()s
+        # A weight blob next to the checkpoints (python -m flowhigh_amd.convert <ckpt_dir>; FH_BLOB = another path, FH_BLOB=0 =
+        # ignore): the packed device weights in one file, mapped and uploaded with one copy -- if it was made from THESE
+        # checkpoint files (content digests) under the current layout switches.  Otherwise the checkpoints are read as always.
+        from . import weights
+        blob = os.environ.get("FH_BLOB", str(ckpt_dir / weights.BLOB_NAME))
+        if blob != "0" and Path(blob).exists():
+            srcs = {f: weights.file_digest(ckpt_dir / f) for f in CKPT_FILES} if os.environ.get("FH_BLOB_VERIFY", "1") != "0" else None
+            store = weights.WeightStore.open(blob, hip.norm_device(dev), expect_format=weights.format_tag(weights_bf16x6()), sources=srcs)
+            if store is not None:
+                return cls(flowhigh=FLowHigh(None, store.cfg, dev, store=store), **kwargs)
+            import logging
+            logging.getLogger("flowhigh_amd").warning("weight blob %s not used (%s): reading the checkpoints", blob, weights.WeightStore.why)
+        sd, cfg = read_checkpoints(ckpt_dir)
         return cls(flowhigh=FLowHigh(sd, cfg, dev), **kwargs)
 
     @classmethod

@@ -375,6 +375,9 @@ def wino_block_mapping(groups, batch, wpad, length, dil, wcfg):
 def make_wino_seg(x, u, cin, k, center=None, xlen=0, taps=3):
     """taps: 3 for the F(4,3) kernel's weights (pack_wino_weight), 4 for F(5,4) (pack_wino54_weight)."""
     s = hip.WinoSeg()
+    if taps == 4 and (-(-k // 4) > 3 or xlen):
+        # (conv_wino54.hip walks segments of 1 .. 3 tap groups and takes no xlen: such a segment would be skipped silently)
+        raise NotImplementedError("F(5,4) segments: at most 12 taps, no xlen")
     s.x, s.u, s.cin, s.ngrp = _addr(x), _addr(u), cin, -(-k // taps)
     s.center = (k - 1) // 2 if center is None else center
     s.xlen = xlen

@@ -26,6 +26,8 @@ def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0, pha
     """Upload descriptors and enqueue one Winograd conv launch (test / one-off use)."""
     d = hip.to_device_struct_array(groups, device)
     if tile_cfg & WINO_F54:            # (F(5,4) kernel: the groups' weights are pack_wino54_weight, ngrp = ceil(k / 4))
+        if any(g.out_stride > 1 or g.out_len or g.seg[i].ngrp > 3 or g.seg[i].xlen for g in groups for i in range(g.nseg)):
+            raise NotImplementedError("the F(5,4) kernel takes plain convs of at most 12 taps (no strided outputs, xlen, out_len)")
         hip.check(hip.lib().fh_conv_wino54_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
                                                int(phase_major), tile_cfg & 15, hip.stream()), "fh_conv_wino54_f32")
         return d

@@ -46,7 +46,7 @@ VOC = "flowhigh.audio_enc_dec.vocoder."
 class Vocoder:
     """Device-resident BigVGAN weights + per-shape launch plans."""
 
-    def __init__(self, cfg, sd, device, prefix=VOC, bf16x6=None, act_blocks=None):
+    def __init__(self, cfg, sd, device, prefix=VOC, bf16x6=None, act_blocks=None, store=None):
         if isinstance(cfg, (str, bytes)) or hasattr(cfg, "read_text"):
             cfg = json.loads(open(cfg).read())
         self.cfg = dict(cfg)
@@ -90,6 +90,10 @@ class Vocoder:
         # ConvTranspose1d(k, u, padding (k - u) // 2) for any (u, k) (models.py:141-146): k - u odd adds one sample per stage
         self.extra = [transposed_conv_extra(k, u) for u, k in zip(self.rates, self.up_k)]
         dev = self.device
+        # every device tensor comes through the weight store: packed here from the checkpoint `sd`, or -- `store` opened on a
+        # weight blob (weights.py; `sd` may then be None) -- taken from the uploaded file without touching the checkpoint
+        from .weights import WeightStore
+        W = store if store is not None else WeightStore(dev)
 
         def g(name):
             """Checkpoint tensor, channel dimensions zero-padded to the counts above."""
@@ -124,28 +128,39 @@ class Vocoder:
         is_beta = cfg["activation"] == "snakebeta"
         logscale = bool(cfg.get("snake_logscale", False))
 
-        def act_params(name):
+        def act_ab(name):
             a = g(name + "act.alpha")
             b = g(name + "act.beta") if is_beta else a
             if logscale:
                 a, b = torch.exp(a), torch.exp(b)
             inv_b = 1.0 / (b + 1e-9)                 # activations.py:57,118
-            return dict(alpha=a.contiguous().to(dev), inv_beta=inv_b.contiguous().to(dev),
-                        up=g(name + "upsample.filter").flatten().tolist(),
-                        down=g(name + "downsample.lowpass.filter").flatten().tolist())
+            return a.contiguous(), inv_b.contiguous()
+
+        def act_params(name):
+            """Activation1d parameters of one site: alpha / inv_beta on the device, the two 12-tap filters as host lists."""
+            ab = None
+
+            def both():
+                nonlocal ab
+                if ab is None:
+                    ab = act_ab(name)
+                return ab
+            return dict(alpha=W.dev("v." + name + "alpha", lambda: both()[0]), inv_beta=W.dev("v." + name + "inv_beta", lambda: both()[1]),
+                        up=W.host("v." + name + "up", lambda: g(name + "upsample.filter").flatten()).tolist(),
+                        down=W.host("v." + name + "down", lambda: g(name + "downsample.lowpass.filter").flatten()).tolist())
 
         # conv_pre
         self.pre_cfg, _, self.pre_cpad = pick_tile_cfg(self.c0)
         self.pre_ck = pick_ck(self.num_mels)
-        self.pre_w = pack_conv_weight(g("conv_pre.weight"), self.pre_cpad, self.pre_ck).to(dev)
-        self.pre_b = g("conv_pre.bias").to(dev)
+        self.pre_w = W.dev("v.conv_pre.w", lambda: pack_conv_weight(g("conv_pre.weight"), self.pre_cpad, self.pre_ck))
+        self.pre_b = W.dev("v.conv_pre.b", lambda: g("conv_pre.bias"))
         # conv_pre (num_mels -> c0, 7 taps) in Winograd form as well when the shapes fit
-        if g("conv_pre.weight").shape[-1] != 7:
+        if sd is not None and g("conv_pre.weight").shape[-1] != 7:
             raise NotImplementedError("conv_pre kernel size other than 7")            # (models.py:134 fixes 7)
         self.pre_u = None
         if use_wino(self.c0, 1) and self.num_mels % 16 == 0 and self.c0 % 64 == 0:
             self.pre_wcfg, self.pre_wpad = pick_wino_tile(self.c0)
-            self.pre_u = pack_wino_weight_any(g("conv_pre.weight"), self.pre_wpad, self.bf).to(dev)
+            self.pre_u = W.dev("v.conv_pre.u", lambda: pack_wino_weight_any(g("conv_pre.weight"), self.pre_wpad, self.bf))
         self.stages = []
         for i, (u, k) in enumerate(zip(self.rates, self.up_k)):
             c = self.chans[i]
@@ -169,20 +184,22 @@ class Vocoder:
             st["amp"] = use_amp(c, self.ks, self.dil) and not self.bf
             pack_res = (lambda w_: pack_wino54_weight(w_, st["wpad"])) if st["w54"] else \
                 (lambda w_: pack_wino_weight_any(w_, st["wpad"], self.bf))
-            wt = g(f"ups.{i}.0.weight")               # [cin, c, k]
-            st["up_b"] = g(f"ups.{i}.0.bias").to(dev)
+            wt = lambda i=i: g(f"ups.{i}.0.weight")               # [cin, c, k]
+            st["up_b"] = W.dev(f"v.ups.{i}.b", lambda: g(f"ups.{i}.0.bias"))
             st["up_phases"] = []
-            for taps in transposed_conv_phases(k, u):
-                wsel = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1)        # [cin, c, nt]
-                st["up_phases"].append(dict(w=pack_conv_weight(wsel.permute(1, 0, 2), cpad, st["up_ck"]).to(dev),
-                                            offs=[o for _, o in taps]))
+            for r_, taps in enumerate(transposed_conv_phases(k, u)):
+                def phase_w(taps=taps):
+                    wsel = torch.stack([wt()[:, :, j] for j, _ in taps], dim=-1)        # [cin, c, nt]
+                    return pack_conv_weight(wsel.permute(1, 0, 2), cpad, st["up_ck"])
+                st["up_phases"].append(dict(w=W.dev(f"v.ups.{i}.phase{r_}.w", phase_w), offs=[o for _, o in taps]))
             # the same transposed conv as Winograd phase groups (strided output) where the tile shapes fit
             st["up_wino"] = None
             if use_wino(max(c, 48), 1) and c % 16 == 0 and c >= 48 and st["cin"] % 16 == 0 and st["cin"] >= WINO_UPS_MIN_CIN:
                 st["up_wino"] = []
-                for taps in transposed_conv_phases(k, u):
-                    wph, center = wino_phase_weight(wt, taps)
-                    st["up_wino"].append(dict(u=pack_wino_weight_any(wph, st["up_wpad"], self.bf).to(dev), k=wph.shape[-1], center=center))
+                for r_, taps in enumerate(transposed_conv_phases(k, u)):
+                    # (taps ordered by input offset: a stride-1 correlation of len(taps) taps, center = - smallest offset)
+                    st["up_wino"].append(dict(u=W.dev(f"v.ups.{i}.phase{r_}.u", lambda taps=taps: pack_wino_weight_any(
+                        wino_phase_weight(wt(), taps)[0], st["up_wpad"], self.bf)), k=len(taps), center=-min(o for _, o in taps)))
             st["blocks"] = []
             for j in range(self.nk):
                 r = i * self.nk + j
@@ -190,30 +207,32 @@ class Vocoder:
                 if self.resblock == "2":        # AMPBlock2 (models.py:81-121): x = conv_l(act_l(x)) + x per dilation
                     for m in range(self.nm):
                         d = self.dil[j][m]
-                        ent = dict(b=g(f"resblocks.{r}.convs.{m}.bias").to(dev))
-                        w = g(f"resblocks.{r}.convs.{m}.weight")
+                        kn = f"resblocks.{r}.convs.{m}"
+                        ent = dict(b=W.dev(f"v.{kn}.b", lambda kn=kn: g(kn + ".bias")))
+                        w = lambda kn=kn: g(kn + ".weight")
                         if st["amp"] and all(self.dil[jj][m] == d for jj in range(self.nk)):
-                            ent["ua"] = pack_amp_weight(w, c).to(dev)
+                            ent["ua"] = W.dev(f"v.{kn}.ua", lambda w=w: pack_amp_weight(w(), c))
                         elif wino_k and use_wino(c, d) and all(self.dil[jj][m] == d for jj in range(self.nk)):
-                            ent["u"] = pack_res(w).to(dev)
+                            ent["u"] = W.dev(f"v.{kn}.u", lambda w=w: pack_res(w()))
                         else:
-                            ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
+                            ent["w"] = W.dev(f"v.{kn}.w", lambda w=w: pack_conv_weight(w(), cpad, st["ck"]))
                         blk["c1"].append(ent)
                         blk["acts"].append(act_params(f"resblocks.{r}.activations.{m}."))
                     st["blocks"].append(blk)
                     continue
                 for m in range(self.nm):
                     for tag, lst, d in (("convs1", blk["c1"], self.dil[j][m]), ("convs2", blk["c2"], 1)):
-                        w = g(f"resblocks.{r}.{tag}.{m}.weight")
-                        ent = dict(b=g(f"resblocks.{r}.{tag}.{m}.bias").to(dev))
+                        kn = f"resblocks.{r}.{tag}.{m}"
+                        w = lambda kn=kn: g(kn + ".weight")
+                        ent = dict(b=W.dev(f"v.{kn}.b", lambda kn=kn: g(kn + ".bias")))
                         # convs1[m] of the nk blocks share one launch: Winograd only if they share the dilation
                         same_d = tag == "convs2" or all(self.dil[jj][m] == d for jj in range(self.nk))
                         if st["amp"] and same_d:
-                            ent["ua"] = pack_amp_weight(w, c).to(dev)
+                            ent["ua"] = W.dev(f"v.{kn}.ua", lambda w=w: pack_amp_weight(w(), c))
                         elif wino_k and use_wino(c, d) and same_d:
-                            ent["u"] = pack_res(w).to(dev)
+                            ent["u"] = W.dev(f"v.{kn}.u", lambda w=w: pack_res(w()))
                         else:
-                            ent["w"] = pack_conv_weight(w, cpad, st["ck"]).to(dev)
+                            ent["w"] = W.dev(f"v.{kn}.w", lambda w=w: pack_conv_weight(w(), cpad, st["ck"]))
                         lst.append(ent)
                 for a in range(2 * self.nm):
                     blk["acts"].append(act_params(f"resblocks.{r}.activations.{a}."))
@@ -223,8 +242,8 @@ class Vocoder:
                                   for b in st["blocks"]).contiguous()
             self.stages.append(st)
         self.post_act = act_params("activation_post.")
-        self.post_w = g("conv_post.weight")[0].contiguous().to(dev)      # [c_last, 7]
-        self.post_b = g("conv_post.bias").to(dev)
+        self.post_w = W.dev("v.conv_post.w", lambda: g("conv_post.weight")[0])      # [c_last, 7]
+        self.post_b = W.dev("v.conv_post.b", lambda: g("conv_post.bias"))
         self.post_k = self.post_w.shape[-1]
         self.wino_flag = WINO_BF16X6 if self.bf else 0             # (the weights above are packed accordingly)
         self._plans = hip.ShapeCache()

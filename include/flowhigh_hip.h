@@ -184,12 +184,14 @@ int fh_conv_wino_ragged_f32(const fh_wino_group* groups, int n_groups, int cout_
  *   u = [cin/16][ngrp][8][cout_pad][16], u[., g, xi, co, .] = sum_j G8[xi][j] * w[co, ., 4g + j]
  * (flowhigh_amd/vocoder.py: pack_wino54_weight); ngrp <= 3 (k <= 12), out_stride <= 1, xlen = 0, out_len = 0 (longer
  * kernels run on fh_conv_grouped_f32, transposed-conv phases on fh_conv_wino_f32; the descriptors live in device memory, so
- * the library cannot check this: flowhigh_amd/vocoder.py does when it builds a launch plan).  Any dilation and any
+ * the library cannot check this on the host: flowhigh_amd/planner.py does when it builds a descriptor, and the kernel traps
+ * on a segment it cannot walk).  Any dilation and any
  * len < 2^24 - 4096 (16.7 M samples = 5.8 min at 48 kHz per row; FH_E_ARG beyond: the kernel finds a sample's phase in fp32): rows
  * that are not 16-byte aligned are read and written with 4-byte accesses, same arithmetic.  tile_cfg: 0 = 128 co x 320 outputs per block,
  * 1 = 96 x 320, 2 = 64 x 320, 3 = 48 x 320 (three 16-row tiles of v_mfma_f32_16x16x4_f32: it sums a chunk's channels in another
  * order than the others, so a caller keeps ONE of {0, 1, 2} / 3 per weight tensor) (cout_pad % fh_wino54_tile_m(tile_cfg) == 0).  Results differ from the F(4,3) form by
- * rounding only (tests/tools/winograd_numerics.py). */
+ * rounding: 0.8-1.1e-5 per conv against float64 on unit-scale data (F(4,3) 0.6-1.1e-5, direct 4e-7), kernel-fuzz worst cases about a
+ * third above F(4,3)'s (tests/tools/winograd_numerics.py, wino_fuzz.py; headroom against the weights' gain: profiles/r05_regime_sweep.txt). */
 int fh_wino54_tile_m(int tile_cfg);
 int fh_wino54_tile_n(void);
 int fh_conv_wino54_f32(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len,

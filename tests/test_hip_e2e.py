@@ -251,9 +251,11 @@ def test_batching_server_matches_single_generate():
         assert np.array_equal(outs[i], ref.cpu().squeeze(0).numpy())
 
 
-def test_graph_capture_replays_bit_identical():
-    """FlowHighSR.capture: the whole device path as one HIP graph; replays equal the eager call bit for bit."""
-    m, _ = model_for(synth.TINY_CFG, 0, upsampling="hip")
+@pytest.mark.parametrize("cfgname", ["TINY_CFG", "ODD_CFG"])
+def test_graph_capture_replays_bit_identical(cfgname):
+    """FlowHighSR.capture: the whole device path as one HIP graph; replays equal the eager call bit for bit.  (ODD_CFG: the
+    vocoder returns 480 N + 98 samples, which keys the post-processing workspace the capture must hold on to.)"""
+    m, _ = model_for(getattr(synth, cfgname), 0, upsampling="hip")
     n_in = 6000
     g = m.capture(2, n_in, 12000, 1)
     for seed in (50, 51):

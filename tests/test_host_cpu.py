@@ -1,5 +1,6 @@
 """CPU: host-side logic of the drop-in class that needs no GPU (checkpoint key contract, safe loading)."""
 import pytest
+from pathlib import Path
 import torch
 
 from flowhigh_amd import synth
@@ -307,3 +308,50 @@ def test_f54_tile_family_is_fixed_by_the_channel_count(monkeypatch):
     for wpad, batch, length in ((48, 1, 240000), (48, 32, 240000), (144, 2, 700)):
         cfg, _ = V.choose_wino_cfg([3, 6, 9], batch, wpad, length, 1, default=V.WINO_F54 | 3)
         assert cfg == V.WINO_F54 | 3
+
+
+def _all_tensors(obj, out, prefix=""):
+    """Every tensor reachable from a constructed model's weight attributes, by path."""
+    if isinstance(obj, torch.Tensor):
+        out[prefix] = obj
+    elif isinstance(obj, dict):
+        for k, v in obj.items():
+            _all_tensors(v, out, f"{prefix}.{k}")
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            _all_tensors(v, out, f"{prefix}[{i}]")
+
+
+@pytest.mark.parametrize("cfgname", ["TINY_CFG", "NK5_AMP2_CFG"])
+def test_weight_blob_gives_the_packers_tensors_bit_for_bit(tmp_path, cfgname, monkeypatch):
+    """flowhigh_amd.convert (reference load path flowhighsr.py:110-149, init_vocoder.py:8-23): the blob written
+    from the reference's three checkpoint files gives back, without reading them, every tensor the in-memory packers make --
+    same values, shapes and host-side lists -- and is refused when the checkpoints or the layout switches changed."""
+    from flowhigh_amd import convert, weights
+    from flowhigh_amd.flow import FlowNet
+    from flowhigh_amd.flowhighsr import CKPT_FILES, read_checkpoints
+    from flowhigh_amd.vocoder import Vocoder
+    cfg = getattr(synth, cfgname)
+    synth.write_checkpoint_dir(tmp_path, cfg, seed=3)
+    info = convert.convert(tmp_path)
+    assert Path(info["blob"]).name == weights.BLOB_NAME and info["tensors"] > 100
+    sd, cfg_read = read_checkpoints(tmp_path)
+    ref_net, ref_voc = FlowNet(sd, "cpu"), Vocoder(cfg_read, sd, "cpu")
+    srcs = {f: weights.file_digest(tmp_path / f) for f in CKPT_FILES}
+    store = weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(False), sources=srcs)
+    assert store is not None and store.cfg == cfg_read
+    net, voc = FlowNet(None, "cpu", store=store), Vocoder(store.cfg, None, "cpu", store=store)
+    for a, b in ((ref_net, net), (ref_voc, voc)):
+        ta, tb = {}, {}
+        _all_tensors({k: v for k, v in vars(a).items() if not k.startswith("_")}, ta)
+        _all_tensors({k: v for k, v in vars(b).items() if not k.startswith("_")}, tb)
+        assert ta.keys() == tb.keys() and len(ta) > 20
+        for k in ta:
+            assert ta[k].dtype == tb[k].dtype and ta[k].shape == tb[k].shape and torch.equal(ta[k], tb[k]), k
+    assert ref_voc.post_act["up"] == voc.post_act["up"] and ref_voc.stages[0]["blocks"][0]["acts"][0]["down"] == voc.stages[0]["blocks"][0]["acts"][0]["down"]
+    assert (net.dim, net.dim_in, net.dw_k, net.layers[0]["inner_pad"]) == (ref_net.dim, ref_net.dim_in, ref_net.dw_k, ref_net.layers[0]["inner_pad"])
+    # other checkpoint content, other layout switches: not used
+    assert weights.WeightStore.open(info["blob"], "cpu", sources=dict(srcs, **{CKPT_FILES[1]: "0" * 32})) is None
+    monkeypatch.setenv("FH_WINO54", "0")
+    assert weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(False)) is None
+    assert "layout switches" in weights.WeightStore.why
