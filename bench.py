@@ -180,7 +180,28 @@ def main():
     sr_in = conf["sr_in"]
     cfg = synth.SYNTH_CFG
     sd = synth.make_state_dict(cfg, 0)
-    model = FlowHighSR(FLowHigh(sd, cfg, dev), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
+    # The model is loaded the way a deployment loads it: rank 0 packs the weights once into the flat blob
+    # (flowhigh_amd/weights.py; on the CPU: float64 Winograd transforms of 118 M parameters), every rank maps that ONE file
+    # and uploads it with one copy.  pack_s / load_s go into the line's config.
+    from flowhigh_amd import convert, weights
+    blob = Path(os.environ.get("FH_BENCH_BLOB", f"/tmp/flowhigh_amd_bench_{os.getuid()}.blob"))
+    pack_s = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        store = convert.build_store(sd, cfg)
+        store.save(blob, cfg, weights.format_tag(False), {})
+        del store
+        pack_s = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    store = weights.WeightStore.open(blob, dev, expect_format=weights.format_tag(False))
+    if store is None:
+        raise SystemExit(f"bench.py: weight blob {blob} not usable: {weights.WeightStore.why}")
+    model = FlowHighSR(FLowHigh(None, cfg, dev, store=store), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
+    torch.cuda.synchronize()
+    load_s = time.perf_counter() - t0
+    blob_mib = blob.stat().st_size / 2 ** 20
     act_blocks = model.flowhigh.vocoder.act_blocks
     B = args.batch if args.batch is not None else conf["per_gpu"]
     n_frames = int(SECS * 100)
@@ -264,9 +285,22 @@ def main():
 
     line = None
     if rank == 0:
+        from tools.make_traffic_json import source_fingerprint
+        fp_now = source_fingerprint(ROOT)
+        stale = {}
+
         def pmc(name):          # (the PMC passes are per batch size: profiles/<name>.json at B = 1, <name>_B<n>.json otherwise)
             f = ROOT / "profiles" / (name if B == 1 else name.replace(".json", f"_B{B}.json"))
-            return json.loads(f.read_text()).get("bytes_per_launch") if f.exists() else None
+            if not f.exists():
+                stale[name] = "no PMC file for this batch size"
+                return None
+            rec = json.loads(f.read_text())
+            if rec.get("source_fingerprint") != fp_now:
+                # the kernels or the launch planner changed since the PMC passes: the committed bytes describe other launches
+                stale[name] = (f"profiles/{f.name} was measured on other kernel / planner sources (fingerprint "
+                               f"{rec.get('source_fingerprint')}, now {fp_now}): re-run tools/profile_round.sh")
+                return None
+            return rec.get("bytes_per_launch")
         metric = "48 kHz audio-seconds/sec (real-time factor), 12→48 kHz, 10 s clips, 1/2/4/8 MI355X"
         if args.config == 4:
             metric = "48 kHz audio-seconds/sec (real-time factor), 8→48 kHz, 10 s clips, clips scattered from / gathered on rank 0"
@@ -287,15 +321,19 @@ def main():
                                        if conf["sharded"] else f"clip-sharded x{world}, no data-path collective"),
                        "rccl_world_size": world if dist is not None else None,
                        "act_blocks_per_cu": act_blocks,       # 0 = no cap; vocoder.calibrate_act_occupancy (same bits either way)
+                       # model construction from the packed weight blob (map + one H2D copy + the activation-occupancy
+                       # calibration launches), and what packing it from the state dict took on this host (once, rank 0)
+                       "load_s": round(load_s, 3), "pack_s": round(pack_s, 2), "blob_mib": round(blob_mib, 1),
                        "sharded_check": None},
             "roofline": {"bound": "mfma",
-                         "kernel": "conv_wino54_kernel + conv_wino_kernel + conv_mfma_kernel (all conv launches of BigVGAN: 97 % of the path's FLOPs)",
+                         "kernel": "conv_wino54_kernel + amp_actconv_kernel + conv_wino_kernel + conv_mfma_kernel (all conv launches of BigVGAN: 97 % of the path's FLOPs)",
                          "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": pmc("conv_hbm_bytes_per_launch.json"),
                          "traffic_source": "profiles/conv_hbm_bytes_per_launch.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                            "passes of an earlier run of this command (tools/profile_round.sh), NOT measured "
-                                           f"by this run; bytes per conv launch at B = {B}",
+                                           f"by this run; bytes per conv launch at B = {B}; null when that file was measured on "
+                                           "other kernel / planner sources (traffic_stale says so)",
                          "note": "achieved = FLOPs issued to the matrix cores (Winograd launches: F(5,4) 1.6 ceil(k/4), F(4,3) 1.5 ceil(k/3) MACs per "
                                  "output and channel pair instead of k) / HIP-event time of the conv launches; "
                                  "algorithmic_equiv = direct-form FLOPs of the same convs (SURVEY.md 8d) / the same time",
@@ -320,6 +358,9 @@ def main():
                              "algorithmic_mb_per_launch": round(act_bytes_per_launch / 1e6, 2),
                              "act_ms_per_step": round(act_ms / max(timed_steps, 1), 3)},
         }
+        for key, name in (("roofline", "conv_hbm_bytes_per_launch.json"), ("roofline_hbm", "act_hbm_bytes_per_launch.json")):
+            if name in stale:
+                line[key]["traffic_stale"] = stale[name]
         if not args.no_alt and world == 1 and args.config == 2:
             line["alt_conv_bf16x6"] = alt_bf16x6(sd, cfg, dev, sr_in, x, z, out, B, n_frames, max(10, args.steps // 2))
         if not args.no_cpu_baseline and world == 1 and args.config == 2:

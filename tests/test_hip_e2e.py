@@ -661,3 +661,30 @@ def test_bench_under_torchrun_one_rank_initialises_rccl_and_checks_the_sharded_p
     line = json.loads(lines[0])
     assert line["config"]["rccl_world_size"] == 1 and line["n_gpus"] == 1
     assert "bit-identical" in line["config"]["sharded_check"]
+
+
+def test_from_local_through_a_weight_blob_gives_the_same_bits(tmp_path, monkeypatch):
+    """SURVEY.md 8f-3 (reference load path flowhighsr.py:110-149): `python -m flowhigh_amd.convert` once, then from_local maps the
+    blob and uploads it with one copy -- no torch.load, no packing -- and generate() returns the bits of the model built from
+    the checkpoint files; a blob that does not belong to the files is ignored."""
+    from flowhigh_amd import convert, weights
+    cfg = synth.TINY_CFG
+    synth.write_checkpoint_dir(tmp_path, cfg, seed=5)
+    monkeypatch.setenv("FH_BLOB", "0")
+    ref_model = FlowHighSR.from_local(tmp_path, "cuda", torchdiffeq_ode_method="euler")
+    clip, noise = synth.lowres_clip(3, 1.0, 12000), synth.prior_noise(3, 100)
+    ref = ref_model.generate(clip, 12000, 48000, 1, noise=noise)
+    convert.convert(tmp_path)
+    monkeypatch.delenv("FH_BLOB")
+    calls = []
+    import flowhigh_amd.flowhighsr as M
+    monkeypatch.setattr(M, "_load_checkpoint", lambda p: calls.append(p) or (_ for _ in ()).throw(AssertionError("checkpoint read")))
+    m = FlowHighSR.from_local(tmp_path, "cuda", torchdiffeq_ode_method="euler")
+    assert not calls
+    got = m.generate(clip, 12000, 48000, 1, noise=noise)
+    assert torch.equal(got, ref)
+    # other checkpoint content behind the same blob: refused (and then the checkpoints ARE read)
+    synth.write_checkpoint_dir(tmp_path, cfg, seed=6)
+    with pytest.raises(AssertionError, match="checkpoint read"):
+        FlowHighSR.from_local(tmp_path, "cuda")
+    assert "other checkpoint files" in weights.WeightStore.why

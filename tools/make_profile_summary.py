@@ -17,7 +17,7 @@ short = lambda n: n.replace('void ', '').replace('(anonymous namespace)::', '').
 def agg(keys):
     sel = [r for r in rows if any(k in r['Name'] for k in keys)]
     return sum(int(r['Calls']) for r in sel), sum(float(r['TotalDurationNs']) for r in sel)
-ccalls, ctot = agg(('conv_mfma_kernel', 'conv_wino_kernel', 'conv_wino54_kernel'))
+ccalls, ctot = agg(('conv_mfma_kernel', 'conv_wino_kernel', 'conv_wino54_kernel', 'amp_actconv_kernel'))
 acalls, atot = agg(('act1d_strip_kernel',))
 rl, rh = line['roofline'], line['roofline_hbm']
 rnd = int(''.join(ch for ch in tag[1:3] if ch.isdigit()))
@@ -26,7 +26,7 @@ o = [f"# Round {rnd} profile summary (1 x MI355X, B = {bsuf[1:]}, 10 s clips, 12
      f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {prof['steps']} --warmup {prof['warmup']} --no-cpu-baseline --no-alt`",
      f"(raw: `{tag}_kernel_stats_bench_{bsuf}.csv`; HBM traffic PMC passes `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of `bench.py --steps 1 --warmup 1`:",
      "`conv_hbm_bytes_per_launch.json`, `act_hbm_bytes_per_launch.json`; reproduce with `tools/profile_round.sh` on the GPU box).", "",
-     f"* all conv launches (conv_wino54_kernel + conv_wino_kernel + conv_mfma_kernel): {ccalls} launches, average duration **{ctot / ccalls / 1e3:.1f} us** under the "
+     f"* all conv launches (conv_wino54_kernel + amp_actconv_kernel + conv_wino_kernel + conv_mfma_kernel): {ccalls} launches, average duration **{ctot / ccalls / 1e3:.1f} us** under the "
      f"profiler; bench.py HIP events in the same run: {prl['avg_launch_us']} us; un-profiled bench run: {rl['avg_launch_us']} us "
      f"-> **{rl['achieved']} TFLOP/s executed on the matrix cores = {rl['frac']} of the 157.3 TFLOP/s fp32 MFMA peak** "
      f"({rl['executed_gflop_per_launch']} GFLOP per launch; direct-form equivalent {rl['algorithmic_equiv']} TFLOP/s = {rl['algorithmic_equiv_frac']}: "
