@@ -275,18 +275,32 @@ def make_amp_group(segs, bias, res, out, length, scale=1.0):
     return g
 
 
-def amp_tile_list(lens, batch, dilation):
-    """The work list of a narrow-stage launch (fh_amp_tile: group, batch item, first output, len): int32 tensor [tiles, 4],
-    groups in the given order (heavy first), a group's tiles in (batch item, time) order."""
+def amp_tile_list(lens, batch, dilation, interleave=None):
+    """The work list of a narrow-stage launch (fh_amp_tile: group, batch item, first output, len): int32 tensor [tiles, 4].
+    The launch's persistent blocks take tiles b, b + grid, b + 2 grid, ... of this list.  Order: the groups' tiles dealt
+    round-robin (group 0's first tile, group 1's first, ...), so that blocks with neighbouring ids work on tiles of DIFFERENT
+    length at any moment: with all tiles of the heaviest group first, every block of the chip ran the same K loop and then
+    stored its outputs in the same microseconds (no stores for 10 us, then 138 MB at once: the epilogue's HBM traffic cost a
+    quarter of the launch, tools/exp/amp_ab.sh).  A block still gets the same share of every group.  FH_AMP_INTERLEAVE=0: group
+    after group (heavy first)."""
+    if interleave is None:
+        interleave = os.environ.get("FH_AMP_INTERLEAVE", "1") != "0"
     tb = amp_tile_len(dilation)
-    rows = []
+    per_group = []
     for gi, length in enumerate(lens):
         t0 = torch.arange(0, length, tb, dtype=torch.int32)
-        for b in range(batch):
-            e = torch.empty(len(t0), 4, dtype=torch.int32)
-            e[:, 0], e[:, 1], e[:, 2], e[:, 3] = gi, b, t0, length
-            rows.append(e)
-    return torch.cat(rows, dim=0).contiguous()
+        e = torch.empty(batch, len(t0), 4, dtype=torch.int32)
+        e[..., 0], e[..., 3] = gi, length
+        e[..., 1] = torch.arange(batch, dtype=torch.int32)[:, None]
+        e[..., 2] = t0[None, :]
+        per_group.append(e.reshape(-1, 4))
+    if not interleave or len(per_group) == 1:
+        return torch.cat(per_group, dim=0).contiguous()
+    n = max(len(e) for e in per_group)
+    # position of tile i of group g in the dealt order: i * n_groups + g (groups that run out leave holes, dropped below)
+    keys = torch.cat([torch.arange(len(e), dtype=torch.int64) * len(per_group) + gi for gi, e in enumerate(per_group)])
+    rows = torch.cat(per_group, dim=0)
+    return rows[torch.argsort(keys)].contiguous()
 
 
 def amp_max_center(groups):

@@ -610,16 +610,29 @@ def test_gemm_geglu_packed():
     assert out[:, inner:].abs().max().item() == 0.0        # zero padding stays exactly zero
 
 
-def test_gemm_dft_magnitude_and_logmel():
-    g = torch.Generator().manual_seed(5)
-    audio = torch.randn(2, 9600, generator=g) * 0.1
-    ref = ref_cpu.logmel(audio)                                           # [2, 20, 256]
+@pytest.mark.parametrize("n,scale,seed,band", [(9600, 0.1, 5, False), (48000, 1.0, 7, False), (96000, 0.1, 9, True)])
+def test_gemm_dft_magnitude_and_logmel(n, scale, seed, band):
+    """Device log-mel (frame -> 2048-point FFT in LDS -> mel GEMM with log-clamp epilogue) against the oracle, with SURVEY.md 8a's
+    split.  Where mel > -8 the survey asks 1e-5 -- measured (profiles/r05_logmel_maxima.txt), the REFERENCE'S OWN fp32 torch.stft
+    sits 0.6-3.5e-5 from its float64 run there, so the bar that can be held is relative to that noise: the device result must be
+    as close to the float64 oracle as the fp32 oracle is (x 1.5 + 1e-5), and within 5e-5 of the fp32 oracle.  Below -8 (near
+    the log(1e-5) clamp, where the reference's fp32 FFT noise is amplified by the log: 8e-4 on a band-limited clip): the
+    survey's 2e-3."""
+    g = torch.Generator().manual_seed(seed)
+    audio = torch.randn(2, n, generator=g) * scale
+    if band:            # a 12 kHz clip upsampled 4 x: the band above 6 kHz is near-silent, as in the workload
+        import scipy.signal
+        low = (torch.randn(2, n // 4, generator=g) * scale).numpy()
+        audio = torch.from_numpy(scipy.signal.resample_poly(low, 4, 1, axis=-1).astype("float32"))
+    ref = ref_cpu.logmel(audio)                                           # [2, N, 256], fp32 torch.stft
+    ref64 = ref_cpu.logmel(audio.double()).float()
     from flowhigh_amd.frontend import LogMel
-    mel = LogMel(DEV)(audio.to(DEV)).view(2, 20, 256)
-    d = (mel.cpu() - ref).abs()
-    loud = ref > -8.0
-    assert d[loud].max().item() <= 1e-4      # relative fp32 DFT noise of the magnitude
-    assert d.max().item() <= 5e-3            # near the log(1e-5) clamp the reference's own FFT noise dominates
+    mel = LogMel(DEV)(audio.to(DEV)).view(ref.shape).cpu()
+    loud = ref64 > -8.0
+    own = float((ref - ref64).abs()[loud].max())                          # the reference's own fp32 noise where there is signal
+    assert float((mel - ref64).abs()[loud].max()) <= 1.5 * own + 1e-5
+    assert float((mel - ref).abs()[loud].max()) <= 5e-5
+    assert float((mel - ref).abs().max()) <= 2e-3
 
 
 def test_gemv_and_time_fourier():
