@@ -218,9 +218,6 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
   u32x4 xq[2][2];                                    // [channel of the pair][vector]: x[tA (- 8) + 4 f ..], f = lane, lane + 64
   float al[2], ib[2];
   auto load_x = [&](const Seg& S, int chunk, bool valid) {
-#ifdef F_ABL_NOX        // (timing experiment: no row requests)
-    valid = false;
-#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int ch = chunk * 8 + 2 * wv + h;
@@ -246,9 +243,6 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
   };
   u32x4 wq[MA];                                      // this thread's 16-byte pieces of the next weight stage
   auto load_w = [&](const float* p, bool valid) {
-#ifdef F_ABL_NOW        // (timing experiment: no weight requests)
-    valid = false;
-#endif
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p, valid ? (unsigned)f_wstage<MA>() * 4u : 0u);
 #pragma unroll
     for (int i = 0; i < MA; ++i) wq[i] = __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(tid + 256 * i) * 16u, 0, 0);
@@ -419,9 +413,6 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
       return row < 16 && co < channels && t < len;
     };
     auto epi_request = [&](int m) {                  // bias and first residual of round m's items
-#if defined(F_ABL_NOEPI) || defined(F_ABL_NOLD)      // (timing experiment: no epilogue requests, stores dropped below)
-      return;
-#endif
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         unsigned soff;
@@ -580,11 +571,7 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
           }
           o *= scale;
           const u32x4 ou = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
-#if defined(F_ABL_NOEPI) || defined(F_ABL_NOST)
-          __builtin_amdgcn_raw_buffer_store_b128(ou, ro, 0x80000000u, 0, 0);
-#else
           __builtin_amdgcn_raw_buffer_store_b128(ou, ro, ok ? soff : 0x80000000u, 0, 0);
-#endif
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
