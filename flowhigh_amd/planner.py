@@ -511,15 +511,16 @@ class _PlanBuilder:
         self.keep.append(d)
         self.add(("act", d, len(groups), c, length, din, dout), groups)
 
-    def res_conv(self, st, ents, xs_in, ks, dil, outs, res, pm=False, defer_sum=False):
+    def res_conv(self, st, ents, xs_in, ks, dil, outs, res, pm=False, defer_sum=False, acts=None):
         """One launch of the same conv position in the nk AMP blocks (one group per block) at the current stage
         length.  Returns, per block, the tensors whose sum is the conv's output (more than one: input-channel slices
         whose partial outputs the caller adds, defer_sum)."""
         c, cpad, wpad, L, B = st["c"], st["cpad"], st["wpad"], self.L, self.B
         biases = [e["b"] for e in ents]
         if all("ua" in e for e in ents):               # narrow stage: plain tensors whatever the dilation
-            self.amp([make_amp_group([make_amp_seg(xs_in[i], ents[i]["ua"], None, ks[i])], biases[i], res[i], outs[i], L)
-                      for i in range(len(ents))], c, L, dil, False)
+            # (acts: the Activation1d in front of each block's conv runs inside the launch: FH_AMP_FUSE_ACT=1)
+            self.amp([make_amp_group([make_amp_seg(xs_in[i], ents[i]["ua"], acts[i] if acts else None, ks[i])], biases[i], res[i],
+                                     outs[i], L) for i in range(len(ents))], c, L, dil, acts is not None)
             return [[o] for o in outs]
         all_wino = all("u" in e for e in ents)
         nsplit = wino_split_k(ks, c, wpad, self.Lref, dil, st["wcfg"], self.v.bf) if all_wino else 1
@@ -658,10 +659,25 @@ class _PlanBuilder:
             # dilated Winograd conv: the activations on both sides write / read phase-major tensors
             pm = same_d and 1 < d1 <= 16 and all("u" in b_["c1"][m] for b_ in blks)
             dpm = d1 if pm else 1
+            ents = [b_["c1"][m] for b_ in blks]
+            ents2 = [b_["c2"][m] for b_ in blks]
+            if amp_fuses_act() and all("ua" in e for e in ents + ents2):
+                # opt-in: every act -> conv pair of the position in ONE narrow-stage launch (the activated tensors stay in LDS)
+                self.at(i, m, 1, 0)
+                self.res_conv(st, ents, [xin[j] for j in order], ks, d1, [T2[j] for j in order], [[] for _ in blks],
+                              acts=[b_["acts"][2 * m] for b_ in blks])
+                self.at(i, m, 4, 0)
+                acts2 = [b_["acts"][2 * m + 1] for b_ in blks]
+                if m < v.nm - 1:
+                    self.res_conv(st, ents2, [T2[j] for j in order], ks, 1, [Y[j][m % 2] for j in order],
+                                  [[xin[j]] for j in order], acts=acts2)
+                    xin = [Y[j][m % 2] for j in range(v.nk)]
+                else:
+                    self.closing_conv(i, m, ents2, ks, [1] * v.nk, xin, acts=acts2, xs_in=[T2[j] for j in order])
+                continue
             self.at(i, m, 0, 0)
             self.act([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L, dout=dpm)
             self.at(i, m, 1, 0)
-            ents = [b_["c1"][m] for b_ in blks]
             if same_d:
                 self.res_conv(st, ents, [T1[j] for j in order], ks, d1, [T2[j] for j in order], [[] for _ in blks], pm=pm)
             else:
@@ -705,7 +721,7 @@ class _PlanBuilder:
             if m == v.nm - 1:            # xs / num_kernels, block order = the reference's xs += order
                 self.average(xin, self.S, self.B * c * L, 1.0 / v.nk, key=(i, m, 6, 0))
 
-    def closing_conv(self, i, m, ents, ks, ds, xin):
+    def closing_conv(self, i, m, ents, ks, ds, xin, acts=None, xs_in=None):
         """The stage-closing conv position: xs = sum over blocks of (conv(T1_j) + x_j); S = xs / num_kernels
         (models.py:181-187).  Fused form: ONE group with nk K segments, the blocks are summed in the accumulator and
         / nk is the epilogue scale.  Unfused form: nk groups (more blocks for the 256 CUs) + one averaging pass; whichever
@@ -718,8 +734,10 @@ class _PlanBuilder:
         fusable = v.nk <= hip.CONV_MAX_SEG          # (K segments of one group; more blocks: one group each + one averaging pass)
         if all("ua" in e for e in ents) and fusable and all(d == ds[0] for d in ds):
             # narrow stage: always the fused form (its blocks are short whatever the length: nothing to decide per clip)
-            segs = [make_amp_seg(T1[j], e["ua"], None, k) for j, e, k in zip(order, ents, ks)]
-            self.amp([make_amp_group(segs, st["last_bias"], [xin[j] for j in order], S, L, scale=scale)], c, L, ds[0], False)
+            src = xs_in if xs_in is not None else [T1[j] for j in order]
+            segs = [make_amp_seg(src[n], e["ua"], acts[n] if acts else None, k) for n, (e, k) in enumerate(zip(ents, ks))]
+            self.amp([make_amp_group(segs, st["last_bias"], [xin[j] for j in order], S, L, scale=scale)], c, L, ds[0],
+                     acts is not None)
             return
         if all("u" in e for e in ents):
             ksteps = [c // 16 * -(-k // st["taps"]) for k in ks]
@@ -745,7 +763,7 @@ class _PlanBuilder:
         if not fusable or all("ua" in e for e in ents):
             outs, res = [Y[j][m % 2] for j in order], [[xin[j]] for j in order]
             if all(d == ds[0] for d in ds):
-                self.res_conv(st, ents, [T1[j] for j in order], ks, ds[0], outs, res)
+                self.res_conv(st, ents, xs_in if xs_in is not None else [T1[j] for j in order], ks, ds[0], outs, res, acts=acts)
             else:
                 self.mixed_dilation_conv(st, order, ents, ks, ds, [T1[j] for j in order], outs, res)
             self.average([Y[j][m % 2] for j in range(v.nk)], S, B * c * L, scale, key=(i, m, 6, 0))
