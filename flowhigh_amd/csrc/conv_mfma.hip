@@ -59,10 +59,14 @@ __device__ __forceinline__ SegU load_seg(const fh_conv_seg* S) {
   return u;
 }
 
-template <int MT, int NT, int WM, int WN, int CK>
-__global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(const fh_conv_group* __restrict__ groups,
-                                                        int n_groups, int batch, int co_tiles,
-                                                        int n_tiles) {
+// PH > 1: "phase-fused" groups (fh_conv_transpose_fused_f32): the group's PH segments are the PH output phases of a
+// ConvTranspose1d with stride PH (the same input, each phase its own taps and weights): segment s accumulates into its OWN
+// accumulator set and the epilogue stores the PH phases of an input position as PH consecutive floats.  One block then writes
+// whole lines; with one block per phase every 128-byte line of the output was written by PH blocks in PH pieces (strided
+// 4-byte stores: 130 MB written for 46 MB of output over a step's upsamplers).  The arithmetic of a phase is unchanged.
+template <int MT, int NT, int WM, int WN, int CK, int PH = 1>
+__global__ __launch_bounds__(256, (MT * NT * PH <= 4 ? 3 : (MT * NT * PH <= 8 ? 2 : 1))) void conv_mfma_kernel(
+    const fh_conv_group* __restrict__ groups, int n_groups, int batch, int co_tiles, int n_tiles) {
   using Cfg = ConvCfg<MT, NT, WM, WN, CK>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, XW = Cfg::XW, WP = Cfg::WP;
   constexpr int XROWS = Cfg::XROWS, XREG = Cfg::XREG, WREG = Cfg::WREG, KQ = CK / 8;
@@ -100,13 +104,15 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   // longest): a block past its group's last column has nothing to do
   if (n0 >= uni(G->n_len)) return;
 
-  f32x16 acc[MT][NT];
+  f32x16 acc[PH][MT][NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int p = 0; p < PH; ++p)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
 
   // total number of (chunk, tap) steps over all segments
   int nsteps = 0;
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   // k-step 1, LDS stores of the next tiles at mid-step, so that a wave that is alone on its SIMD
   // keeps the matrix pipe fed; only the barrier and the first fragment reads stay exposed.
   int xoff_cur = toff[0];
-  auto step = [&](int it, u32x4 (&LOAD)[WREG], const u32x4 (&STORE)[WREG]) {
+  auto step = [&](f32x16 (&ACC)[MT][NT], int it, u32x4 (&LOAD)[WREG], const u32x4 (&STORE)[WREG]) {
     constexpr int KS = 4 * KQ;
     const bool last_tap = K.j == K.nt - 1;
     const bool more_chunks = K.cl > 1 || K.s + 1 < nseg;
@@ -254,8 +260,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks >> 2][mt][ks & 3], bf[ks & 1][nt],
-                                                             acc[mt][nt], 0, 0, 0);
+          ACC[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks >> 2][mt][ks & 3], bf[ks & 1][nt],
+                                                             ACC[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -274,9 +280,23 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
     }
   };
 
-  for (int it = 0; it < nsteps; it += 2) {
-    step(it, wregA, wregB);
-    if (it + 1 < nsteps) step(it + 1, wregB, wregA);
+  if constexpr (PH == 1) {
+    for (int it = 0; it < nsteps; it += 2) {
+      step(acc[0], it, wregA, wregB);
+      if (it + 1 < nsteps) step(acc[0], it + 1, wregB, wregA);
+    }
+  } else {
+    // one loop per phase (its accumulator set is a compile-time choice); every phase has an even number of steps (checked by
+    // the host), so the two weight register sets keep their roles across the phase boundaries
+    int it = 0;
+#pragma unroll
+    for (int p = 0; p < PH; ++p) {
+      const int n = uni((G->seg[p].cin / CK) * G->seg[p].ntaps);
+      for (int j = 0; j < n; j += 2, it += 2) {
+        step(acc[p], it, wregA, wregB);
+        step(acc[p], it + 1, wregB, wregA);
+      }
+    }
   }
 
   // ---- epilogue: bias + residuals, scale, strided store -------------------------------------
@@ -300,6 +320,34 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
     const int n = n0 + (wn * NT + nt) * 32 + l31;
     coloff[nt] = n < n_len ? (unsigned)(n * ostride + ophase) * 4u : 0x80000000u;
   }
+  if constexpr (PH > 1) {
+    // out[co, PH n + p] for p < PH: PH consecutive floats per lane, lanes on consecutive positions: whole lines per wave store
+    // (ostride == PH, ophase == 0, no residuals: checked by the launcher / the host)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bv = (bias && co < cout) ? bias[co] : 0.f;
+        const unsigned rowoff = (unsigned)co * (unsigned)lout * 4u;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const unsigned off = (co < cout) ? rowoff + coloff[nt] : 0x80000000u;
+          if constexpr (PH == 2) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = {__float_as_uint((acc[0][mt][nt][r] + bv) * scale), __float_as_uint((acc[1][mt][nt][r] + bv) * scale)};
+            __builtin_amdgcn_raw_buffer_store_b64(v, ro, off, 0, 0);
+          } else {
+            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+            const u32x3 v = {__float_as_uint((acc[0][mt][nt][r] + bv) * scale), __float_as_uint((acc[1][mt][nt][r] + bv) * scale),
+                             __float_as_uint((acc[PH - 1][mt][nt][r] + bv) * scale)};
+            __builtin_amdgcn_raw_buffer_store_b96(v, ro, off, 0, 0);
+          }
+        }
+      }
+    return;
+  }
+  auto& acc1 = acc[0];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -314,7 +362,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           off[q][nt] = (co < cout) ? rowoff + coloff[nt] : 0x80000000u;
-          v[q][nt] = acc[mt][nt][4 * g4 + q] + bv;
+          v[q][nt] = acc1[mt][nt][4 * g4 + q] + bv;
         }
       }
       if (nres > 0) {
@@ -352,7 +400,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(
   }
 }
 
-template <int MT, int NT, int WM, int WN, int CK>
+template <int MT, int NT, int WM, int WN, int CK, int PH = 1>
 int launch_conv(const fh_conv_group* groups, int n_groups, int batch, int cout_pad, int n_len,
                 hipStream_t stream) {
   using Cfg = ConvCfg<MT, NT, WM, WN, CK>;
@@ -362,7 +410,7 @@ int launch_conv(const fh_conv_group* groups, int n_groups, int batch, int cout_p
   const long long runs = panels * fh_cdiv(n_tiles, NT_RUN);
   const long long blocks = (long long)fh_cdiv(runs, 8) * 8 * NT_RUN;
   FH_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fh_conv_grouped_f32: grid too large");
-  hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WM, WN, CK>), dim3((unsigned)blocks), dim3(256), 0, stream,
+  hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WM, WN, CK, PH>), dim3((unsigned)blocks), dim3(256), 0, stream,
                      groups, n_groups, batch, co_tiles, n_tiles);
   FH_CHECK_LAUNCH("fh_conv_grouped_f32");
   return FH_OK;
@@ -462,6 +510,27 @@ extern "C" int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, in
     FH_CONV_CASE(6, 3, 1, 1, 4)
   }
 #undef FH_CONV_CASE
+  return FH_E_ARG;
+}
+
+extern "C" int fh_conv_transpose_fused_f32(const fh_conv_group* groups, int n_groups, int batch, int cout_pad, int n_len,
+                                          int tile_cfg, int phases, void* stream) {
+  FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && n_len > 0, "fh_conv_transpose_fused_f32: bad sizes");
+  FH_CHECK_ARG(phases == 2 || phases == 3, "fh_conv_transpose_fused_f32: %d phases (2 or 3)", phases);
+  const int bm = fh_conv_tile_m(tile_cfg);
+  FH_CHECK_ARG(bm > 0 && cout_pad % bm == 0, "fh_conv_transpose_fused_f32: cout_pad %d / tile_cfg %d", cout_pad, tile_cfg);
+  hipStream_t st = (hipStream_t)stream;
+#define FH_CONVT_CASE(id, MT, NT, WM, WN)                                                                       \
+  case id:                                                                                                      \
+    return phases == 2 ? launch_conv<MT, NT, WM, WN, 16, 2>(groups, n_groups, batch, cout_pad, n_len, st)       \
+                       : launch_conv<MT, NT, WM, WN, 16, 3>(groups, n_groups, batch, cout_pad, n_len, st);
+  switch (tile_cfg) {          // the shapes the launch plans use for upsamplers (channel chunk 16)
+    FH_CONVT_CASE(3, 2, 2, 1, 4)
+    FH_CONVT_CASE(4, 1, 4, 1, 4)
+    FH_CONVT_CASE(6, 3, 1, 1, 4)
+  }
+#undef FH_CONVT_CASE
+  fh_set_error("fh_conv_transpose_fused_f32: tile_cfg %d has no phase-fused form (3, 4, 6)", tile_cfg);
   return FH_E_ARG;
 }
 

@@ -80,6 +80,7 @@ _SIGS = {
     "fh_conv_tile_m": [_I],
     "fh_conv_tile_n": [_I],
     "fh_conv_grouped_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
+    "fh_conv_transpose_fused_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
     "fh_sizeof_wino_group": [],
     "fh_wino_tile_m": [_I],
     "fh_phase_len": [_I, _I],
@@ -98,6 +99,7 @@ _SIGS = {
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_pm_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
+    "fh_act_post_conv_tanh_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act_tile_len": [],
     "fh_act_set_blocks_per_cu": [_I],
     "fh_act_get_blocks_per_cu": [],

@@ -230,6 +230,18 @@ def use_amp(c, ks, dils):
             and all(cmax - (k - 1) // 2 + 4 * -(-k // 4) + 3 <= 16 for k in ks))
 
 
+def ups_fused_ok(st):
+    """A stage's direct-kernel ConvTranspose1d runs with all its output phases in one block (conv_mfma.hip, PH = 2 / 3): stride
+    2 or 3 with an even k - u, 16-channel chunks, one of the tile shapes that have the form, and an even number of K steps per
+    phase (the kernel's two weight register sets alternate per step).  A per-stage property; FH_UPS_FUSE=0: one group per phase
+    with strided stores, as until round 4 (same bits)."""
+    if os.environ.get("FH_UPS_FUSE", "1") == "0":
+        return False
+    return (st["u"] in (2, 3) and st["extra"] == 0 and st["up_ck"] == 16 and st["tile_cfg"] in (3, 4, 6)
+            and len(st["up_phases"]) <= hip.CONV_MAX_SEG
+            and all((st["cin"] // 16 * len(ph["offs"])) % 2 == 0 for ph in st["up_phases"]))
+
+
 def amp_fuses_act():
     """FH_AMP_FUSE_ACT=1: the narrow-stage launches also run the Activation1d in front of their conv (one launch per
     act -> conv pair, the activated tensor never leaves LDS).  Off by default: measured slower than the two launches
@@ -469,6 +481,15 @@ class _PlanBuilder:
         self.direct += flops
         self.add(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops), groups)
 
+    def convt(self, groups, cpad, n_len, tcfg, phases):
+        """Direct-kernel launch of phase-fused transposed-conv groups (fh_conv_transpose_fused_f32)."""
+        d = hip.to_device_struct_array(groups, self.v.device)
+        self.keep.append(d)
+        flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * self.B for g in groups for i in range(g.nseg))
+        self.executed += flops
+        self.direct += flops
+        self.add(("convt", d, len(groups), cpad, n_len, tcfg, phases, flops), groups)
+
     def wino(self, groups, wpad, length, dil, wcfg, pm=False, flops=None, batch=None, novl=False):
         """Winograd launch; the tile shape is the launch model's (choose_wino_cfg).  batch: launches whose groups are
         per batch item (input-channel slices) pass 1.  novl: some row of the launch is not 16-byte aligned although
@@ -617,6 +638,12 @@ class _PlanBuilder:
         extra = st["extra"]
         npos = lin + extra
         self.at(i, -1, 0, 0)
+        if st["up_wino"] is None and ups_fused_ok(st):
+            # all u output phases of a (co, time) tile in ONE block: segment p = phase p, whole-line stores
+            segs = [make_conv_seg(cur, ph["w"], st["cin"], ph["offs"]) for ph in st["up_phases"]]
+            self.convt([make_conv_group(segs, st["up_b"], [], X, c, st["cpad"], lin, L, lin, stride=u, phase=0)],
+                       st["cpad"], lin, st["tile_cfg"], u)
+            return
         if st["up_wino"] is None:
             self.conv([make_conv_group([make_conv_seg(cur, ph["w"], st["cin"], ph["offs"])], st["up_b"], [], X, c,
                                        st["cpad"], lin, L, npos if r == 0 else lin, stride=u, phase=r)
@@ -777,11 +804,15 @@ class _PlanBuilder:
         """activation_post + conv_post + tanh, and the plan record."""
         v, B, L = self.v, self.B, self.L
         c_last = v.stages[-1]["c"]
-        post_t = self.pool[2, :B * c_last * L].view(B, c_last, L)
-        self.at(99, 0, 0, 0)
-        self.act([make_act_group(cur, post_t, v.post_act)], c_last, L)
         wav = torch.empty(B, L, **self.f32)
-        self.add(("post", post_t, wav, c_last, L), key=(99, 0, 1, 0))
+        if L % 4 == 0 and v.post_k == 7 and os.environ.get("FH_FUSE_TAIL", "1") != "0":
+            # activation_post -> conv_post -> tanh as one launch (act1d.hip: act_post_conv_tanh_kernel; the bits of the two)
+            self.add(("tail", cur, wav, c_last, L), key=(99, 0, 1, 0))
+        else:
+            post_t = self.pool[2, :B * c_last * L].view(B, c_last, L)
+            self.at(99, 0, 0, 0)
+            self.act([make_act_group(cur, post_t, v.post_act)], c_last, L)
+            self.add(("post", post_t, wav, c_last, L), key=(99, 0, 1, 0))
         # algorithmic HBM bytes of the Activation1d launches: every site reads and writes its [B, C, L] tensor once
         act_bytes = sum(8.0 * s_[2] * B * s_[3] * s_[4] for s_ in self.steps if s_[0] == "act")
         return dict(steps=self.steps, meta=self.meta, keep=self.keep, mel_in=self.mel_in, wav=wav, B=B, N=self.N, L=L,
@@ -824,7 +855,8 @@ def merge_ragged(voc, frames):
     tt = hip.lib().fh_act_tile_len()
     for k in sorted(by_key):
         items = by_key[k]
-        kinds = {"sum" if it[1][0] == "mean" else it[1][0] for it in items}     # (a mean is a 2-3 term sum job)
+        # (a mean is a 2-3 term sum job; the fused tail launch and conv_post share a position: both run per clip)
+        kinds = {{"mean": "sum", "tail": "post"}.get(it[1][0], it[1][0]) for it in items}
         if len(kinds) != 1:
             raise NotImplementedError(f"launch position {k}: kinds {kinds} cannot be merged")
         kind = kinds.pop()
@@ -884,6 +916,14 @@ def merge_ragged(voc, frames):
                 allg.sort(key=lambda t: (-t[0], -t[1]))
                 tcfg = max(lst, key=lambda t: t[0])[1]
                 merged.append(("rconv", blob([t[2] for t in allg]), len(allg), cpad, max(t[1] for t in allg), tcfg, ck))
+        elif kind == "convt":
+            classes = {}
+            for ci, st_, groups in items:
+                _, _d, ng, cpad, n_len, tcfg, phases, _fl = st_
+                classes.setdefault((cpad, tcfg, phases), []).append((n_len, groups))
+            for (cpad, tcfg, phases), lst in classes.items():
+                allg = sorted(((n_len, g) for n_len, groups in lst for g in groups), key=lambda t: -t[0])
+                merged.append(("rconvt", blob([t[1] for t in allg]), len(allg), cpad, allg[0][0], tcfg, phases))
         elif kind == "amp":
             classes = {}
             for ci, st_, groups in items:
@@ -929,7 +969,7 @@ def merge_ragged(voc, frames):
                     raise NotImplementedError("partial-sum job shape")
                 jobs.append(j)
             merged.append(("rsum", blob(jobs), len(jobs), max(j.n for j in jobs)))
-        elif kind == "post":
+        elif kind in ("post", "tail"):
             for ci, st_, _ in items:
                 merged.append(st_)
         else:

@@ -208,6 +208,16 @@ def launch_step(voc, s, B, st):
         if timing is not None:
             e1.record()
             timing.append((e0, e1))
+    elif s[0] == "convt":
+        _, d, ng, cpad, n_len, tcfg, phases, _flops = s
+        timing = voc.conv_timing
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hip.check(L.fh_conv_transpose_fused_f32(d.data_ptr(), ng, B, cpad, n_len, tcfg, phases, st), "fh_conv_transpose_fused_f32")
+        if timing is not None:
+            e1.record()
+            timing.append((e0, e1))
     elif s[0] == "amp":
         _, d, ng, tiles, nt, c, dil, cmax, flags, _flops = s
         timing = voc.conv_timing
@@ -236,6 +246,12 @@ def launch_step(voc, s, B, st):
         if timing is not None:
             e1.record()
             timing.append((e0, e1))
+    elif s[0] == "tail":
+        _, x, wav, c, length = s
+        pa = voc.post_act
+        hip.check(L.fh_act_post_conv_tanh_f32(x.data_ptr(), pa["alpha"].data_ptr(), pa["inv_beta"].data_ptr(), voc.post_taps.data_ptr(),
+                                              voc.post_w.data_ptr(), voc.post_b.data_ptr(), wav.data_ptr(), B, c, length,
+                                              voc.post_k, st), "fh_act_post_conv_tanh_f32")
     else:
         _, x, wav, c, length = s
         hip.check(L.fh_conv_post_tanh_f32(x.data_ptr(), voc.post_w.data_ptr(), voc.post_b.data_ptr(),
@@ -264,6 +280,9 @@ def run_ragged_steps(voc, rp):
         elif s[0] == "ract":
             _, off, ng, c, din, dout, tiles, mult4 = s
             hip.check(L.fh_act1d_ragged_f32(base + off, ng, c, din, dout, tiles, mult4, st), "fh_act1d_ragged_f32")
+        elif s[0] == "rconvt":
+            _, off, ng, cpad, maxlen, tcfg, phases = s
+            hip.check(L.fh_conv_transpose_fused_f32(base + off, ng, 1, cpad, maxlen, tcfg, phases, st), "fh_conv_transpose_fused_f32")
         elif s[0] == "ramp":
             _, off, ng, off_t, nt, c, dil, cmax, flags = s
             hip.check(L.fh_amp_actconv_f32(base + off, ng, base + off_t, nt, c, dil, cmax, flags, st), "fh_amp_actconv_f32")

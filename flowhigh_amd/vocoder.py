@@ -33,7 +33,7 @@ from .planner import (  # noqa: F401
     _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_fuses_act, amp_max_center,
     amp_tile_len, amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,
     make_conv_seg, make_wino_group, make_wino_seg, merge_ragged, pick_tile_cfg, pick_wino54_tile,
-    pick_wino_tile, use_amp, use_bf16x6, use_wino, use_wino54, wino_block_mapping, wino_conv_ok,
+    pick_wino_tile, ups_fused_ok, use_amp, use_bf16x6, use_wino, use_wino54, wino_block_mapping, wino_conv_ok,
     wino_launch_cost, wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
 from .runtime import (  # noqa: F401
     ACT_BLOCKS_CHOICES, _act_blocks, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped,
@@ -242,6 +242,8 @@ class Vocoder:
                                   for b in st["blocks"]).contiguous()
             self.stages.append(st)
         self.post_act = act_params("activation_post.")
+        # (its 24 filter taps on the device as well: the fused tail launch reads them there)
+        self.post_taps = W.dev("v.activation_post.taps", lambda: torch.tensor(self.post_act["up"] + self.post_act["down"], dtype=torch.float32))
         self.post_w = W.dev("v.conv_post.w", lambda: g("conv_post.weight")[0])      # [c_last, 7]
         self.post_b = W.dev("v.conv_post.b", lambda: g("conv_post.bias"))
         self.post_k = self.post_w.shape[-1]

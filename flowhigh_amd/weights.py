@@ -29,7 +29,7 @@ def format_tag(bf16x6=False):
     """Everything that decides WHICH layouts the constructors pack: a blob made under other switches is not used."""
     from . import hip
     env = {k: os.environ.get(k, "") for k in ("FH_WINO", "FH_WINO54", "FH_WINO54_MIN_C", "FH_WINO54_H16", "FH_AMP")}
-    return json.dumps(dict(abi=hip.ABI_VERSION, layout=1, bf16x6=bool(bf16x6), env=env), sort_keys=True)
+    return json.dumps(dict(abi=hip.ABI_VERSION, layout=2, bf16x6=bool(bf16x6), env=env), sort_keys=True)
 
 
 def file_digest(path):

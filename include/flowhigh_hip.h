@@ -89,6 +89,15 @@ int fh_conv_tile_n(int tile_cfg);
 int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, int batch, int cout_pad,
                         int n_len, int tile_cfg, int ck, void* stream);
 
+/* ConvTranspose1d(k, stride u, padding (k - u) / 2) with u = `phases` in {2, 3} and k - u even (models/bigvgan/models.py:141-146,179)
+ * with ALL output phases of a (co tile, time tile) computed by one block: every group has nseg == phases segments -- segment p =
+ * output phase p: the same x, that phase's taps and packed weights (as the per-phase groups of fh_conv_grouped_f32 would have
+ * them), an EVEN number of (16-channel chunk, tap) steps -- out_stride == phases, out_phase == 0, n_len input positions, no
+ * residuals.  out[b, co, phases * n + p] = scale * (bias[co] + phase p's sum).  Same bits as `phases` groups with strided stores;
+ * the block writes phases consecutive floats per position (whole lines).  tile_cfg 3, 4 or 6; channel chunk 16. */
+int fh_conv_transpose_fused_f32(const fh_conv_group* groups, int n_groups, int batch, int cout_pad, int n_len,
+                                int tile_cfg, int phases, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * The same Conv1d call sites (models/bigvgan/models.py:63-72, "same"-padded, stride 1, square
  * cin x cout residual-stack convs) evaluated with the Winograd minimal-filtering identity
@@ -267,6 +276,14 @@ int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups, int batch,
  * total_tiles = groups[n-1].tile_base + C * ceil(groups[n-1].len / fh_act_tile_len()).  Same arithmetic per
  * sample as the launches above (replicate padding at each clip's own ends).  all_len_mult4: every group's len is a
  * multiple of 4 (rows 16-byte aligned: vector accesses). */
+/* The generator's tail in one launch: activation_post -> conv_post (7 taps, cin -> 1) -> tanh, models/bigvgan/models.py:189-192.
+ * x [B, C, len], taps = the activation's 24 filter taps (12 up, then 12 down) in DEVICE memory, w [C, 7], bias [1], out [B, len].
+ * Needs len % 4 == 0 and 16-byte aligned x / out (FH_E_ARG otherwise: the caller then runs fh_act1d_grouped_f32 +
+ * fh_conv_post_tanh_f32).  Same bits as those two launches: same expressions in the same order; the [B, C, len] tensor between
+ * them is never written. */
+int fh_act_post_conv_tanh_f32(const float* x, const float* alpha, const float* inv_beta, const float* taps,
+                              const float* w, const float* bias, float* out, int batch, int channels, int len,
+                              int ksz, void* stream);
 int fh_act_tile_len(void);
 int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, int din, int dout,
                         long long total_tiles, int all_len_mult4, void* stream);

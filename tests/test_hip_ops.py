@@ -96,6 +96,37 @@ def test_conv_transpose_as_phase_groups(u, k):
     assert maxdiff(out, ref) <= 1e-5
 
 
+@pytest.mark.parametrize("u,k,cin,cout,L,B,tile_cfg", [(2, 4, 96, 48, 1000, 2, 3), (2, 4, 48, 24, 2049, 1, 4), (2, 4, 192, 96, 700, 1, 6),
+                                                        (3, 7, 384, 192, 333, 1, 6), (3, 9, 32, 48, 157, 2, 3), (2, 6, 32, 24, 5, 1, 4)])
+def test_conv_transpose_all_phases_in_one_block(u, k, cin, cout, L, B, tile_cfg):
+    """fh_conv_transpose_fused_f32 (conv_mfma.hip, PH = 2 / 3): every block computes all u output phases of its (co, time)
+    tile and stores u consecutive floats per input position (whole lines instead of u strided 4-byte pieces).  Same bits as
+    the u phase groups of fh_conv_grouped_f32, and both equal torch's ConvTranspose1d (models.py:141-146)."""
+    x, wt, b = rnd(B, cin, L, seed=11), rnd(cin, cout, k, seed=12, scale=0.2 / (cin / 32) ** 0.5), rnd(cout, seed=13)
+    ref = F.conv_transpose1d(x, wt, b, stride=u, padding=(k - u) // 2)
+    lout = u * L
+    assert ref.shape[-1] == lout
+    cpad = -(-cout // hip.lib().fh_conv_tile_m(tile_cfg)) * hip.lib().fh_conv_tile_m(tile_cfg)
+    xd, bd = x.to(DEV), b.to(DEV)
+    one, per = torch.full((B, cout, lout), float("nan"), device=DEV), torch.full((B, cout, lout), float("nan"), device=DEV)
+    segs, groups, keep = [], [], []
+    for r, taps in enumerate(V.transposed_conv_phases(k, u)):
+        wsel = torch.stack([wt[:, :, j] for j, _ in taps], dim=-1).permute(1, 0, 2)
+        wp = V.pack_conv_weight(wsel, cpad, 16).to(DEV)
+        keep.append(wp)
+        offs = [o for _, o in taps]
+        assert (cin // 16 * len(offs)) % 2 == 0
+        segs.append(V.make_conv_seg(xd, wp, cin, offs))
+        groups.append(V.make_conv_group([V.make_conv_seg(xd, wp, cin, offs)], bd, [], per, cout, cpad, L, lout, L, stride=u, phase=r))
+    keep.append(V.conv_grouped(groups, B, cpad, L, tile_cfg, DEV, 16))
+    g = V.make_conv_group(segs, bd, [], one, cout, cpad, L, lout, L, stride=u, phase=0)
+    d = hip.to_device_struct_array([g], DEV)
+    hip.check(hip.lib().fh_conv_transpose_fused_f32(d.data_ptr(), 1, B, cpad, L, tile_cfg, u, hip.stream()), "fused")
+    torch.cuda.synchronize()
+    assert torch.equal(one, per)
+    assert maxdiff(one, ref) <= 1e-5 * max(1.0, (cin / 32) ** 0.5)
+
+
 def test_conv_three_segments_fused_average():
     """Last conv2 of a stage: one accumulator over the three AMP blocks + residuals, / 3."""
     c, L, B = 48, 400, 2
@@ -385,6 +416,33 @@ def test_conv_post_tanh():
     hip.check(hip.lib().fh_conv_post_tanh_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(),
                                               B, c, L, 7, hip.stream()), "conv_post")
     assert maxdiff(out, ref) <= 2e-6
+
+
+@pytest.mark.parametrize("L,B,C", [(3024, 2, 24), (4, 1, 8), (1008, 1, 24), (1012, 2, 16), (20000, 1, 24)])
+def test_fused_tail_has_the_bits_of_the_two_launches(L, B, C):
+    """activation_post -> conv_post -> tanh in one launch (bigvgan/models.py:189-192; act1d.hip: act_post_conv_tanh_kernel)
+    against fh_act1d_grouped_f32 + fh_conv_post_tanh_f32: bit for bit (same expressions in the same order), and both against
+    the oracle."""
+    filt = synth.kaiser_sinc_filter()
+    al, be = rnd(C, seed=301, scale=0.4), rnd(C, seed=302, scale=0.4)
+    sd = {"a.act.alpha": al, "a.act.beta": be, "a.upsample.filter": filt, "a.downsample.lowpass.filter": filt}
+    h = {"activation": "snakebeta", "snake_logscale": True}
+    x, w, b = rnd(B, C, L, seed=303, scale=1.5), rnd(C, 7, seed=304, scale=0.1), rnd(1, seed=305, scale=0.1)
+    ref = torch.tanh(F.conv1d(ref_cpu.activation1d(sd, "a.", x, h), w[None], b, padding=3)).squeeze(1)
+    p = dict(alpha=torch.exp(al).to(DEV), inv_beta=(1.0 / (torch.exp(be) + 1e-9)).to(DEV), up=filt.flatten().tolist(),
+             down=filt.flatten().tolist())
+    taps = torch.tensor(p["up"] + p["down"], dtype=torch.float32, device=DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    mid, two, one = torch.empty_like(xd), torch.full((B, L), float("nan"), device=DEV), torch.full((B, L), float("nan"), device=DEV)
+    Lb, st = hip.lib(), hip.stream()
+    keep = V.act1d_grouped([V.make_act_group(xd, mid, p)], B, C, L, DEV)
+    hip.check(Lb.fh_conv_post_tanh_f32(mid.data_ptr(), wd.data_ptr(), bd.data_ptr(), two.data_ptr(), B, C, L, 7, st), "post")
+    hip.check(Lb.fh_act_post_conv_tanh_f32(xd.data_ptr(), p["alpha"].data_ptr(), p["inv_beta"].data_ptr(), taps.data_ptr(),
+                                           wd.data_ptr(), bd.data_ptr(), one.data_ptr(), B, C, L, 7, st), "tail")
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    assert maxdiff(one, ref) <= 3e-6
+    del keep
 
 
 def test_rfft_irfft_2048():

@@ -65,7 +65,7 @@ def test_plan_steps_have_unique_sorted_position_keys(cfgname):
         keys = [m[0] for m in p["meta"]]
         assert len(keys) == len(p["steps"]) and len(set(keys)) == len(keys) and keys == sorted(keys)
         for step, (_, structs) in zip(p["steps"], p["meta"]):
-            assert (structs is not None) == (step[0] in ("conv", "wino", "act", "amp"))
+            assert (structs is not None) == (step[0] in ("conv", "convt", "wino", "act", "amp"))
             if structs is not None:
                 assert len(structs) == step[2]
 
@@ -86,7 +86,7 @@ def test_odd_upsamplers_carry_the_reference_lengths():
         assert voc.stage_lengths(n) == want and voc.out_len(n) == 480 * n + 98
         p = voc.plan(2, n)
         assert tuple(p["wav"].shape) == (2, want[-1])
-        ups = [(st, m[1]) for st, m in zip(p["steps"], p["meta"]) if m[0][1] == -1 and st[0] in ("conv", "wino")]
+        ups = [(st, m[1]) for st, m in zip(p["steps"], p["meta"]) if m[0][1] == -1 and st[0] in ("conv", "convt", "wino")]
         assert len(ups) == 5
         lin = n
         for i, (st, groups) in enumerate(ups):
@@ -96,6 +96,10 @@ def test_odd_upsamplers_carry_the_reference_lengths():
                 for g in groups:
                     assert g.len == lin + extra and g.out_stride == u
                     assert (g.out_len, g.seg[0].xlen) == ((want[i], lin) if extra else (0, 0))
+            elif st[0] == "convt":          # all u phases in one block (even k - u, stride 2 or 3): one group, segment = phase
+                assert extra == 0 and st[4] == lin and st[6] == u and len(groups) == 1
+                g = groups[0]
+                assert (g.lin, g.lout, g.n_len, g.out_stride, g.out_phase, g.nseg) == (lin, want[i], lin, u, 0, u)
             else:
                 assert st[4] == lin + extra
                 for r, g in enumerate(groups):
