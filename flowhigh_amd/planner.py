@@ -231,13 +231,15 @@ def use_amp(c, ks, dils):
 
 
 def ups_fused_ok(st):
-    """A stage's direct-kernel ConvTranspose1d runs with all its output phases in one block (conv_mfma.hip, PH = 2 / 3): stride
-    2 or 3 with an even k - u, 16-channel chunks, one of the tile shapes that have the form, and an even number of K steps per
-    phase (the kernel's two weight register sets alternate per step).  A per-stage property; FH_UPS_FUSE=0: one group per phase
-    with strided stores, as until round 4 (same bits)."""
-    if os.environ.get("FH_UPS_FUSE", "1") == "0":
+    """A stage's direct-kernel ConvTranspose1d runs with all its output phases in one block (conv_mfma.hip, PH = 2): stride 2
+    with an even k - u, 16-channel chunks, one of the tile shapes that have the form, and an even number of K steps per phase
+    (the kernel's two weight register sets alternate per step).  A per-stage property; FH_UPS_FUSE=0: one group per phase with
+    strided stores, as until round 4 (same bits); FH_UPS_FUSE=3: stride 3 as well (the kernel has the form; measured 275 us
+    against 139 us for the 384 -> 192 stage at batch 1: a third of the blocks, 1.2 per CU: profiles/r05_upsampler_phases.txt)."""
+    mode = os.environ.get("FH_UPS_FUSE", "1")
+    if mode == "0":
         return False
-    return (st["u"] in (2, 3) and st["extra"] == 0 and st["up_ck"] == 16 and st["tile_cfg"] in (3, 4, 6)
+    return (st["u"] in ((2, 3) if mode == "3" else (2,)) and st["extra"] == 0 and st["up_ck"] == 16 and st["tile_cfg"] in (3, 4, 6)
             and len(st["up_phases"]) <= hip.CONV_MAX_SEG
             and all((st["cin"] // 16 * len(ph["offs"])) % 2 == 0 for ph in st["up_phases"]))
 
@@ -805,8 +807,10 @@ class _PlanBuilder:
         v, B, L = self.v, self.B, self.L
         c_last = v.stages[-1]["c"]
         wav = torch.empty(B, L, **self.f32)
-        if L % 4 == 0 and v.post_k == 7 and os.environ.get("FH_FUSE_TAIL", "1") != "0":
-            # activation_post -> conv_post -> tanh as one launch (act1d.hip: act_post_conv_tanh_kernel; the bits of the two)
+        if L % 4 == 0 and v.post_k == 7 and os.environ.get("FH_FUSE_TAIL", "0") == "1":
+            # opt-in: activation_post -> conv_post -> tanh as one launch (act1d.hip: act_post_conv_tanh_kernel; the bits of the
+            # two).  Off by default: 66 us against 20 + 13 us at batch 1 -- 477 blocks that each walk 24 channels serially are
+            # 1.9 blocks per CU where the activation launch alone has 11 340 (profiles/r05_summary.md)
             self.add(("tail", cur, wav, c_last, L), key=(99, 0, 1, 0))
         else:
             post_t = self.pool[2, :B * c_last * L].view(B, c_last, L)

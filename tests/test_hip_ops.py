@@ -445,6 +445,24 @@ def test_fused_tail_has_the_bits_of_the_two_launches(L, B, C):
     del keep
 
 
+def test_vocoder_plans_with_the_opt_in_fusions_give_the_same_bits(monkeypatch):
+    """FH_FUSE_TAIL=1 (activation_post + conv_post + tanh as one launch) and FH_UPS_FUSE=3 / 0 (all phases of the stride-3
+    upsampler in one block too / no phase fusion at all) change launches, not arithmetic: same waveform bits as the default plan."""
+    cfg = synth.ALT3_CFG                          # rates 8, 6, 5, 2: the last upsampler has stride 2, AMPBlock2
+    sd = synth.make_vocoder_state_dict(cfg, seed=1)
+    mel = (rnd(2, 40, 256, seed=176, scale=2.0) - 3.0).to(DEV)
+    base = V.Vocoder(cfg, sd, DEV).forward(mel).clone()
+    for env in ({"FH_FUSE_TAIL": "1"}, {"FH_UPS_FUSE": "0"}, {"FH_UPS_FUSE": "3", "FH_FUSE_TAIL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        voc = V.Vocoder(cfg, sd, DEV)
+        kinds = {s_[0] for s_ in voc.plan(2, 40)["steps"]}
+        assert ("tail" in kinds) == (env.get("FH_FUSE_TAIL") == "1") and ("convt" in kinds) == (env.get("FH_UPS_FUSE") != "0")
+        assert torch.equal(voc.forward(mel), base)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_rfft_irfft_2048():
     """LDS FFT against torch.fft (float64): packed spectrum, magnitudes, and the C2R inverse."""
     from flowhigh_amd import tables
