@@ -50,9 +50,6 @@ constexpr int F_SLAB_BUF = F_SLAB + 128;   // + one trash pair per lane
 constexpr int F_YP = 324;                  // row pitch of the output staging
 constexpr int F_MAX_D = 6;
 // tuning switches (A/B builds: tools/build_variant.sh)
-#ifndef F_EPI_EARLY_MA      // row-tile counts up to which the last K step requests round 0's bias / residual (registers)
-#define F_EPI_EARLY_MA 2
-#endif
 #ifndef F_A_AHEAD           // A fragments requested one pair of points ahead of their MFMAs
 #define F_A_AHEAD 1
 #endif
@@ -403,22 +400,28 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
     const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (unsigned)channels * 4u : 0u);
     float bv[2][5];
     u32x4 rs[2][5];
-    auto epi_geom = [&](int m, int i, unsigned& soff) {
-      int it_ = sitem[i];
-      asm volatile("" : "+v"(it_));
-      const int row = it_ >> 16, col = it_ & 0xffff;
-      const int co = 16 * m + row;
-      const int t = t0 + col;
-      soff = ((unsigned)co * (unsigned)len + (unsigned)t) * 4u;
-      return row < 16 && co < channels && t < len;
+    // store items: byte offset of the item's vector in round 0 and whether its column lies inside the row, made once per tile
+    // behind the K loop (round m adds 16 m rows); the row test is per round
+    unsigned soff0[5];
+    int irow[5];
+    auto epi_setup = [&]() {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        int it_ = sitem[i];
+        asm volatile("" : "+v"(it_));                // (opaque: nothing of this is hoisted into the K loop's registers)
+        const int row = it_ >> 16, col = it_ & 0xffff;
+        irow[i] = (row < 16 && t0 + col < len) ? row : 0x4000;      // 0x4000: never a valid row
+        soff0[i] = ((unsigned)row * (unsigned)len + (unsigned)(t0 + col)) * 4u;
+      }
     };
+    const unsigned round_bytes = 16u * (unsigned)len * 4u;
     auto epi_request = [&](int m) {                  // bias and first residual of round m's items
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        unsigned soff;
-        const bool ok = epi_geom(m, i, soff);
-        bv[m & 1][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, ok ? (unsigned)(16 * m + (sitem[i] >> 16)) * 4u : 0x80000000u, 0, 0));
-        if (VEC) rs[m & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, ok ? soff : 0x80000000u, 0, 0);
+        const int co = 16 * m + irow[i];
+        const bool ok = co < channels;
+        bv[m & 1][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, ok ? (unsigned)co * 4u : 0x80000000u, 0, 0));
+        if (VEC) rs[m & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rr0, ok ? soff0[i] + (unsigned)m * round_bytes : 0x80000000u, 0, 0);
       }
     };
 
@@ -450,8 +453,6 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
           const float* wnext = (last_g && last_c) ? SN.u : S.u + (size_t)(c * GC + g + 1) * f_wstage<MA>();
           load_w(wnext, nw);
           if (g == 0) load_x(last_c ? SN : S, last_c ? 0 : c + 1, nx);
-          // last step of the tile: round 0's bias / residual under its MFMAs
-          if (MA <= F_EPI_EARLY_MA && last_g && last_c && !more_seg) epi_request(0);
           const float* const wl = wbuf0 + wb * f_wstage<MA>();
           // the tile's 8 samples of this tap group, both channels of the pair (one ds_read_b64 each)
           f32x2 xr[8];
@@ -526,7 +527,8 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
 
     // ---- epilogue -------------------------------------------------------------------------------------------------
     // (the last step ended on a barrier; the staging is not the slab: the next tile's first chunk is already there)
-    if (MA > F_EPI_EARLY_MA) epi_request(0);
+    epi_setup();
+    epi_request(0);
 #pragma unroll
     for (int m = 0; m < MA; ++m) {
       f32x4 y[5];
@@ -552,8 +554,8 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        unsigned soff;
-        const bool ok = epi_geom(m, i, soff);
+        const bool ok = 16 * m + irow[i] < channels;
+        const unsigned soff = soff0[i] + (unsigned)m * round_bytes;
         const float b_ = bv[m & 1][i];
         const int yrow = sitem[i] >> 16, ycol = sitem[i] & 0xffff;
         const f32x4 yv = *reinterpret_cast<const f32x4*>(ybuf + (yrow < 16 ? yrow : 0) * F_YP + ycol);
