@@ -194,6 +194,10 @@ def main():
         pack_s = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
+        # one activation-occupancy setting for the node, measured by rank 0 while the others wait (an explicit collective:
+        # the model constructors never communicate)
+        from flowhigh_amd import vocoder as _voc
+        _voc.sync_act_blocks(dev)
     t0 = time.perf_counter()
     store = weights.WeightStore.open(blob, dev, expect_format=weights.format_tag(False))
     if store is None:

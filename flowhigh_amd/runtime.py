@@ -88,21 +88,47 @@ def parse_act_blocks(value):
     return v
 
 
-def decide_act_blocks(measure, group=None):
-    """The node-wide choice: with an initialised torch.distributed process group of more than one rank, rank 0 alone runs
-    `measure()` (-> list of per-pass {blocks: us}) and broadcasts its choice -- eight ranks timing launch pairs while
-    their neighbours load models under one power budget would each measure something else.  Returns (choice, passes)."""
-    import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    if not multi:
+def decide_act_blocks(measure, group=None, collective=False):
+    """(choice, passes) from `measure()` (-> list of per-pass {blocks: us}).
+    collective=False (what a constructor does): measured by the calling process, no communication -- a constructor must never
+    enter a collective: whether a rank gets here depends on per-process state (the per-device cache, FH_ACT_BLOCKS, a second
+    model on one rank), and the ranks that wait would hang.
+    collective=True (sync_act_blocks: an explicit call that EVERY rank of `group` makes at the same point of the program): rank 0
+    of the group alone measures -- eight ranks timing launch pairs while their neighbours load models under one power budget
+    would each measure something else -- and broadcasts its choice, or the error it hit (a failing rank 0 must not leave the
+    others waiting: they raise too)."""
+    if not collective:
         passes = measure()
         return pick_act_blocks(passes), passes
+    import torch.distributed as dist
     box = [None]
     if dist.get_rank(group) == 0:
-        passes = measure()
-        box[0] = (pick_act_blocks(passes), passes)
+        try:
+            passes = measure()
+            box[0] = ("ok", pick_act_blocks(passes), passes)
+        except Exception as e:                            # noqa: BLE001  (reported on every rank)
+            box[0] = ("error", f"{type(e).__name__}: {e}", None)
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    return box[0]
+    if box[0][0] != "ok":
+        raise RuntimeError(f"activation occupancy calibration failed on rank 0 of the group: {box[0][1]}")
+    return box[0][1], box[0][2]
+
+
+def sync_act_blocks(device, group=None):
+    """One setting for all ranks of `group` (default: the world; pass a per-node group when the nodes differ): call it on EVERY
+    rank, before the models are built; it returns the setting and puts it in force (and in the per-device cache, so that the
+    constructors measure nothing).  FH_ACT_BLOCKS still overrides.  Without an initialised process group: the local calibration."""
+    import torch.distributed as dist
+    dev = hip.norm_device(device)
+    fixed = parse_act_blocks(os.environ.get("FH_ACT_BLOCKS"))
+    if fixed is not None or not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return calibrate_act_occupancy(dev)
+
+    def measure():
+        return [{b: measure_act_conv_pair(dev, b) for b in ACT_BLOCKS_CHOICES} for _ in range(2)]
+    choice, passes = decide_act_blocks(measure, group=group, collective=True)
+    calibrate_act_occupancy.last_measurement = passes
+    return calibrate_act_occupancy(dev, force=True, act_blocks=choice)
 
 
 def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100):
@@ -152,8 +178,8 @@ def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100
 def calibrate_act_occupancy(device, force=False, act_blocks=None):
     """Choose and set the activation launches' blocks per CU on `device` (once per device and process).
     act_blocks (Vocoder(act_blocks=)) or FH_ACT_BLOCKS = auto | 0 | 2..5 override the measurement -- a deployment that
-    knows its boxes, or a launcher that wants every rank alike, passes the number.  With torch.distributed initialised
-    rank 0 measures and every rank takes its choice (decide_act_blocks).  The measured pair times are logged
+    knows its boxes, or a launcher that wants every rank alike, passes the number.  No communication here: ranks that want one
+    setting call sync_act_blocks() before they build their models (bench.py does).  The measured pair times are logged
     (logger 'flowhigh_amd').  Returns the setting.  Results do not depend on it, only launch times."""
     dev = hip.norm_device(device)
     if dev.type != "cuda" or not torch.cuda.is_available():

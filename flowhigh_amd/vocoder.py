@@ -38,7 +38,7 @@ from .planner import (  # noqa: F401
 from .runtime import (  # noqa: F401
     ACT_BLOCKS_CHOICES, _act_blocks, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped,
     conv_wino, decide_act_blocks, launch_step, measure_act_conv_pair, parse_act_blocks, pick_act_blocks,
-    run_ragged_steps, run_steps)
+    run_ragged_steps, run_steps, sync_act_blocks)
 
 VOC = "flowhigh.audio_enc_dec.vocoder."
 

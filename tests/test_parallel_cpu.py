@@ -126,15 +126,26 @@ def _calib_worker(rank, world, port, q):
         def measure():              # rank 0's box has the clock dip, the others' measurement would say it has not
             calls.append(rank)
             return [{0: 615.0, 3: 560.0}, {0: 610.0, 3: 570.0}] if rank == 0 else [{0: 540.0, 3: 560.0}] * 2
-        choice, passes = V.decide_act_blocks(measure)
-        q.put((rank, choice, len(calls), passes[0][3]))
+        choice, passes = V.decide_act_blocks(measure, collective=True)
+        # a failing rank 0 reaches every rank as an error instead of leaving them in the broadcast
+        def broken():
+            raise ValueError("no device")
+        try:
+            V.decide_act_blocks(broken if rank == 0 else measure, collective=True)
+            failed = False
+        except RuntimeError as e:
+            failed = "ValueError: no device" in str(e)
+        # and without collective=True nothing is exchanged: every rank's own measurement
+        own = V.decide_act_blocks(measure)[0]
+        q.put((rank, choice, len(calls), passes[0][3], failed, own))
     finally:
         dist.destroy_process_group()
 
 
 def test_act_occupancy_choice_is_measured_on_rank_0_and_broadcast():
-    """vocoder.decide_act_blocks under torch.distributed: only rank 0 times launch pairs, every rank takes its choice
-    (eight ranks calibrating concurrently under one power budget would each measure something else)."""
+    """vocoder.decide_act_blocks(collective=True) (sync_act_blocks: an explicit call every rank makes): only rank 0 times launch
+    pairs, every rank takes its choice (eight ranks calibrating concurrently under one power budget would each measure something
+    else); rank 0's failure raises on every rank; the constructors' form (collective=False) never communicates."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -146,7 +157,7 @@ def test_act_occupancy_choice_is_measured_on_rank_0_and_broadcast():
         p.join(120)
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
-    assert got == [(0, 3, 1, 560.0), (1, 3, 0, 560.0)]
+    assert got == [(0, 3, 2, 560.0, True, 3), (1, 3, 1, 560.0, True, 0)]
     # without a process group: measured locally
     from flowhigh_amd import vocoder as V
     assert V.decide_act_blocks(lambda: [{0: 540.0, 3: 560.0}] * 2)[0] == 0
