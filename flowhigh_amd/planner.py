@@ -230,18 +230,28 @@ def use_amp(c, ks, dils):
             and all(cmax - (k - 1) // 2 + 4 * -(-k // 4) + 3 <= 16 for k in ks))
 
 
-def ups_fused_ok(st):
+def ups_fused_ok(st, mode=None):
     """A stage's direct-kernel ConvTranspose1d runs with all its output phases in one block (conv_mfma.hip, PH = 2): stride 2
     with an even k - u, 16-channel chunks, one of the tile shapes that have the form, and an even number of K steps per phase
     (the kernel's two weight register sets alternate per step).  A per-stage property; FH_UPS_FUSE=0: one group per phase with
     strided stores, as until round 4 (same bits); FH_UPS_FUSE=3: stride 3 as well (the kernel has the form; measured 275 us
     against 139 us for the 384 -> 192 stage at batch 1: a third of the blocks, 1.2 per CU: profiles/r05_upsampler_phases.txt)."""
-    mode = os.environ.get("FH_UPS_FUSE", "1")
+    mode = os.environ.get("FH_UPS_FUSE", "1") if mode is None else mode
     if mode == "0":
         return False
     return (st["u"] in ((2, 3) if mode == "3" else (2,)) and st["extra"] == 0 and st["up_ck"] == 16 and st["tile_cfg"] in (3, 4, 6)
             and len(st["up_phases"]) <= hip.CONV_MAX_SEG
             and all((st["cin"] // 16 * len(ph["offs"])) % 2 == 0 for ph in st["up_phases"]))
+
+
+def plan_switches():
+    """The environment switches that shape a launch PLAN, read ONCE when a model is built (Vocoder.sw) and used for every plan
+    of that model: a model's launches (and, for FH_WINO_SPLITK, its bits) do not change when the environment does while it
+    lives.  (The switches that decide which kernel a stage's weights are packed for -- FH_WINO, FH_WINO54*, FH_AMP,
+    FH_CONV_BF16X6 -- are read at construction as well, by use_wino / use_wino54 / use_amp / use_bf16x6.)"""
+    return dict(splitk=os.environ.get("FH_WINO_SPLITK", "1") != "0", ups_fuse=os.environ.get("FH_UPS_FUSE", "1"),
+                amp_fuse_act=os.environ.get("FH_AMP_FUSE_ACT", "0") == "1", fuse_tail=os.environ.get("FH_FUSE_TAIL", "0") == "1",
+                amp_interleave=os.environ.get("FH_AMP_INTERLEAVE", "1") != "0")
 
 
 def amp_fuses_act():
@@ -349,18 +359,18 @@ def wino_taps(cfg):
     return 4 if cfg & WINO_F54 else 3
 
 
-def wino_split_k(ks, c, wpad, length, dil, default_cfg, bf=False):
+def wino_split_k(ks, c, wpad, length, dil, default_cfg, bf=False, enabled=None):
     """Number of input-channel slices (1, 2 or 3) of a residual-stack launch (one group per kernel size in ks)."""
     t = wino_taps(default_cfg)
-    return wino_split_steps([c // 16 * -(-k // t) for k in ks], c, wpad, length, dil, default_cfg, bf)
+    return wino_split_steps([c // 16 * -(-k // t) for k in ks], c, wpad, length, dil, default_cfg, bf, enabled)
 
 
-def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg, bf=False):
+def wino_split_steps(ksteps, cin, wpad, length, dil, default_cfg, bf=False, enabled=None):
     """Number of input-channel slices (1, 2 or 3) of a Winograd launch whose groups have `ksteps` K steps
     (cin / 16 x tap groups) each: more than one only where the batch-1 launch model says the blocks are too few and
     too long (clips under ~2 s); never a function of the batch size, so a clip gives the same bits alone and inside a
-    batch.  FH_WINO_SPLITK=0 switches it off."""
-    if os.environ.get("FH_WINO_SPLITK", "1") == "0":
+    batch.  FH_WINO_SPLITK=0 switches it off (enabled: a model's snapshot of that switch, Vocoder.sw; None: the environment)."""
+    if not (os.environ.get("FH_WINO_SPLITK", "1") != "0" if enabled is None else enabled):
         return 1
     base = choose_wino_cfg(ksteps, 1, wpad, length, dil, default_cfg, bf)[1]
     best, n = base, 1
@@ -521,7 +531,7 @@ class _PlanBuilder:
     def amp(self, groups, c, length, dil, fused_act):
         """Narrow-stage launch (fh_amp_actconv_f32): the groups' convs, with their activation in front when fused_act."""
         B = self.B
-        tiles = amp_tile_list([g.len for g in groups], B, dil).to(self.v.device)
+        tiles = amp_tile_list([g.len for g in groups], B, dil, self.v.sw["amp_interleave"]).to(self.v.device)
         d = hip.to_device_struct_array(groups, self.v.device)
         self.keep += [d, tiles]
         flops = sum(2.0 * c * c * (2 * g.seg[i].center + 1) * length * B for g in groups for i in range(g.nseg))
@@ -546,7 +556,7 @@ class _PlanBuilder:
                                      outs[i], L) for i in range(len(ents))], c, L, dil, acts is not None)
             return [[o] for o in outs]
         all_wino = all("u" in e for e in ents)
-        nsplit = wino_split_k(ks, c, wpad, self.Lref, dil, st["wcfg"], self.v.bf) if all_wino else 1
+        nsplit = wino_split_k(ks, c, wpad, self.Lref, dil, st["wcfg"], self.v.bf, self.v.sw["splitk"]) if all_wino else 1
         if nsplit > 1:
             # Short clips: a launch of a few dozen blocks is bound by the K loop of ONE block.  The input channels
             # are cut into nsplit slices, one group each (first slice: bias and residual), and the partial
@@ -640,7 +650,7 @@ class _PlanBuilder:
         extra = st["extra"]
         npos = lin + extra
         self.at(i, -1, 0, 0)
-        if st["up_wino"] is None and ups_fused_ok(st):
+        if st["up_wino"] is None and ups_fused_ok(st, v.sw["ups_fuse"]):
             # all u output phases of a (co, time) tile in ONE block: segment p = phase p, whole-line stores
             segs = [make_conv_seg(cur, ph["w"], st["cin"], ph["offs"]) for ph in st["up_phases"]]
             self.convt([make_conv_group(segs, st["up_b"], [], X, c, st["cpad"], lin, L, lin, stride=u, phase=0)],
@@ -655,7 +665,7 @@ class _PlanBuilder:
         xlen, olen = (lin, L) if extra else (0, 0)
         up_flops = sum(2.0 * c * st["cin"] * ph["k"] * lin * B for ph in st["up_wino"])
         nsplit = wino_split_steps([st["cin"] // 16 * -(-ph["k"] // 3) for ph in st["up_wino"]], st["cin"], st["up_wpad"],
-                                  self.lin_ref + extra, 1, st["up_wcfg"], v.bf)
+                                  self.lin_ref + extra, 1, st["up_wcfg"], v.bf, v.sw["splitk"])
         if nsplit == 1:
             self.wino([make_wino_group([make_wino_seg(cur, ph["u"], st["cin"], ph["k"], ph["center"], xlen=xlen)], st["up_b"],
                                        [], X, c, st["up_wpad"], npos, stride=u, phase=r, out_len=olen)
@@ -690,7 +700,7 @@ class _PlanBuilder:
             dpm = d1 if pm else 1
             ents = [b_["c1"][m] for b_ in blks]
             ents2 = [b_["c2"][m] for b_ in blks]
-            if amp_fuses_act() and all("ua" in e for e in ents + ents2):
+            if v.sw["amp_fuse_act"] and all("ua" in e for e in ents + ents2):
                 # opt-in: every act -> conv pair of the position in ONE narrow-stage launch (the activated tensors stay in LDS)
                 self.at(i, m, 1, 0)
                 self.res_conv(st, ents, [xin[j] for j in order], ks, d1, [T2[j] for j in order], [[] for _ in blks],
@@ -807,7 +817,7 @@ class _PlanBuilder:
         v, B, L = self.v, self.B, self.L
         c_last = v.stages[-1]["c"]
         wav = torch.empty(B, L, **self.f32)
-        if L % 4 == 0 and v.post_k == 7 and os.environ.get("FH_FUSE_TAIL", "0") == "1":
+        if L % 4 == 0 and v.post_k == 7 and v.sw["fuse_tail"]:
             # opt-in: activation_post -> conv_post -> tanh as one launch (act1d.hip: act_post_conv_tanh_kernel; the bits of the
             # two).  Off by default: 66 us against 20 + 13 us at batch 1 -- 477 blocks that each walk 24 channels serially are
             # 1.9 blocks per CU where the activation launch alone has 11 340 (profiles/r05_summary.md)
@@ -937,7 +947,7 @@ def merge_ragged(voc, frames):
                 allg = [g for groups in lst for g in groups]
                 # heavy groups first (the persistent blocks walk the tile list in order), then long ones
                 allg.sort(key=lambda g: (-sum(g.seg[i].ngrp for i in range(g.nseg)), -g.len))
-                tl = amp_tile_list([g.len for g in allg], 1, dil)
+                tl = amp_tile_list([g.len for g in allg], 1, dil, voc.sw["amp_interleave"])
                 off_t = sum(len(b) for b in blobs)
                 raw = tl.numpy().tobytes()
                 blobs.append(raw + bytes(-len(raw) % 16))

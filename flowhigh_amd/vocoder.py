@@ -33,8 +33,8 @@ from .planner import (  # noqa: F401
     _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_fuses_act, amp_max_center,
     amp_tile_len, amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,
     make_conv_seg, make_wino_group, make_wino_seg, merge_ragged, pick_tile_cfg, pick_wino54_tile,
-    pick_wino_tile, ups_fused_ok, use_amp, use_bf16x6, use_wino, use_wino54, wino_block_mapping, wino_conv_ok,
-    wino_launch_cost, wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
+    pick_wino_tile, plan_switches, ups_fused_ok, use_amp, use_bf16x6, use_wino, use_wino54, wino_block_mapping,
+    wino_conv_ok, wino_launch_cost, wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
 from .runtime import (  # noqa: F401
     ACT_BLOCKS_CHOICES, _act_blocks, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped,
     conv_wino, decide_act_blocks, launch_step, measure_act_conv_pair, parse_act_blocks, pick_act_blocks,
@@ -59,6 +59,8 @@ class Vocoder:
         # bf16x6: the Winograd convs contract on the BF16 matrix cores, operands split into three bf16 pieces
         # (None: FH_CONV_BF16X6; see use_bf16x6)
         self.bf = use_bf16x6() if bf16x6 is None else bool(bf16x6)
+        # plan-shaping environment switches, read once: every plan of this model uses this snapshot (planner.plan_switches)
+        self.sw = plan_switches()
         self.rates = list(cfg["upsample_rates"])
         self.up_k = list(cfg["upsample_kernel_sizes"])
         self.c0 = int(cfg["upsample_initial_channel"])

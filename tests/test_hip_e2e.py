@@ -15,8 +15,13 @@ TOL_WAVEFORM = 1e-4
 _MODELS = {}
 
 
-def model_for(cfg, seed, method="euler", cfm_method="basic_cfm", sigma=0.0, upsampling="scipy", bf16x6=False):
+def model_for(cfg, seed, method="euler", cfm_method="basic_cfm", sigma=0.0, upsampling="scipy", bf16x6=False, fresh=False):
+    """fresh: build a model now (under the environment as it is now) instead of taking the cached one."""
     key = (repr(sorted(cfg.items())), seed, bf16x6)
+    if fresh:
+        sd = synth.make_state_dict(cfg, seed)
+        fh = FLowHigh(sd, cfg, "cuda", conv_bf16x6=bf16x6)
+        return FlowHighSR(fh, sigma=sigma, cfm_method=cfm_method, torchdiffeq_ode_method=method, upsampling_method=upsampling), sd
     if key not in _MODELS:
         sd = synth.make_state_dict(cfg, seed)
         _MODELS[key] = (FLowHigh(sd, cfg, "cuda", conv_bf16x6=bf16x6), sd)
@@ -314,11 +319,15 @@ def test_short_clip_split_k_launches(monkeypatch):
     assert torch.equal(one[0], two[1])
     ref = ref_cpu.generate(sd, cfg, a, 12000, na, 1, "euler")
     assert (one.cpu() - ref).abs().max().item() <= TOL_WAVEFORM
+    # FH_WINO_SPLITK=0 is read when a model is BUILT (Vocoder.sw): this model keeps slicing whatever the environment says now ...
     monkeypatch.setenv("FH_WINO_SPLITK", "0")
     voc._plans.clear()
-    assert "sum" not in [s_[0] for s_ in voc.plan(1, 50)["steps"]]
-    plain = m.generate_batch([a], 12000, 48000, 1, noise=na)
-    voc._plans.clear()
+    assert [s_[0] for s_ in voc.plan(1, 50)["steps"]].count("sum") >= 5
+    # ... and a model built under the switch never slices
+    m2, _ = model_for(cfg, 0, "euler", fresh=True)
+    assert m2.flowhigh.vocoder.sw["splitk"] is False
+    assert "sum" not in [s_[0] for s_ in m2.flowhigh.vocoder.plan(1, 50)["steps"]]
+    plain = m2.generate_batch([a], 12000, 48000, 1, noise=na)
     assert (plain - one).abs().max().item() <= 2e-5
 
 

@@ -359,3 +359,24 @@ def test_weight_blob_gives_the_packers_tensors_bit_for_bit(tmp_path, cfgname, mo
     monkeypatch.setenv("FH_WINO54", "0")
     assert weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(False)) is None
     assert "layout switches" in weights.WeightStore.why
+
+
+def test_plan_switches_are_read_when_the_model_is_built(monkeypatch):
+    """FH_WINO_SPLITK / FH_UPS_FUSE / FH_FUSE_TAIL / FH_AMP_FUSE_ACT / FH_AMP_INTERLEAVE shape launch plans (the first one also the
+    order of additions of short clips): a model takes them as they are when it is BUILT (Vocoder.sw) and plans with that
+    snapshot for its whole life, whatever the environment says later."""
+    for var in ("FH_WINO_SPLITK", "FH_UPS_FUSE", "FH_FUSE_TAIL", "FH_AMP_FUSE_ACT", "FH_AMP_INTERLEAVE"):
+        monkeypatch.delenv(var, raising=False)
+    voc = _cpu_vocoder("SYNTH_CFG")
+    assert voc.sw == dict(splitk=True, ups_fuse="1", amp_fuse_act=False, fuse_tail=False, amp_interleave=True)
+    kinds = [s_[0] for s_ in voc.plan(1, 50)["steps"]]
+    assert "sum" in kinds and "convt" in kinds and "tail" not in kinds and kinds.count("act") == 37
+    monkeypatch.setenv("FH_WINO_SPLITK", "0")
+    monkeypatch.setenv("FH_UPS_FUSE", "0")
+    monkeypatch.setenv("FH_FUSE_TAIL", "1")
+    monkeypatch.setenv("FH_AMP_FUSE_ACT", "1")
+    voc._plans.clear()
+    assert [s_[0] for s_ in voc.plan(1, 50)["steps"]] == kinds                 # the living model does not follow the environment
+    voc2 = _cpu_vocoder("SYNTH_CFG")
+    kinds2 = [s_[0] for s_ in voc2.plan(1, 50)["steps"]]
+    assert "sum" not in kinds2 and "convt" not in kinds2 and "tail" in kinds2 and kinds2.count("act") == 36 - 12
