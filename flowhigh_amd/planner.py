@@ -306,7 +306,8 @@ def amp_tile_list(lens, batch, dilation, interleave=None):
     length at any moment: with all tiles of the heaviest group first, every block of the chip ran the same K loop and then
     stored its outputs in the same microseconds (no stores for 10 us, then 138 MB at once: the epilogue's HBM traffic cost a
     quarter of the launch, tools/exp/amp_ab.sh).  A block still gets the same share of every group.  FH_AMP_INTERLEAVE=0: group
-    after group (heavy first)."""
+    after group (heavy first).  (Both orders, and a layout that deals the tiles to the blocks by weight, longest first, measure
+    the same to +-0.1 %: profiles/r05_amp_ablation.txt item 9.)"""
     if interleave is None:
         interleave = os.environ.get("FH_AMP_INTERLEAVE", "1") != "0"
     tb = amp_tile_len(dilation)
