@@ -7,13 +7,17 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libflowhigh_hip.so"
-SOURCES = ["api_common.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino54.hip", "amp_fused.hip", "act1d.hip", "gemm_mfma.hip", "flow_ops.hip",
+SOURCES = ["api_common.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino54.hip", "conv_wino54_bf.hip", "amp_fused.hip", "act1d.hip", "gemm_mfma.hip", "flow_ops.hip",
            "attention.hip", "frontend.hip", "fft.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-source extra flags.  The bf16 x 6 kernels keep everything beside their MFMAs one result per lane: the SLP vectoriser
+# would re-pack it into v_pk_*_f32, which stall a bf16 MFMA (conv_wino54_kernel.h)
+EXTRA_FLAGS = {"conv_wino54_bf.hip": ["-fno-slp-vectorize"]}
+HEADERS = ["fh_common.h", "conv_wino54_kernel.h"]
 
 
 def _deps():
-    return [CSRC / "fh_common.h", PKG.parent / "include" / "flowhigh_hip.h"]
+    return [CSRC / h for h in HEADERS] + [PKG.parent / "include" / "flowhigh_hip.h"]
 
 
 def needs_build():
@@ -37,7 +41,7 @@ def build(force=False, verbose=True):
         src = CSRC / s
         if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
             continue
-        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

@@ -57,15 +57,23 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {          // v_
   const bf16x2 v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(unsigned, v);
 }
+// Everything that runs beside the bf16 MFMAs is written one result per lane, and this file's BF instantiations are compiled
+// with -fno-slp-vectorize (conv_wino_bf.hip): at plain -O3 the SLP vectoriser re-packs adjacent scalar subtractions / FMAs into
+// v_pk_add_f32 / v_pk_fma_f32, which share the matrix cores' fp32 lanes -- each costs 11-13 cycles of a 32-cycle bf16 MFMA gap,
+// a plain instruction issues in the MFMA's shadow (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+__device__ __forceinline__ float bf_lo(unsigned p) {                       // the low bf16 of a pair as a float
+  return __uint_as_float(__builtin_amdgcn_perm(0u, p, 0x01000c0cu));
+}
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
   unsigned hp[4], mp[4], lp[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = v[2 * i], b = v[2 * i + 1];
     hp[i] = pack_bf16(a, b);
-    const float ra = a - __uint_as_float(hp[i] << 16), rb = b - __uint_as_float(hp[i] & 0xffff0000u);
+    // (low half -> float by v_perm_b32: from `hp << 16` the combiner makes a SECOND v_cvt_pk of (a, 0) and then the shift)
+    const float ra = a - bf_lo(hp[i]), rb = b - __uint_as_float(hp[i] & 0xffff0000u);
     mp[i] = pack_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(mp[i] << 16), sb = rb - __uint_as_float(mp[i] & 0xffff0000u);
+    const float sa = ra - bf_lo(mp[i]), sb = rb - __uint_as_float(mp[i] & 0xffff0000u);
     lp[i] = pack_bf16(sa, sb);
   }
   h = __builtin_bit_cast(bf16x8, (u32x4){hp[0], hp[1], hp[2], hp[3]});
@@ -463,11 +471,14 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
                 const int j = 3 * g + sh + o[r];
                 x[r] = *reinterpret_cast<const f32x2*>(xsb + ((j & 3) * W_P + (j >> 2)) * 2 + kp * W_RP2 + 128 * nt);
               }
-              const f32x2 pp = __builtin_elementwise_fma(c0, x[0], x[1]);
-              const f32x2 qq = __builtin_elementwise_fma(c1, x[2], x[3]);
-              const f32x2 t = __builtin_elementwise_fma(c2, qq, pp);
-              v[2 * kp] = t[0];
-              v[2 * kp + 1] = t[1];
+              // (one result per lane on purpose, see split8; same bits as the packed form of the fp32 kernel: every element
+              // is one fma chain)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const float pp = __builtin_fmaf(bc0, x[0][e], x[1][e]);
+                const float qq = __builtin_fmaf(bc1, x[2][e], x[3][e]);
+                v[2 * kp + e] = __builtin_fmaf(bc2, qq, pp);
+              }
             }
             bf16x8 bh, bm, bl;
             split8(v, bh, bm, bl);

@@ -147,6 +147,12 @@ def pack_wino_weight_any(w, cout_pad, bf):
     return split_bf3(u) if bf else u
 
 
+def pack_wino54_weight_any(w, cout_pad, bf):
+    """pack_wino54_weight, in the three-piece bf16 form when bf ([ci/16, G, 8, cout_pad, 3, 16] bf16 bit patterns)."""
+    u = pack_wino54_weight(w, cout_pad)
+    return split_bf3(u) if bf else u
+
+
 def wino_phase_weight(wt, taps):
     """ConvTranspose1d weight [cin, cout, k] + the taps [(j, offset)] of one output phase (transposed_conv_phases)
     -> (Conv1d-style weight [cout, cin, k_r] with taps ordered by input offset, center = -smallest offset)."""

@@ -109,7 +109,11 @@ _WINO_RUN = 8                      # W_RUN of conv_wino.hip
 # 2.47 / 1.72 / 1.34 / 1.08 / 2.43 us against 3.28 / 2.27 / 1.86 / 1.14 / 3.22): the matrix pipe needs 0.375 of the
 # cycles, but the B split (36 VALU instructions per 8 values), 1.5 x the weight bytes and the unchanged slab / transform
 # work keep the loop issue-bound (ablations: no weight loads -10 %, no split -10 %, neither and no slab -35 %)
-_WINO_BF_SPEED = {0: 0.75, 1: 0.76, 4: 0.72, 5: 0.94, 6: 0.75}
+_WINO_BF_SPEED = {0: 0.75, 1: 0.76, 4: 0.72, 5: 0.94, 6: 0.75,
+                  # F(5,4) bf16 x 6 blocks (round 6; 96- and 64-row blocks: the 128-row one spills): tools/wino54_cost_fit.py ... bf
+                  WINO_F54 | 0: 0.62, WINO_F54 | 1: 0.62, WINO_F54 | 2: 0.66}
+# F(5,4) tiles that have a bf16 x 6 form the planner may pick
+_WINO54_BF_TILES = (WINO_F54 | 1, WINO_F54 | 2)
 
 
 def wino_n_tiles(cfg, length, dil, pm):
@@ -132,7 +136,7 @@ def wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, cus_per_xcd=32, bf=F
     bm, bt = _WINO_TILES[cfg]
     a, b = _WINO_COST[cfg]
     if bf:
-        a *= _WINO_BF_SPEED[cfg]              # (the F(5,4) kernel has no bf16 x 6 form: never asked for)
+        a *= _WINO_BF_SPEED[cfg]
     n_tiles = wino_n_tiles(cfg, length, dil, dil > 1)       # (dilated Winograd launches of the model are phase-major)
     cot = wpad // bm
     panel_w = [a * k + b for k in ksteps for _ in range(batch * cot)]
@@ -173,7 +177,8 @@ def _choose_wino_cfg(ksteps, batch, wpad, length, dil, default, bf=False):
     # weights it alone divides, never an alternative to the 96-row block)
     cands = [cfg for cfg, (bm, _) in _WINO_TILES.items()
              if wpad % bm == 0 and cfg not in _WINO_TILES_OFF and (cfg & WINO_F54) == fam
-             and not (cfg == WINO_F54 | 3 and wpad % 96 == 0)]
+             and not (cfg == WINO_F54 | 3 and wpad % 96 == 0)
+             and not (bf and fam and cfg not in _WINO54_BF_TILES)]
     cost = {cfg: wino_launch_cost(ksteps, batch, wpad, length, dil, cfg, bf=bf) for cfg in cands}
     best = min(cands, key=lambda cfg: cost[cfg])
     if default in cost and cost[best] > 0.97 * cost[default]:
@@ -190,9 +195,11 @@ def pick_wino_tile(c):
     return 0, -(-c // WINO_BM) * WINO_BM
 
 
-def pick_wino54_tile(c):
+def pick_wino54_tile(c, bf=False):
     """(plan tile id, cout_pad) of the F(5,4) kernel: 128-row blocks where they divide c, else 96, else 48 (three 16-row MFMA
-    tiles), else 64 (padded)."""
+    tiles), else 64 (padded).  bf (the bf16 x 6 form): 96-row blocks where they divide c, else 64 (padded)."""
+    if bf:
+        return (WINO_F54 | 1, c) if c % 96 == 0 else (WINO_F54 | 2, -(-c // 64) * 64)
     if c % 128 == 0:
         return WINO_F54 | 0, c
     if c % 96 == 0:

@@ -29,7 +29,7 @@ def conv_wino(groups, batch, cout_pad, length, dilation, device, tile_cfg=0, pha
         if any(g.out_stride > 1 or g.out_len or g.seg[i].ngrp > 3 or g.seg[i].xlen for g in groups for i in range(g.nseg)):
             raise NotImplementedError("the F(5,4) kernel takes plain convs of at most 12 taps (no strided outputs, xlen, out_len)")
         hip.check(hip.lib().fh_conv_wino54_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
-                                               int(phase_major), tile_cfg & 15, hip.stream()), "fh_conv_wino54_f32")
+                                               int(phase_major), tile_cfg & 31, hip.stream()), "fh_conv_wino54_f32")
         return d
     hip.check(hip.lib().fh_conv_wino_f32(d.data_ptr(), len(groups), batch, cout_pad, length, dilation,
                                          int(phase_major), tile_cfg, hip.stream()), "fh_conv_wino_f32")
@@ -228,7 +228,7 @@ def launch_step(voc, s, B, st):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if wcfg & WINO_F54:
-            hip.check(L.fh_conv_wino54_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, wcfg & 15, st), "fh_conv_wino54_f32")
+            hip.check(L.fh_conv_wino54_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, (wcfg & 15) | voc.wino_flag, st), "fh_conv_wino54_f32")
         else:
             hip.check(L.fh_conv_wino_f32(d.data_ptr(), ng, bb, wpad, length, dil, pm, wcfg | voc.wino_flag, st), "fh_conv_wino_f32")
         if timing is not None:
@@ -295,7 +295,7 @@ def run_ragged_steps(voc, rp):
         if s[0] == "rwino":
             _, off, ng, wpad, maxlen, dil, wcfg, pmflag, off_map, n_runs = s
             if wcfg & WINO_F54:
-                hip.check(L.fh_conv_wino54_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, wcfg & 15, base + off_map,
+                hip.check(L.fh_conv_wino54_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, (wcfg & 15) | voc.wino_flag, base + off_map,
                                                       n_runs, st), "fh_conv_wino54_ragged_f32")
             else:
                 hip.check(L.fh_conv_wino_ragged_f32(base + off, ng, wpad, maxlen, dil, pmflag, wcfg | voc.wino_flag,

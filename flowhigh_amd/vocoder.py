@@ -25,7 +25,7 @@ import torch
 from . import hip
 from .packing import (  # noqa: F401
     _WINO54_G, _WINO_G, fold_weight_norm, from_phase_major, pack_amp_weight, pack_conv_weight,
-    pack_wino54_weight, pack_wino_weight, pack_wino_weight_any, phase_len, pick_ck, split_bf3, to_phase_major,
+    pack_wino54_weight, pack_wino54_weight_any, pack_wino_weight, pack_wino_weight_any, phase_len, pick_ck, split_bf3, to_phase_major,
     transposed_conv_extra, transposed_conv_phases, wino_phase_weight)
 from .planner import (  # noqa: F401
     AMP_MAX_D, WINO54_MIN_C, WINO_BF16X6, WINO_BM, WINO_F54, WINO_MAX_K, WINO_MIN_C, WINO_NARROW, WINO_NOVL,
@@ -176,15 +176,16 @@ class Vocoder:
                 if not (wino_k and use_wino(c, 1)) and (kk > hip.CONV_MAX_TAPS or (kk - 1) * max(dl) > hip.CONV_MAX_HALO):
                     raise NotImplementedError(f"resblock kernel {kk} x dilation {max(dl)} exceeds the direct kernel's "
                                               f"{hip.CONV_MAX_TAPS} taps / {hip.CONV_MAX_HALO} samples of reach")
-            # residual stack: F(5,4) kernel from WINO54_MIN_C channels on (not in the bf16 x 6 form), else F(4,3); the
+            # residual stack: F(5,4) kernel from WINO54_MIN_C channels on, else F(4,3); the
             # transposed conv's phase groups always run in the F(4,3) kernel (strided outputs)
             st["up_wcfg"], st["up_wpad"] = pick_wino_tile(c)
-            st["w54"] = use_wino54(c) and not self.bf and max(self.ks) <= WINO_MAX_K
-            st["wcfg"], st["wpad"] = pick_wino54_tile(c) if st["w54"] else (st["up_wcfg"], st["up_wpad"])
+            st["w54"] = use_wino54(c) and max(self.ks) <= WINO_MAX_K
+            st["wcfg"], st["wpad"] = pick_wino54_tile(c, self.bf) if st["w54"] else (st["up_wcfg"], st["up_wpad"])
             st["taps"] = 4 if st["w54"] else 3
             # narrow stages (<= 48 channels): the residual-stack convs run on the narrow-stage kernel (planner.use_amp)
-            st["amp"] = use_amp(c, self.ks, self.dil) and not self.bf
-            pack_res = (lambda w_: pack_wino54_weight(w_, st["wpad"])) if st["w54"] else \
+            # (also in the bf16 x 6 form, which has no narrow-stage kernel of its own: those stages keep the fp32 one)
+            st["amp"] = use_amp(c, self.ks, self.dil)
+            pack_res = (lambda w_: pack_wino54_weight_any(w_, st["wpad"], self.bf)) if st["w54"] else \
                 (lambda w_: pack_wino_weight_any(w_, st["wpad"], self.bf))
             wt = lambda i=i: g(f"ups.{i}.0.weight")               # [cin, c, k]
             st["up_b"] = W.dev(f"v.ups.{i}.b", lambda: g(f"ups.{i}.0.bias"))

@@ -285,6 +285,43 @@ def test_conv_wino_bf16x6_fuzz():
     assert "FAIL" not in r.stdout and "150 cases (bf16 x 6)" in r.stdout, r.stdout[-2000:]
 
 
+def test_conv_wino54_bf16x6_fuzz():
+    """tests/tools/wino_fuzz.py f54bf: the F(5,4) kernel in the three-piece bf16 form (round 6), 128 / 96 / 64-row blocks, both
+    layouts and loaders, residuals, K segments, against float64 at the fp32-MFMA F(5,4) form's tolerance."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tests" / "tools" / "wino_fuzz.py"), "150", "7", "f54bf"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "FAIL" not in r.stdout and "150 cases (F(5,4) bf16 x 6)" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("k,d,L,pm", [(11, 1, 1000, False), (7, 3, 777, True), (3, 1, 2049, False), (7, 1, 1203, False)])
+def test_conv_wino54_bf16x6_tile_heights_give_the_same_bits_and_the_fp32_forms_values(k, d, L, pm):
+    """The bf16 x 6 form of the F(5,4) kernel: 128-, 96- and 64-row blocks give the same bits (a block's rows do not change a
+    row's arithmetic), and the result is the fp32-MFMA form's up to rounding (same transform bits, fp32-grade products)."""
+    c, B = 384, 2
+    x, w, b = rnd(B, c, L, seed=200), rnd(c, c, k, seed=201, scale=1.0 / (c * k) ** 0.5), rnd(c, seed=202)
+    xd = (V.to_phase_major(x, d) if pm else x).to(DEV)
+    u = V.pack_wino54_weight(w, c)
+    ud, u3, bd = u.to(DEV), V.split_bf3(u).to(DEV), b.to(DEV)
+    outs = []
+    for cfg, uu in ((V.WINO_F54 | 1, ud), (V.WINO_F54 | 0 | V.WINO_BF16X6, u3), (V.WINO_F54 | 1 | V.WINO_BF16X6, u3),
+                    (V.WINO_F54 | 2 | V.WINO_BF16X6, u3)):
+        out = torch.full_like(xd, float("nan"))
+        g = V.make_wino_group([V.make_wino_seg(xd, uu, c, k, taps=4)], bd, [], out, c, c, L)
+        keep = V.conv_wino([g], B, c, L, d, DEV, cfg, phase_major=pm)
+        torch.cuda.synchronize()
+        outs.append(V.from_phase_major(out.cpu(), d, L) if pm else out.cpu())
+        del keep
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[2], outs[3])
+    ref = F.conv1d(x.double(), w.double(), b.double(), dilation=d, padding=(k - 1) // 2 * d).float()
+    assert maxdiff(outs[2], ref) <= 6e-5          # (the fp32 form's bound in test_conv_wino54_every_tile_height_gives_the_same_bits)
+    assert maxdiff(outs[2], outs[0]) <= 6e-5      # |out| ~ 4, K = 384 x 11: both forms round the same products, in different places (4.2e-5 seen)
+
+
 def test_split_bf3_is_exact():
     """x = h + m + l exactly (the weights' three bf16 pieces; the kernel splits the activations the same way)."""
     x = rnd(4096, 16, seed=99, scale=1.0) * torch.exp(rnd(4096, 16, seed=98, scale=3.0))

@@ -1,15 +1,16 @@
 """Randomised check of fh_conv_wino_f32 (all tiles, layouts, dilations, residuals, ragged lengths) against
-float64 F.conv1d.  python tests/tools/wino_fuzz.py [n_cases] [seed] [bf | f54]
+float64 F.conv1d.  python tests/tools/wino_fuzz.py [n_cases] [seed] [bf | f54 | f54bf]
 bf: the three-piece bf16 form (tile_cfg | FH_WINO_BF16X6, weights split by vocoder.split_bf3), same tolerance.
-f54: fh_conv_wino54_f32 (the F(5,4) kernel: groups of 4 taps, 128 / 96 / 64-row tiles), same tolerance."""
+f54: fh_conv_wino54_f32 (the F(5,4) kernel: groups of 4 taps, 128 / 96 / 64-row tiles), same tolerance.
+f54bf: the F(5,4) kernel in the three-piece bf16 form (round 6: 128 / 96 / 64-row tiles), the F(5,4) tolerance."""
 import sys, random, torch, torch.nn.functional as F
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, vocoder as V
 DEV = torch.device('cuda:0')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-BF = len(sys.argv) > 3 and sys.argv[3] == "bf"
-F54 = len(sys.argv) > 3 and sys.argv[3] == "f54"
+BF = len(sys.argv) > 3 and sys.argv[3] in ("bf", "f54bf")
+F54 = len(sys.argv) > 3 and sys.argv[3] in ("f54", "f54bf")
 worst = 0.0
 for case in range(n_cases):
     c = rng.choice([16, 32, 48, 64, 96, 128, 192] + ([256, 384, 48, 144] if F54 else []))
@@ -29,10 +30,10 @@ for case in range(n_cases):
     scale = rng.choice([1.0, 0.5, 1.0 / 3])
     ref = sum(F.conv1d(x.double(), w.double(), None, dilation=d, padding=(kk - 1) // 2 * d) for x, w, kk in zip(xs, ws, ks))
     ref = ((ref + bias.double().view(1, -1, 1) + sum(r.double() for r in res)) * scale).float()
-    wcfg, cpad = V.pick_wino54_tile(c) if F54 else V.pick_wino_tile(c)
+    wcfg, cpad = V.pick_wino54_tile(c, BF) if F54 else V.pick_wino_tile(c)
     if F54 and rng.random() < 0.3:                                  # (any tile height that divides cout_pad)
         wcfg = rng.choice([t for t in (V.WINO_F54, V.WINO_F54 | 1, V.WINO_F54 | 2, V.WINO_F54 | 3) if cpad % V._WINO_TILES[t][0] == 0
-                           and not (t == V.WINO_F54 | 3 and cpad % 96 == 0)])      # (the 48-row block: only where no 96-row block fits)
+                           and not (t == V.WINO_F54 | 3 and (cpad % 96 == 0 or BF))])      # (the 48-row block: only where no 96-row block fits; no bf16 x 6 form)
     if wcfg == 0 and rng.random() < 0.3:
         wcfg = rng.choice([4, 5, 6] if cpad % 128 == 0 else [4, 5])
     pack = V.pack_wino54_weight if F54 else V.pack_wino_weight
@@ -59,4 +60,4 @@ for case in range(n_cases):
     ok = err <= tol and bool(torch.isfinite(got).all())
     if not ok:
         print(f"FAIL case {case}: c={c} ks={ks} d={d} B={B} L={L} pm={pm} nres={nres} cfg={wcfg} err={err}")
-print(f"{n_cases} cases{' (bf16 x 6)' if BF else ' (F(5,4))' if F54 else ''}, worst error {worst:.2e}")
+print(f"{n_cases} cases{' (F(5,4) bf16 x 6)' if BF and F54 else ' (bf16 x 6)' if BF else ' (F(5,4))' if F54 else ''}, worst error {worst:.2e}")
