@@ -76,13 +76,55 @@ def cpu_baseline(sd, cfg, sr_in):
                       f"threads of {avail} visible host CPUs"}
 
 
-def alt_bf16x6(sd, cfg, dev, sr_in, x, z, out_fp32, B, n_frames, steps):
-    """NOT the headline: the same workload with the vocoder's Winograd convs in the opt-in bf16 x 6 form
-    (FLowHigh(..., conv_bf16x6=True): every fp32 operand split exactly into three bf16 pieces, six
-    v_mfma_f32_32x32x16_bf16 per 16-channel k-block, fp32 accumulation -- fp32-grade products on the BF16 matrix
-    cores).  Reported next to the fp32-MFMA headline with its distance from that form's waveform."""
+DTYPE_BY_FORM = {
+    "winograd": "f32",
+    "direct": "f32",
+    "bf16x6": "f32 in / out / accumulate; the wide-stage Winograd convs' products as 6 bf16 MFMAs over exact 3-piece splits "
+              "(conv_form='bf16x6': fp32-grade, dropped terms <= 2^-24 |a b|); everything else fp32 arithmetic",
+}
+KERNEL_BY_FAMILY = {
+    "wino54": "conv_wino54_kernel (Winograd F(5,4) wide-stage conv, v_mfma_f32_32x32x2_f32)",
+    "wino54_bf16x6": "conv_wino54_kernel<BF> (Winograd F(5,4) wide-stage conv, 6 x v_mfma_f32_32x32x16_bf16 per fp32 k-block)",
+    "wino43": "conv_wino_kernel (Winograd F(4,3): conv_pre, first two upsamplers, v_mfma_f32_32x32x2_f32)",
+    "wino43_bf16x6": "conv_wino_kernel<BF> (Winograd F(4,3): conv_pre, first two upsamplers, bf16 x 6)",
+    "amp": "amp_actconv_kernel (narrow-stage Winograd F(5,4) conv, v_mfma_f32_16x16x4_f32)",
+    "direct": "conv_mfma_kernel (direct implicit-GEMM conv: last four upsamplers, v_mfma_f32_32x32x2_f32)",
+}
+PEAK_BY_FAMILY = {"wino54_bf16x6": 2500.0, "wino43_bf16x6": 2500.0}      # dense bf16 MFMA; every other family: the fp32 MFMA peak
+
+
+def family_split(conv_ev, launches, timed_steps):
+    """roofline.by_family: the conv launches of the sampled steps by kernel family (the plan tags every launch: planner.conv_launches),
+    each with launches per step, ms per step, executed GFLOP per step, TFLOP/s on its own matrix instructions and the fraction of
+    THAT pipe's dense peak (bf16 x 6 families: 6 bf16 MFMA FLOPs per executed fp32-equivalent FLOP against 2.5 PFLOP/s)."""
+    fam = {}
+    n = len(launches)
+    for i, (a, b) in enumerate(conv_ev):
+        name, ex, alg = launches[i % n]
+        f = fam.setdefault(name, dict(launches=0, ms=0.0, executed=0.0, algorithmic=0.0))
+        f["launches"] += 1
+        f["ms"] += a.elapsed_time(b)
+        f["executed"] += ex
+        f["algorithmic"] += alg
+    out = {}
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        bf = name.endswith("_bf16x6")
+        issued = f["executed"] * (6.0 if bf else 1.0)
+        peak = PEAK_BY_FAMILY.get(name, PEAK_FP32_MFMA_TFLOPS)
+        tf = issued / (f["ms"] / 1e3) / 1e12 if f["ms"] > 0 else 0.0
+        out[name] = {"launches_per_step": f["launches"] // max(timed_steps, 1), "ms_per_step": round(f["ms"] / max(timed_steps, 1), 3),
+                     "executed_gflop_per_step": round(f["executed"] / max(timed_steps, 1) / 1e9, 1),
+                     "algorithmic_gflop_per_step": round(f["algorithmic"] / max(timed_steps, 1) / 1e9, 1),
+                     "matrix_tflops": round(tf, 1), "matrix_instructions": "bf16 (6 per fp32 product)" if bf else "fp32",
+                     "peak": peak, "frac": round(tf / peak, 4)}
+    return out
+
+
+def alt_form(form, sd, cfg, dev, sr_in, x, z, out_main, B, n_frames, steps):
+    """NOT the headline: the same workload with the vocoder's convs in another arithmetic form (FLowHigh(..., conv_form=form)),
+    reported next to the headline with its distance from the headline form's waveform."""
     from flowhigh_amd import FLowHigh, FlowHighSR
-    model = FlowHighSR(FLowHigh(sd, cfg, dev, conv_bf16x6=True), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
+    model = FlowHighSR(FLowHigh(sd, cfg, dev, conv_form=form), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
     voc = model.flowhigh.vocoder
     for _ in range(3):
         out = model.generate_from_device(x, sr_in, STEPS_ODE, noise=z)
@@ -98,17 +140,11 @@ def alt_bf16x6(sd, cfg, dev, sr_in, x, z, out_fp32, B, n_frames, steps):
     voc.conv_timing = None
     conv_ms = sum(a.elapsed_time(b) for a, b in conv_ev) / max(timed, 1)
     plan = voc.plan(B, n_frames)
-    # matrix-core FLOPs actually issued: 6 bf16 MFMAs per fp32 k-block in the Winograd launches, fp32 MFMAs in the rest
-    bf16_tflops = 6.0 * (plan["conv_executed_flops"] - plan["conv_direct_flops"]) / (conv_ms / 1e3) / 1e12 if conv_ms > 0 else 0.0
-    return {"value": round(B * SECS / dt, 3), "unit": "audio-seconds/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
-            "conv_ms_per_step": round(conv_ms, 3),
-            "dtype": "f32 in / out / accumulate; Winograd-conv products as 6 bf16 MFMAs over exact 3-piece splits",
-            "max_abs_diff_vs_fp32_mfma_waveform": float((out - out_fp32).abs().max().item()),
-            "fp32_equivalent_tflops_executed": round(plan["conv_executed_flops"] / (conv_ms / 1e3) / 1e12, 2) if conv_ms > 0 else 0.0,
-            "bf16_mfma_tflops_issued": round(bf16_tflops, 1), "bf16_peak": 2500.0,
-            "bf16_frac": round(bf16_tflops / 2500.0, 4),
-            "note": "opt-in (conv_bf16x6=True / FH_CONV_BF16X6=1), not the headline; bf16_frac = bf16 MFMA FLOPs of the "
-                    "Winograd launches / time of ALL conv launches (the direct-kernel ones stay fp32 MFMA) / 2.5 PFLOP/s"}
+    return {"conv_form": form, "value": round(B * SECS / dt, 3), "unit": "audio-seconds/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "conv_ms_per_step": round(conv_ms, 3), "act_blocks_per_cu": voc.act_blocks, "dtype": DTYPE_BY_FORM[form],
+            "max_abs_diff_vs_headline_waveform": float((out - out_main).abs().max().item()),
+            "by_family": family_split(conv_ev, plan["conv_launches"], timed),
+            "note": f"the same workload with conv_form='{form}' (FlowHighSR.from_local(..., conv_form=); INTEGRATION.md section 1); not the headline"}
 
 
 def visible_gpus():
@@ -155,7 +191,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 1 for --config 2, 32 for --config 4)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the opt-in bf16 x 6 conv form's side measurement")
+    ap.add_argument("--no-alt", action="store_true", help="skip the side measurement of the other conv form (fp32-MFMA Winograd next to a bf16 x 6 headline, or the reverse)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("FH_BENCH_GRAPH", "0")),
                     help="1: a step replays the HIP graph of generate_from_device (same launches, one enqueue)")
     args = ap.parse_args()
@@ -184,12 +220,16 @@ def main():
     # (flowhigh_amd/weights.py; on the CPU: float64 Winograd transforms of 118 M parameters), every rank maps that ONE file
     # and uploads it with one copy.  pack_s / load_s go into the line's config.
     from flowhigh_amd import convert, weights
+    from flowhigh_amd.planner import resolve_conv_form
+    # the arithmetic form of the vocoder's convs: what a deployment gets by default (conv_form='auto' resolves to it; FH_CONV_FORM
+    # overrides).  No load-time probe here: the blob path has no checkpoint at hand, and the bench names its form in the line.
+    form = resolve_conv_form()[0]
     blob = Path(os.environ.get("FH_BENCH_BLOB", f"/tmp/flowhigh_amd_bench_{os.getuid()}.blob"))
     pack_s = None
     if rank == 0:
         t0 = time.perf_counter()
-        store = convert.build_store(sd, cfg)
-        store.save(blob, cfg, weights.format_tag(False), {})
+        store = convert.build_store(sd, cfg, conv_form=form)
+        store.save(blob, cfg, weights.format_tag(form), {})
         del store
         pack_s = time.perf_counter() - t0
     if dist is not None:
@@ -197,16 +237,18 @@ def main():
         # one activation-occupancy setting for the node, measured by rank 0 while the others wait (an explicit collective:
         # the model constructors never communicate)
         from flowhigh_amd import vocoder as _voc
-        _voc.sync_act_blocks(dev)
+        _voc.sync_act_blocks(dev, bf=form == "bf16x6")
     t0 = time.perf_counter()
-    store = weights.WeightStore.open(blob, dev, expect_format=weights.format_tag(False))
+    store = weights.WeightStore.open(blob, dev, expect_format=weights.format_tag(form))
     if store is None:
         raise SystemExit(f"bench.py: weight blob {blob} not usable: {weights.WeightStore.why}")
-    model = FlowHighSR(FLowHigh(None, cfg, dev, store=store), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
+    model = FlowHighSR(FLowHigh(None, cfg, dev, store=store, conv_form=form), torchdiffeq_ode_method=METHOD, upsampling_method="hip")
     torch.cuda.synchronize()
     load_s = time.perf_counter() - t0
     blob_mib = blob.stat().st_size / 2 ** 20
     act_blocks = model.flowhigh.vocoder.act_blocks
+    from flowhigh_amd import vocoder as _vocmod
+    act_table = _vocmod.calibrate_act_occupancy.last_measurement        # [{cap: pair us}] per pass, None when the setting was given
     B = args.batch if args.batch is not None else conf["per_gpu"]
     n_frames = int(SECS * 100)
     n_in, t48 = int(SECS * sr_in), int(SECS * 48000)
@@ -287,6 +329,8 @@ def main():
     act_bytes_per_launch = plan["act_bytes"] * timed_steps / max(n_act, 1)
     act_gbs = act_bytes_per_launch / act_s / 1e9 if act_s > 0 else 0.0
 
+    fams = family_split(conv_ev, plan["conv_launches"], timed_steps)
+    dom = next(iter(fams)) if fams else None
     line = None
     if rank == 0:
         from tools.make_traffic_json import source_fingerprint
@@ -316,7 +360,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "hip_graph": bool(args.graph and not conf["sharded"]),
+            "dtype": DTYPE_BY_FORM[form], "data": "synthetic", "hip_graph": bool(args.graph and not conf["sharded"]),
             "config": {"workload": f"{conf['name']}: B={B} per GPU x 10 s clip, {sr_in // 1000}->48 kHz, time_step=1 euler, "
                                    "transformer 2x16x64, BigVGAN-48k-256band SYNTH-CFG (rates 5,4,3,2,2,2; C0 1536), "
                                    "random-init weights",
@@ -324,29 +368,41 @@ def main():
                        "parallelism": (f"{n_clips} clips on rank 0, RCCL P2P scatter -> generate -> gather, x{world}"
                                        if conf["sharded"] else f"clip-sharded x{world}, no data-path collective"),
                        "rccl_world_size": world if dist is not None else None,
+                       "conv_form": form,
                        "act_blocks_per_cu": act_blocks,       # 0 = no cap; vocoder.calibrate_act_occupancy (same bits either way)
+                       # what the calibration measured at load: per pass {cap: us of an (activation, conv) launch pair}
+                       "act_calibration_pair_us": act_table,
                        # model construction from the packed weight blob (map + one H2D copy + the activation-occupancy
                        # calibration launches), and what packing it from the state dict took on this host (once, rank 0)
                        "load_s": round(load_s, 3), "pack_s": round(pack_s, 2), "blob_mib": round(blob_mib, 1),
                        "sharded_check": None},
             "roofline": {"bound": "mfma",
-                         "kernel": "conv_wino54_kernel + amp_actconv_kernel + conv_wino_kernel + conv_mfma_kernel (all conv launches of BigVGAN: 97 % of the path's FLOPs)",
-                         "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                         # the dominant kernel family of the step (most conv time; by_family has all of them)
+                         "kernel": KERNEL_BY_FAMILY[dom],
+                         "achieved": fams[dom]["matrix_tflops"], "peak": fams[dom]["peak"], "unit": "TFLOP/s",
+                         "frac": fams[dom]["frac"],
+                         "launches_per_step": fams[dom]["launches_per_step"],
+                         "avg_launch_us": round(fams[dom]["ms_per_step"] * 1e3 / max(fams[dom]["launches_per_step"], 1), 2),
                          "traffic": pmc("conv_hbm_bytes_per_launch.json"),
                          "traffic_source": "profiles/conv_hbm_bytes_per_launch.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                            "passes of an earlier run of this command (tools/profile_round.sh), NOT measured "
-                                           f"by this run; bytes per conv launch at B = {B}; null when that file was measured on "
-                                           "other kernel / planner sources (traffic_stale says so)",
-                         "note": "achieved = FLOPs issued to the matrix cores (Winograd launches: F(5,4) 1.6 ceil(k/4), F(4,3) 1.5 ceil(k/3) MACs per "
-                                 "output and channel pair instead of k) / HIP-event time of the conv launches; "
-                                 "algorithmic_equiv = direct-form FLOPs of the same convs (SURVEY.md 8d) / the same time",
-                         "algorithmic_equiv": round(alg_equiv, 2),
-                         "algorithmic_equiv_frac": round(alg_equiv / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "launches_per_step": n_conv // max(timed_steps, 1),
-                         "avg_launch_us": round(conv_s * 1e6, 2),
-                         "executed_gflop_per_launch": round(exec_per_launch / 1e9, 3),
-                         "algorithmic_gflop_per_launch": round(alg_per_launch / 1e9, 3),
+                                           f"by this run; bytes per conv launch (all families) at B = {B}; null when that file was "
+                                           "measured on other kernel / planner sources (traffic_stale says so)",
+                         "note": "achieved = FLOPs the dominant family issues to ITS matrix instructions (Winograd F(5,4): 1.6 ceil(k/4) MACs per "
+                                 "output and channel pair instead of k; bf16 x 6: six bf16 MFMA FLOPs per such fp32-equivalent FLOP, against the "
+                                 "dense bf16 peak) / HIP-event time of that family's launches, measured live in this run; by_family: every "
+                                 "conv kernel family the same way; all_conv: every conv launch together in fp32-equivalent executed FLOPs "
+                                 "against the fp32 MFMA peak (the line's `frac` until round 5), algorithmic_equiv = direct-form FLOPs of the "
+                                 "same convs (SURVEY.md 8d) / the same time",
+                         "by_family": fams,
+                         "all_conv": {"executed_fp32_equiv_tflops": round(executed, 2), "peak_fp32_mfma": PEAK_FP32_MFMA_TFLOPS,
+                                      "frac_of_fp32_mfma_peak": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                                      "algorithmic_equiv": round(alg_equiv, 2),
+                                      "algorithmic_equiv_frac": round(alg_equiv / PEAK_FP32_MFMA_TFLOPS, 4),
+                                      "launches_per_step": n_conv // max(timed_steps, 1),
+                                      "avg_launch_us": round(conv_s * 1e6, 2),
+                                      "executed_gflop_per_launch": round(exec_per_launch / 1e9, 3),
+                                      "algorithmic_gflop_per_launch": round(alg_per_launch / 1e9, 3)},
                          "conv_ms_per_step": round(conv_ms / max(timed_steps, 1), 3)},
             "roofline_hbm": {"bound": "hbm",
                              "kernel": "act1d_strip_kernel (all Activation1d launches: up2x -> Snake(Beta) -> down2x)",
@@ -366,7 +422,8 @@ def main():
             if name in stale:
                 line[key]["traffic_stale"] = stale[name]
         if not args.no_alt and world == 1 and args.config == 2:
-            line["alt_conv_bf16x6"] = alt_bf16x6(sd, cfg, dev, sr_in, x, z, out, B, n_frames, max(10, args.steps // 2))
+            other = "winograd" if form == "bf16x6" else "bf16x6"
+            line["alt_conv_form"] = alt_form(other, sd, cfg, dev, sr_in, x, z, out, B, n_frames, max(10, args.steps // 2))
         if not args.no_cpu_baseline and world == 1 and args.config == 2:
             line["cpu_baseline"] = cpu_baseline(sd, cfg, sr_in)
         else:

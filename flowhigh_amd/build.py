@@ -1,5 +1,6 @@
 """Build libflowhigh_hip.so (gfx950) in-tree with hipcc.  `python -m flowhigh_amd.build`."""
 import os
+import re
 import subprocess
 import sys
 from pathlib import Path
@@ -12,7 +13,12 @@ SOURCES = ["api_common.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino54.hip"
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-source extra flags.  The bf16 x 6 kernels keep everything beside their MFMAs one result per lane: the SLP vectoriser
 # would re-pack it into v_pk_*_f32, which stall a bf16 MFMA (conv_wino54_kernel.h)
-EXTRA_FLAGS = {"conv_wino54_bf.hip": ["-fno-slp-vectorize"]}
+# (conv_wino.hip as a whole: its bf16 x 6 instantiations need it for the same reason, and without it the 128 x 256 one spills)
+EXTRA_FLAGS = {"conv_wino54_bf.hip": ["-fno-slp-vectorize"], "conv_wino.hip": ["-fno-slp-vectorize"]}
+# every kernel's resources are read from the compiler's remarks: a kernel that needs scratch (spilled registers) fails the build.
+# The conv kernels place their waits by counting the loads in flight and fill every register they are given; the two times a
+# variant spilled in round 6 (F(5,4) bf16 x 6 with the 4-byte loader, F(4,3) bf16 x 6 at 128 x 256) its results were wrong.
+RESOURCE_FLAGS = ["-Rpass-analysis=kernel-resource-usage"]
 HEADERS = ["fh_common.h", "conv_wino54_kernel.h"]
 
 
@@ -25,6 +31,21 @@ def needs_build():
         return True
     t = LIB.stat().st_mtime
     return any(d.stat().st_mtime > t for d in [CSRC / s for s in SOURCES] + _deps())
+
+
+def parse_resource_remarks(stderr_text):
+    """{kernel name: {field: int}} from hipcc's -Rpass-analysis=kernel-resource-usage remarks."""
+    import re
+    kernels, cur = {}, None
+    for ln in stderr_text.splitlines():
+        m = re.search(r"remark: (?:[^:]*: )?Function Name: (\S+)", ln)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark: (?:[^:]*: )?\s*([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", ln)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return kernels
 
 
 def build(force=False, verbose=True):
@@ -41,13 +62,38 @@ def build(force=False, verbose=True):
         src = CSRC / s
         if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
             continue
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), *RESOURCE_FLAGS, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
-        if p.wait() != 0:
+        procs.append((s, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    spilled = []
+    for s, obj, p in procs:
+        err = p.communicate()[1]
+        # the resource remarks are read, everything else the compiler said is passed on
+        kernels = parse_resource_remarks(err)
+        rest, in_remark = [], False
+        lines = err.splitlines()
+        for n, ln in enumerate(lines):               # (a remark = its header line + the source line and caret clang prints under it)
+            if ln.startswith("In file included from") and n + 1 < len(lines) and "remark:" in lines[n + 1]:
+                continue
+            if "remark:" in ln:
+                in_remark = True
+                continue
+            if in_remark and (re.match(r"\s*\d*\s*\|", ln) or ln.startswith("In file included from") or not ln.strip()):
+                continue
+            in_remark = False
+            rest.append(ln)
+        rest = [ln for ln in rest if not re.match(r"\d+ warnings? generated", ln) or any("warning:" in r_ for r_ in rest)]
+        if verbose and any(ln.strip() for ln in rest):
+            print("\n".join(rest), file=sys.stderr, flush=True)
+        if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}")
+        bad = [(k, r) for k, r in kernels.items() if r.get("ScratchSize", 0) > 0]
+        if bad:
+            obj.unlink(missing_ok=True)
+            spilled += [f"{s}: {k} needs {r['ScratchSize']} bytes of scratch per lane ({r.get('VGPRs Spill', '?')} VGPRs spilled)" for k, r in bad]
+    if spilled:
+        raise RuntimeError("kernels that spill registers are not built (their results cannot be trusted):\n  " + "\n  ".join(spilled))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(objdir / (s + ".o")) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -443,172 +443,6 @@ __global__ __launch_bounds__(256) void act1d_strip_kernel(const fh_act_group* __
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// The tail of the generator in one launch: x = activation_post(x); x = conv_post(x); x = tanh(x)
-// (/root/reference/src/flowhigh/models/bigvgan/models.py:189-192).  A block owns 1008 output samples of one clip and walks
-// the C channels: per channel the strip kernel's three phases (same expressions, same order: the activated samples have the
-// bits fh_act1d_grouped_f32 gives) on the tile's 1016 samples, which then stay in LDS; the 7 taps of conv_post are added in
-// the order of conv_post_tanh_vec_kernel (channel outer, tap inner, fmaf), so the waveform has the bits of the two launches
-// it replaces.  The next channel's samples are requested while this one computes.  Saves the [B, C, L] round trip (2 x 46 MB
-// per 10 s clip) and a launch.
-constexpr int POST_TT = ACT_TT - 8;            // conv_post outputs per tile (3 taps of reach each side, rounded to the alignment)
-
-template <bool UNUSED = false>
-__global__ __launch_bounds__(256) void act_post_conv_tanh_kernel(const float* __restrict__ x, const float* __restrict__ alpha_p,
-                                                                 const float* __restrict__ inv_beta_p, const float* __restrict__ taps_g,
-                                                                 const float* __restrict__ w, const float* __restrict__ bias,
-                                                                 float* __restrict__ out, int channels, int len) {
-  static_assert(ACT_THREADS == 256 && ACT_PPT == 4, "written for 256 threads x 4 outputs");
-  __shared__ __attribute__((aligned(16))) float xs[ACT_PAIRS + 16];
-  __shared__ __attribute__((aligned(16))) float zs[2 * ACT_PAIRS + 16];
-  __shared__ __attribute__((aligned(16))) float ys[ACT_PAIRS + 16];
-  __shared__ __attribute__((aligned(16))) f32x2 taps[16];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  const int t0 = (int)blockIdx.x * POST_TT - 4;          // first activated sample of the tile (conv output p needs samples p - 3 .. p + 3)
-  if (tid < 12) {        // up pair j = (f_up[10 - 2j], f_up[11 - 2j]) x 2, down pair m = (f_dn[2m], f_dn[2m+1]): as the strip kernel
-    const bool up = tid < 6;
-    const int j = up ? tid : tid - 6;
-    const int i0 = up ? 10 - 2 * j : 12 + 2 * j;
-    const float sc = up ? 2.f : 1.f;
-    taps[tid] = (f32x2){sc * taps_g[i0], sc * taps_g[i0 + 1]};
-  }
-  const unsigned row_bytes = (unsigned)len * 4u;
-  auto row = [&](int c) { return make_rsrc(x + ((size_t)b * channels + c) * (size_t)len, c < channels ? row_bytes : 0u); };
-  unsigned ld_off[2];
-#pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
-    const int f = tid + 256 * rep;
-    ld_off[rep] = f < ACT_XF4 ? (unsigned)((t0 - 8 + 4 * f) * 4) : 0x80000000u;      // (before the row: wraps out of range -> 0)
-  }
-  u32x4 cur[2], nxt[2];
-#pragma unroll
-  for (int rep = 0; rep < 2; ++rep) cur[rep] = __builtin_amdgcn_raw_buffer_load_b128(row(0), ld_off[rep], 0, 0);
-  const int zlast = 2 * len - 1, tb = t0 - 8, o0 = ACT_PPT * tid, i0 = t0 + o0;
-  const bool edge_x = tb < 0 || tb + ACT_XS > len;
-  const bool edge_z = t0 <= 0 || t0 + ACT_TT + 3 > len;
-  const float b0 = bias[0];
-  float acc[4] = {b0, b0, b0, b0};
-  for (int c = 0; c < channels; ++c) {
-    const float alpha = alpha_p[c], inv_beta = inv_beta_p[c];
-    *reinterpret_cast<u32x4*>(xs + 4 * tid) = cur[0];
-    if (tid + 256 < ACT_XF4) *reinterpret_cast<u32x4*>(xs + 4 * (tid + 256)) = cur[1];
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) nxt[rep] = __builtin_amdgcn_raw_buffer_load_b128(row(c + 1), ld_off[rep], 0, 0);
-    __syncthreads();
-    if (edge_x) {                                   // replicate padding at the row ends
-      for (int j = tid; j < ACT_XS; j += 256) {
-        const int t = tb + j;
-        if (t < 0) xs[j] = xs[-tb];
-        else if (t >= len && len - 1 - tb >= 0) xs[j] = xs[len - 1 - tb];
-      }
-      __syncthreads();
-    }
-    {   // phase 2 of act1d_strip_kernel
-      const f32x2* tp = taps;
-      f32x2 fu2[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) fu2[q] = tp[q];
-      float xv[ACT_PPT + 8];
-#pragma unroll
-      for (int v = 0; v < ACT_PPT / 4 + 2; ++v) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(xs + ACT_PPT * tid + 4 * v);
-        xv[4 * v] = t4[0]; xv[4 * v + 1] = t4[1]; xv[4 * v + 2] = t4[2]; xv[4 * v + 3] = t4[3];
-      }
-      f32x2 zout[ACT_PPT], zf[ACT_PPT], arg[ACT_PPT];
-#pragma unroll
-      for (int r = 0; r < ACT_PPT; ++r) {
-        f32x2 z = {0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 6; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + 2 + q]), fu2[q], z);
-        zf[r] = z;
-        arg[r] = z * alpha;
-      }
-      f32x2 s2[ACT_PPT];
-      float amax = 0.f;
-#pragma unroll
-      for (int r = 0; r < ACT_PPT; ++r) {
-        s2[r] = sin_squared2(arg[r]);
-        amax = fmaxf(fmaxf(amax, fabsf(arg[r][0])), fabsf(arg[r][1]));
-      }
-      if (__builtin_expect(amax >= 32768.f, 0)) {
-#pragma unroll 1
-        for (int r = 0; r < ACT_PPT; ++r)
-          if (fabsf(arg[r][0]) >= 32768.f || fabsf(arg[r][1]) >= 32768.f) {
-            s2[r][0] = sin_squared_slow(arg[r][0]);
-            s2[r][1] = sin_squared_slow(arg[r][1]);
-          }
-      }
-#pragma unroll
-      for (int r = 0; r < ACT_PPT; ++r) zout[r] = __builtin_elementwise_fma((f32x2)(inv_beta), s2[r], zf[r]);
-      f32x4* zw = reinterpret_cast<f32x4*>(zs + 2 * ACT_PPT * tid);
-#pragma unroll
-      for (int v = 0; v < ACT_PPT / 2; ++v)
-        zw[v] = (f32x4){zout[2 * v][0], zout[2 * v][1], zout[2 * v + 1][0], zout[2 * v + 1][1]};
-    }
-    __syncthreads();
-    {   // phase 3 of act1d_strip_kernel; the activated samples go to LDS (zero outside the row: conv_post's padding)
-      const f32x2* tp = taps;
-      f32x2 fdp[6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) fdp[j] = tp[6 + j];
-      float zv[2 * ACT_PPT + 12];
-#pragma unroll
-      for (int v = 0; v < ACT_PPT / 2 + 3; ++v) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 2 * ACT_PPT * tid + 4 * v);
-        zv[4 * v] = t4[0]; zv[4 * v + 1] = t4[1]; zv[4 * v + 2] = t4[2]; zv[4 * v + 3] = t4[3];
-      }
-      float o[ACT_PPT];
-      const int zbase = 2 * (t0 - 4) + 1;
-#pragma unroll
-      for (int r = 0; r < ACT_PPT; ++r) {
-        f32x2 a2 = {0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-          a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
-        asm("v_add_f32 %0, %1, %2" : "=v"(o[r]) : "v"(a2[0]), "v"(a2[1]));
-      }
-      if (edge_z) {
-#pragma unroll 1
-        for (int r = 0; r < ACT_PPT; ++r) {
-          const int i = i0 + r;
-          if (i < 0 || i >= len) o[r] = 0.f;
-          else if (!(2 * i - 5 >= 0 && 2 * i + 6 <= zlast) && o0 < ACT_TT) {
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-              int m = 2 * i + k - 5;
-              m = m < 0 ? 0 : (m > zlast ? zlast : m);
-              a = fmaf(zs[m - zbase], taps_g[12 + k], a);
-            }
-            o[r] = a;
-          }
-        }
-      }
-      *reinterpret_cast<f32x4*>(ys + o0) = (f32x4){o[0], o[1], o[2], o[3]};
-    }
-    __syncthreads();
-    {   // conv_post: output p = 4 tid + r of the tile is activated sample index p + 4: taps at ys[p + 1 .. p + 7]
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(ys + 4 * tid), mid = *reinterpret_cast<const f32x4*>(ys + 4 * tid + 4),
-                  hi = *reinterpret_cast<const f32x4*>(ys + 4 * tid + 8);
-      const float v[12] = {lo[0], lo[1], lo[2], lo[3], mid[0], mid[1], mid[2], mid[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-      for (int jj = 0; jj < 7; ++jj) {
-        const float wv = w[c * 7 + jj];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = fmaf(wv, v[r + jj + 1], acc[r]);
-      }
-    }
-    cur[0] = nxt[0];
-    cur[1] = nxt[1];
-  }
-  const int p = (int)blockIdx.x * POST_TT + 4 * tid;
-  if (4 * tid < POST_TT && p < len) {
-    const f32x4 o = {tanhf(acc[0]), tanhf(acc[1]), tanhf(acc[2]), tanhf(acc[3])};
-    *reinterpret_cast<f32x4*>(out + (size_t)b * len + p) = o;
-  }
-}
-
 // Occupancy cap (fh_act_set_blocks_per_cu).  At its natural 7 blocks (28 waves) per CU this kernel keeps the vector ALUs, the
 // LDS and HBM busy at once, and on some MI355X boxes the power management answers with a lower shader clock that outlasts the
 // NEXT launch: a Winograd launch that follows an activation launch then runs at 2.11 instead of 2.38 GHz (+14 % time), far more
@@ -694,21 +528,6 @@ extern "C" int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups,
 }
 
 extern "C" int fh_act_tile_len(void) { return ACT_TT; }
-
-extern "C" int fh_act_post_conv_tanh_f32(const float* x, const float* alpha, const float* inv_beta, const float* taps,
-                                         const float* w, const float* bias, float* out, int batch, int channels, int len,
-                                         int ksz, void* stream) {
-  FH_CHECK_ARG(x && alpha && inv_beta && taps && w && bias && out && batch > 0 && channels > 0 && len > 0,
-               "fh_act_post_conv_tanh_f32: bad args");
-  FH_CHECK_ARG(ksz == 7 && len % 4 == 0 && ((((size_t)x) | ((size_t)out)) & 15) == 0,
-               "fh_act_post_conv_tanh_f32: needs a 7-tap conv_post and 16-byte aligned rows (len %d, ksz %d): run "
-               "fh_act1d_grouped_f32 + fh_conv_post_tanh_f32 instead (same bits)", len, ksz);
-  FH_CHECK_ARG((long long)len * 4 < (1ll << 31), "fh_act_post_conv_tanh_f32: rows of %d samples are too long", len);
-  hipLaunchKernelGGL((act_post_conv_tanh_kernel<false>), dim3((unsigned)fh_cdiv(len, POST_TT), (unsigned)batch), dim3(256), 0,
-                     (hipStream_t)stream, x, alpha, inv_beta, taps, w, bias, out, channels, len);
-  FH_CHECK_LAUNCH("fh_act_post_conv_tanh_f32");
-  return FH_OK;
-}
 
 extern "C" int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, int din, int dout,
                                    long long total_tiles, int all_len_mult4, void* stream) {

@@ -1,21 +1,20 @@
-// Narrow stages of BigVGAN (C <= 48): anti-aliased activation and the conv behind it in ONE launch.
+// Narrow stages of BigVGAN (C <= 48): the residual-stack convs, shaped for few channels.  (Round 5 also ran the anti-aliased
+// activation in front of the conv inside this launch; that form measured 0.92 ms per step slower than the pair of launches --
+// matrix and packed vector instructions share the fp32 ALUs, profiles/r05_amp_ablation.txt -- and left the library in round 6.)
 //
-// Replaces, per launch, one `xt = act(x); xt = conv(xt)` pair of the AMP blocks
+// Replaces, per launch, the `xt = conv(xt)` half of one `xt = act(x); xt = conv(xt)` pair of the AMP blocks
 // (/root/reference/src/flowhigh/models/bigvgan/models.py:63-72 AMPBlock1, :108-117 AMPBlock2;
 //  Activation1d alias_free_torch/act.py:23-28 = UpSample1d resample.py:25-33 -> SnakeBeta activations.py:107-120 ->
 //  DownSample1d filter.py:86-95; the convs are "same"-padded, k = 3 / 7 / 11, dilation 1 / 3 / 5), including "+ x"
 //  (:70) and the "xs / num_kernels" average over the blocks (:181-187, K segments of one group).
 //
-// Why: at 24 / 48 channels the unfused pair was 2.5 x above its own HBM floor -- the activation launch wrote the [B, C, L]
-// tensor, the conv launch read it back, and the conv kernels built for wide stages spent 37 % of a block outside their K loop
-// (eight transform points in eight waves meet through LDS) or multiplied 25 % padding rows.  Here the activated samples only
-// ever exist in LDS and the conv is shaped for few channels:
+// Why: at 24 / 48 channels the conv kernels built for wide stages spent 37 % of a block outside their K loop (eight transform
+// points in eight waves meet through LDS) or multiplied 25 % padding rows.  Here the conv is shaped for few channels:
 //   * block = 4 waves, 64 F(5,4) tiles = 300-320 outputs of every channel (a multiple of 20 x dilation, so that every block
 //     starts on a tile boundary of every dilation phase and on a 16-byte boundary); two blocks per CU, so that one block's
 //     prologue / epilogue / barriers run under the other's K loop;
-//   * the K loop walks 8-channel chunks.  For the NEXT chunk, wave w runs the activation of channel pair w over the block's
-//     samples + halo (one pass of 384 z pairs per channel through wave-private LDS: no block barrier) and writes the result
-//     into the chunk's slab in the Winograd read layout: per dilation phase 5 planes (sample w -> plane w % 5, index w / 5),
+//   * the K loop walks 8-channel chunks.  For the NEXT chunk, wave w loads channel pair w over the block's samples + halo and
+//     writes it into the chunk's slab in the Winograd read layout: per dilation phase 5 planes (sample w -> plane w % 5, index w / 5),
 //     channel pairs interleaved, so that lane `tile` reads sample 5 tile + e with ONE conflict-free ds_read_b64 for both
 //     channels of its pair;
 //   * ONE wave owns all 8 transform points of its 16 tiles: v_mfma_f32_16x16x4_f32 with M = 16 output channels, N = 16
@@ -39,12 +38,7 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int F_THREADS = 256;             // 4 waves
-constexpr int F_PPT = 6;                   // z pairs (and activation outputs) per lane
-constexpr int F_PAIRS = 64 * F_PPT;        // z pairs of a wave pass: samples i = tA - 4 + q
-constexpr int F_NOUT = F_PAIRS - 8;        // activation outputs of a pass: t = tA + j, j < 376
-constexpr int F_XS = F_PAIRS + 16;         // staged inputs x[tA - 8 .. tA + 391]
-constexpr int F_ZS = 2 * F_PAIRS + 16;
-constexpr int F_SCR = F_XS + F_ZS;         // wave-private scratch, floats
+constexpr int F_NOUT = 376;                // samples a wave stages per channel and pass: t = tA + j, j < 376
 constexpr int F_SLAB = 3840;               // floats of a slab (one 8-channel chunk): 40 d PL <= this for d <= 6
 constexpr int F_SLAB_BUF = F_SLAB + 128;   // + one trash pair per lane
 constexpr int F_YP = 324;                  // row pitch of the output staging
@@ -64,39 +58,22 @@ static_assert(40 * 1 * f_pl(1) <= F_SLAB && 40 * 2 * f_pl(2) <= F_SLAB && 40 * 3
 template <int MA>
 constexpr int f_wstage() { return 1024 * MA; }           // floats of one (chunk, tap group) weight stage
 
-constexpr int F_YBUF = 16 * F_YP > 4 * F_SCR ? 16 * F_YP : 4 * F_SCR;     // output staging | the four waves' activation scratch
+constexpr int F_YBUF = 16 * F_YP;          // output staging
 
 template <int MA>
-constexpr int f_lds_floats() { return 2 * F_SLAB_BUF + 2 * f_wstage<MA>() + F_YBUF + 2 * 3 * 32; }
-
-// sin^2 of two values (act1d.hip: sin_squared2; |a| >= 32768 is patched by the caller)
-__device__ __forceinline__ f32x2 f_sin_squared2(f32x2 a) {
-  const f32x2 k = __builtin_elementwise_fma(a, (f32x2)(0.31830988618379067154f), (f32x2)(12582912.f)) - 12582912.f;
-  f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-3.14159274101257324f), a);
-  r = __builtin_elementwise_fma(k, (f32x2)(8.742277657347586e-08f), r);
-  const f32x2 w = r * r;
-  f32x2 p = __builtin_elementwise_fma(w, (f32x2)(-3.6304279547e-06f), (f32x2)(1.3934598246e-04f));
-  p = __builtin_elementwise_fma(w, p, (f32x2)(-3.1723924913e-03f));
-  p = __builtin_elementwise_fma(w, p, (f32x2)(4.4443175197e-02f));
-  p = __builtin_elementwise_fma(w, p, (f32x2)(-3.3333307505e-01f));
-  p = __builtin_elementwise_fma(w, p, (f32x2)(1.0f));
-  return w * p;
-}
-__device__ __noinline__ float f_sin_squared_slow(float a) {
-  const float s = sinf(a);
-  return s * s;
-}
+constexpr int f_lds_floats() { return 2 * F_SLAB_BUF + 2 * f_wstage<MA>() + F_YBUF; }
 
 // MA: 16-row output tiles (channels <= 16 MA).  VEC: rows are 16-byte aligned (len % 4 == 0 for every group).
-// ACT = false: no activation (x is the conv's input): the form the launch plans use -- the activation stays a launch of its own
-// (act1d.hip), see "measured" in the header.
+// The conv's input is read as it is: the Activation1d in front of it is a launch of its own (act1d.hip).  (Round 5 also built the
+// form with the activation inside this launch: 0.92 ms per step slower, profiles/r05_amp_ablation.txt; it left the library in
+// round 6 -- `git show 60fcf48:flowhigh_amd/csrc/amp_fused.hip` has it.)
 //
 // Persistent blocks: block b works on tiles b, b + gridDim, ... of the launch's flattened (group, batch item, tile) list, and the
 // chunk pipeline runs across tile boundaries: the last K step of a tile requests and stages the first chunk (rows, weight stage)
 // of the block's NEXT tile and the bias / first residual of its own epilogue, so that no HBM round trip is waited for between
 // tiles.  (One block per tile spent more time outside its K loop than inside at 24 channels: 3-9 K steps of ~0.6 us against
 // ~6 us of descriptor reads, first loads, barriers and store phases.)
-template <int MA, bool VEC, bool ACT>
+template <int MA, bool VEC>
 #ifndef F_WAVES_PER_EU
 #define F_WAVES_PER_EU 2
 #endif
@@ -106,8 +83,7 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const slab0 = lds;
   float* const wbuf0 = lds + 2 * F_SLAB_BUF;
-  float* const ybuf = wbuf0 + 2 * f_wstage<MA>();     // output staging of the epilogue | wave-private scratch of the activation
-  f32x2* const taps = reinterpret_cast<f32x2*>(ybuf + F_YBUF);        // [tile parity][seg][16]: 0..5 up pairs (x 2), 6..11 down pairs
+  float* const ybuf = wbuf0 + 2 * f_wstage<MA>();     // output staging of the epilogue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -117,8 +93,6 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
   const int NTP = uni(f_ntp(d)), TB = 5 * d * NTP, PL = uni(f_pl(d)), NT = d * NTP;
   const int A = (cmax * d + 3) & ~3;                   // a tile's staged range starts at tA = t0 - A (16-byte aligned)
   const int nch = channels >> 3;
-  float* const xs = ybuf + wv * F_SCR;
-  float* const zs = xs + F_XS;
 
   // ---- tile -> (group, batch item, first output): one 16-byte entry of the host-made tile list ---------------------------
   // (found in the kernel -- prefix search over the groups, two integer divisions -- a tile cost ~150 instructions and a chain
@@ -139,27 +113,14 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
     T.nseg = uni(T.G->nseg);
     return T;
   };
-  // taps of every segment of a tile's group -> LDS (read as broadcasts by the activation passes)
-  auto publish_taps = [&](const Tile& T, int par) {
-    if (ACT && tid < 12 * T.nseg) {
-      const int s = tid / 12, e = tid - 12 * s;
-      const bool up = e < 6;
-      const int j = up ? e : e - 6;
-      const float* src = up ? T.G->seg[s].up_taps : T.G->seg[s].down_taps;
-      const int i0 = up ? 10 - 2 * j : 2 * j;
-      const float sc = up ? 2.f : 1.f;                // (the 2x of UpSample1d folded in: exact)
-      taps[(par * 3 + s) * 16 + e] = (f32x2){sc * src[i0], sc * src[i0 + 1]};
-    }
-  };
-
   // ---- slab geometry of this lane (the same for every tile: the launch's largest center `cmax` places the samples) ------
   // writer: sample j of the staged range is t = tA + j: rel = j - A = d u + p, slab sample w = u + cmax of phase p.
-  // With the activation a lane holds outputs j = 6 lane + r; without it the quads j = 4 (lane + 64 v) + e of its two loads.
-  constexpr int NWO = ACT ? F_PPT : 8;
+  // A lane holds the quads j = 4 (lane + 64 v) + e of its two loads.
+  constexpr int NWO = 8;
   int wofs[NWO];
 #pragma unroll
   for (int r = 0; r < NWO; ++r) {
-    const int j = ACT ? F_PPT * lane + r : 4 * (lane + 64 * (r >> 2)) + (r & 3);
+    const int j = 4 * (lane + 64 * (r >> 2)) + (r & 3);
     const int rel = j - A;
     int u = rel / d;
     int p = rel - u * d;
@@ -193,27 +154,21 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
   struct Seg {                                         // one K segment of one tile (wave-uniform)
     const float* x;
     const float* u;
-    const float* alpha;
-    const float* inv_beta;
-    int ngrp, center, len, bb, tA, tapi;
+    int ngrp, center, len, bb, tA;
   };
   auto load_seg = [&](const Tile& T, int s, int par) {
     Seg S;
     const fh_amp_seg* P = &T.G->seg[s];
     S.x = uni(P->x);
     S.u = uni(P->u);
-    S.alpha = uni(P->alpha);
-    S.inv_beta = uni(P->inv_beta);
     S.ngrp = uni(P->ngrp);
     S.center = uni(P->center);
     S.len = uni(T.len);
     S.bb = uni(T.bb);
     S.tA = uni(T.t0 - A);
-    S.tapi = (par * 3 + s) * 16;
     return S;
   };
-  u32x4 xq[2][2];                                    // [channel of the pair][vector]: x[tA (- 8) + 4 f ..], f = lane, lane + 64
-  float al[2], ib[2];
+  u32x4 xq[2][2];                                    // [channel of the pair][vector]: x[tA + 4 f ..], f = lane, lane + 64
   auto load_x = [&](const Seg& S, int chunk, bool valid) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -222,8 +177,8 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const int f = lane + 64 * v;
-        const int t = S.tA - (ACT ? 8 : 0) + 4 * f;
-        const bool in = f < (ACT ? F_XS / 4 : F_NOUT / 4);
+        const int t = S.tA + 4 * f;
+        const bool in = f < F_NOUT / 4;
         if (VEC) {
           xq[h][v] = __builtin_amdgcn_raw_buffer_load_b128(r, in ? (unsigned)(t * 4) : 0x80000000u, 0, 0);
         } else {
@@ -231,10 +186,6 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
           for (int e = 0; e < 4; ++e)
             xq[h][v][e] = __builtin_amdgcn_raw_buffer_load_b32(r, in ? (unsigned)((t + e) * 4) : 0x80000000u, 0, 0);
         }
-      }
-      if (ACT) {
-        al[h] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(S.alpha, valid ? (unsigned)channels * 4u : 0u), (unsigned)ch * 4u, 0, 0));
-        ib[h] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(S.inv_beta, valid ? (unsigned)channels * 4u : 0u), (unsigned)ch * 4u, 0, 0));
       }
     }
   };
@@ -250,141 +201,27 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
     for (int i = 0; i < MA; ++i) *reinterpret_cast<u32x4*>(dst + (tid + 256 * i) * 4) = wq[i];
   };
 
-  // ---- this wave's channel pair of a chunk (the loaded rows, through the activation) -> slab ----------------------------
-  auto stage_pair = [&](int sbuf, const Seg& SX) {
+  // ---- this wave's channel pair of a chunk -> slab (zero outside the row: the loads' out-of-range value) -------------------
+  auto stage_pair = [&](int sbuf, const Seg&) {
     float* const sl = slab0 + sbuf * F_SLAB_BUF;
-    if constexpr (!ACT) {
-      // conv-only form: the loaded samples are the conv's input (zero outside the row: the loads' out-of-range value)
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        *reinterpret_cast<f32x2*>(sl + wofs[r]) = (f32x2){__uint_as_float(xq[0][r >> 2][r & 3]), __uint_as_float(xq[1][r >> 2][r & 3])};
-      return;
-    }
-    const int len = SX.len, tA = SX.tA;
-    const bool edge = tA - 8 < 0 || tA - 8 + F_XS > len;          // the pass touches a row end (block-uniform)
-    float out[2][F_PPT];
-    const f32x2* tp_ = taps + SX.tapi;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      __builtin_amdgcn_wave_barrier();
-      *reinterpret_cast<u32x4*>(xs + 4 * lane) = xq[h][0];
-      if (lane < F_XS / 4 - 64) *reinterpret_cast<u32x4*>(xs + 4 * (lane + 64)) = xq[h][1];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (edge) {                                    // replicate padding at the row ends (act1d.hip)
-        const int tb = tA - 8;
-        for (int j = lane; j < F_XS; j += 64) {
-          const int t = tb + j;
-          if (t < 0) xs[j] = xs[-tb];
-          else if (t >= len && len - 1 - tb >= 0) xs[j] = xs[len - 1 - tb];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-      const float alpha = al[h], inv_beta = ib[h];
-      {   // z pairs q = 6 lane + r: P = (z[2i+1], z[2i+2]), i = tA - 4 + q, from x[i-2 .. i+3] = xs[q + 2 .. q + 7]
-        f32x2 fu2[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) fu2[q] = tp_[q];
-        float xv[12];
-#pragma unroll
-        for (int v = 0; v < 6; ++v) {
-          const f32x2 t2 = *reinterpret_cast<const f32x2*>(xs + F_PPT * lane + 2 + 2 * v);
-          xv[2 * v] = t2[0];
-          xv[2 * v + 1] = t2[1];
-        }
-        f32x2 zf[F_PPT], arg[F_PPT], s2[F_PPT];
-        float amax = 0.f;
-#pragma unroll
-        for (int r = 0; r < F_PPT; ++r) {
-          f32x2 z = {0.f, 0.f};
-#pragma unroll
-          for (int q = 0; q < 6; ++q) z = __builtin_elementwise_fma((f32x2)(xv[r + q]), fu2[q], z);
-          zf[r] = z;
-          arg[r] = z * alpha;
-        }
-#pragma unroll
-        for (int r = 0; r < F_PPT; ++r) {
-          s2[r] = f_sin_squared2(arg[r]);
-          amax = fmaxf(fmaxf(amax, fabsf(arg[r][0])), fabsf(arg[r][1]));
-        }
-        if (__builtin_expect(amax >= 32768.f, 0)) {
-#pragma unroll 1
-          for (int r = 0; r < F_PPT; ++r)
-            if (fabsf(arg[r][0]) >= 32768.f || fabsf(arg[r][1]) >= 32768.f) {
-              s2[r][0] = f_sin_squared_slow(arg[r][0]);
-              s2[r][1] = f_sin_squared_slow(arg[r][1]);
-            }
-        }
-        f32x4* zw = reinterpret_cast<f32x4*>(zs + 2 * F_PPT * lane);
-#pragma unroll
-        for (int v = 0; v < F_PPT / 2; ++v) {
-          const f32x2 a = __builtin_elementwise_fma((f32x2)(inv_beta), s2[2 * v], zf[2 * v]);
-          const f32x2 b = __builtin_elementwise_fma((f32x2)(inv_beta), s2[2 * v + 1], zf[2 * v + 1]);
-          zw[v] = (f32x4){a[0], a[1], b[0], b[1]};
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      {   // outputs j = 6 lane + r (t = tA + j): y = sum_m P_{t - 3 + m} . (f_dn[2m], f_dn[2m+1]); P_{t-3+m} is pair q = j + 1 + m
-        f32x2 fdp[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) fdp[j] = tp_[6 + j];
-        float zv[24];
-#pragma unroll
-        for (int v = 0; v < 6; ++v) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(zs + 2 * F_PPT * lane + 4 * v);
-          zv[4 * v] = t4[0]; zv[4 * v + 1] = t4[1]; zv[4 * v + 2] = t4[2]; zv[4 * v + 3] = t4[3];
-        }
-#pragma unroll
-        for (int r = 0; r < F_PPT; ++r) {
-          f32x2 a2 = {0.f, 0.f};
-#pragma unroll
-          for (int j = 0; j < 6; ++j)
-            a2 = __builtin_elementwise_fma((f32x2){zv[2 * r + 2 + 2 * j], zv[2 * r + 3 + 2 * j]}, fdp[j], a2);
-          out[h][r] = a2[0] + a2[1];
-        }
-        if (edge) {
-          // outputs whose taps leave [0, 2 len - 1] (z index clamped), and the conv's zero padding outside the row
-          const int zlast = 2 * len - 1, zbase = 2 * (tA - 4) + 1;           // zs[m - zbase] = z[m]
-#pragma unroll 1
-          for (int r = 0; r < F_PPT; ++r) {
-            const int i = tA + F_PPT * lane + r;
-            if (i < 0 || i >= len) out[h][r] = 0.f;
-            else if (!(2 * i - 5 >= 0 && 2 * i + 6 <= zlast) && F_PPT * lane + r < F_NOUT) {
-              float acc = 0.f;
-#pragma unroll 1
-              for (int k = 0; k < 12; ++k) {
-                int m = 2 * i + k - 5;
-                m = m < 0 ? 0 : (m > zlast ? zlast : m);
-                acc = fmaf(zs[m - zbase], tp_[6 + (k >> 1)][k & 1], acc);
-              }
-              out[h][r] = acc;
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < F_PPT; ++r) *reinterpret_cast<f32x2*>(sl + wofs[ACT ? r : 0]) = (f32x2){out[0][r], out[1][r]};
+    for (int r = 0; r < 8; ++r)
+      *reinterpret_cast<f32x2*>(sl + wofs[r]) = (f32x2){__uint_as_float(xq[0][r >> 2][r & 3]), __uint_as_float(xq[1][r >> 2][r & 3])};
   };
 
   // ---- first tile: its first chunk and weight stage ------------------------------------------------------------------------
   int tile = blockIdx.x;
   Tile T = locate(tile);
-  publish_taps(T, 0);
   int par = 0, sbuf = 0, wb = 0;
   Seg S = load_seg(T, 0, 0);
   load_w(S.u, true);
   load_x(S, 0, true);
-  __syncthreads();                                   // taps
   store_w(0);
   stage_pair(0, S);
   __syncthreads();
 
   for (;;) {
     const Tile TN = locate(tile + (int)gridDim.x);
-    publish_taps(TN, par ^ 1);                       // (read from this tile's last K step on: behind at least one barrier)
     // ---- epilogue state of this tile (the last K step requests round 0's bias and residual) ----------------------------
     const fh_amp_group* __restrict__ const G = (const fh_amp_group*)uni((const float*)T.G);
     const int len = uni(T.len), t0 = uni(T.t0), nseg = uni(T.nseg);
@@ -594,7 +431,7 @@ void amp_actconv_kernel(const fh_amp_group* __restrict__ groups, const fh_amp_ti
   }
 }
 
-template <int MA, bool VEC, bool ACT>
+template <int MA, bool VEC>
 int launch_amp(const fh_amp_group* groups, const fh_amp_tile* tiles, int channels, int dilation, int total_tiles, int cmax, hipStream_t stream) {
   static std::atomic<int> blocks_per_launch[FH_MAX_DEVICES];      // 0 = LDS opt-in not done yet; else 2 x the device's CUs
   int dev = 0;
@@ -605,7 +442,7 @@ int launch_amp(const fh_amp_group* groups, const fh_amp_tile* tiles, int channel
   constexpr int bytes = f_lds_floats<MA>() * 4;
   int resident = blocks_per_launch[dev].load(std::memory_order_acquire);
   if (!resident) {
-    hipError_t e = hipFuncSetAttribute((const void*)amp_actconv_kernel<MA, VEC, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)amp_actconv_kernel<MA, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess || cus <= 0) {
@@ -616,7 +453,7 @@ int launch_amp(const fh_amp_group* groups, const fh_amp_tile* tiles, int channel
     blocks_per_launch[dev].store(resident, std::memory_order_release);
   }
   const int grid = total_tiles < resident ? total_tiles : resident;
-  hipLaunchKernelGGL((amp_actconv_kernel<MA, VEC, ACT>), dim3((unsigned)grid), dim3(F_THREADS), bytes, stream, groups, tiles,
+  hipLaunchKernelGGL((amp_actconv_kernel<MA, VEC>), dim3((unsigned)grid), dim3(F_THREADS), bytes, stream, groups, tiles,
                      channels, dilation, total_tiles, cmax);
   FH_CHECK_LAUNCH("fh_amp_actconv_f32");
   return FH_OK;
@@ -637,16 +474,15 @@ extern "C" int fh_amp_actconv_f32(const fh_amp_group* groups, int n_groups, cons
   FH_CHECK_ARG(channels >= 8 && channels <= 48 && channels % 8 == 0, "fh_amp_actconv_f32: %d channels (8 .. 48, a multiple of 8)", channels);
   FH_CHECK_ARG(dilation >= 1 && dilation <= F_MAX_D, "fh_amp_actconv_f32: dilation %d (1 .. %d)", dilation, F_MAX_D);
   FH_CHECK_ARG(max_center >= 0 && max_center <= 5, "fh_amp_actconv_f32: max_center %d (0 .. 5: kernels of at most 11 taps)", max_center);
-  FH_CHECK_ARG(flags >= 0 && flags <= 3, "fh_amp_actconv_f32: flags %d (bit 0: rows 16-byte aligned, bit 1: no activation)", flags);
+  FH_CHECK_ARG(flags == 2 || flags == 3, "fh_amp_actconv_f32: flags %d (bit 0: rows 16-byte aligned; bit 1 must be set: the form with the "
+               "Activation1d inside the launch left the library in round 6)", flags);
   const int ma = (channels + 15) / 16;
-  const bool vec = flags & 1, act = !(flags & 2);
+  const bool vec = flags & 1;
   hipStream_t st = (hipStream_t)stream;
-#define FH_AMP_CASE(MA)                                                                                          \
-  case MA:                                                                                                       \
-    if (!act) return vec ? launch_amp<MA, true, false>(groups, tiles, channels, dilation, total_tiles, max_center, st)    \
-                         : launch_amp<MA, false, false>(groups, tiles, channels, dilation, total_tiles, max_center, st);  \
-    return vec ? launch_amp<MA, true, true>(groups, tiles, channels, dilation, total_tiles, max_center, st)               \
-               : launch_amp<MA, false, true>(groups, tiles, channels, dilation, total_tiles, max_center, st);
+#define FH_AMP_CASE(MA)                                                                                   \
+  case MA:                                                                                                \
+    return vec ? launch_amp<MA, true>(groups, tiles, channels, dilation, total_tiles, max_center, st)     \
+               : launch_amp<MA, false>(groups, tiles, channels, dilation, total_tiles, max_center, st);
   switch (ma) {
     FH_AMP_CASE(1)
     FH_AMP_CASE(2)

@@ -65,7 +65,9 @@ __device__ __forceinline__ SegU load_seg(const fh_conv_seg* S) {
 // whole lines; with one block per phase every 128-byte line of the output was written by PH blocks in PH pieces (strided
 // 4-byte stores: 130 MB written for 46 MB of output over a step's upsamplers).  The arithmetic of a phase is unchanged.
 template <int MT, int NT, int WM, int WN, int CK, int PH = 1>
-__global__ __launch_bounds__(256, (MT * NT * PH <= 4 ? 3 : (MT * NT * PH <= 8 ? 2 : 1))) void conv_mfma_kernel(
+// (blocks per CU the launch bounds promise: 3 for the small accumulator sets, except the 32 x 256 tile with 16-channel chunks, whose
+// staging registers leave room for 2 -- the compiler said so with -Wpass-failed until round 6)
+__global__ __launch_bounds__(256, (MT * NT * PH <= 4 && !(MT == 1 && NT == 4 && CK == 16) ? 3 : (MT * NT * PH <= 8 ? 2 : 1))) void conv_mfma_kernel(
     const fh_conv_group* __restrict__ groups, int n_groups, int batch, int co_tiles, int n_tiles) {
   using Cfg = ConvCfg<MT, NT, WM, WN, CK>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, XW = Cfg::XW, WP = Cfg::WP;
@@ -516,14 +518,13 @@ extern "C" int fh_conv_grouped_f32(const fh_conv_group* groups, int n_groups, in
 extern "C" int fh_conv_transpose_fused_f32(const fh_conv_group* groups, int n_groups, int batch, int cout_pad, int n_len,
                                           int tile_cfg, int phases, void* stream) {
   FH_CHECK_ARG(groups && n_groups > 0 && batch > 0 && n_len > 0, "fh_conv_transpose_fused_f32: bad sizes");
-  FH_CHECK_ARG(phases == 2 || phases == 3, "fh_conv_transpose_fused_f32: %d phases (2 or 3)", phases);
+  FH_CHECK_ARG(phases == 2, "fh_conv_transpose_fused_f32: %d phases (2: the stride-3 form left the library with ABI 4)", phases);
   const int bm = fh_conv_tile_m(tile_cfg);
   FH_CHECK_ARG(bm > 0 && cout_pad % bm == 0, "fh_conv_transpose_fused_f32: cout_pad %d / tile_cfg %d", cout_pad, tile_cfg);
   hipStream_t st = (hipStream_t)stream;
-#define FH_CONVT_CASE(id, MT, NT, WM, WN)                                                                       \
-  case id:                                                                                                      \
-    return phases == 2 ? launch_conv<MT, NT, WM, WN, 16, 2>(groups, n_groups, batch, cout_pad, n_len, st)       \
-                       : launch_conv<MT, NT, WM, WN, 16, 3>(groups, n_groups, batch, cout_pad, n_len, st);
+#define FH_CONVT_CASE(id, MT, NT, WM, WN) \
+  case id:                                \
+    return launch_conv<MT, NT, WM, WN, 16, 2>(groups, n_groups, batch, cout_pad, n_len, st);
   switch (tile_cfg) {          // the shapes the launch plans use for upsamplers (channel chunk 16)
     FH_CONVT_CASE(3, 2, 2, 1, 4)
     FH_CONVT_CASE(4, 1, 4, 1, 4)

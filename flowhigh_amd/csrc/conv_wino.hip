@@ -461,7 +461,9 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
           for (int nt = 0; nt < NT; ++nt) {
             // (one column at a time, also for the instruction scheduler: with both columns' 32 LDS reads hoisted to
             // the top the 64 x 512 tile needs 240 VGPRs more than the 168 a 12-wave block may use)
-            if (nt > 0) __builtin_amdgcn_sched_barrier(0);
+            // (... and nothing of the next tap group's work moves above this group's MFMAs: the 128 x 256 tile otherwise fills
+            // its 168 registers with hoisted reads and spills a hundred)
+            __builtin_amdgcn_sched_barrier(0);
             float v[8];
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) {

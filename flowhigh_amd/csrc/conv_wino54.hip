@@ -3,12 +3,15 @@
 #include "conv_wino54_kernel.h"
 
 extern "C" int fh_wino54_tile_m(int tile_cfg) {
-  if (tile_cfg & FH_WINO_BF16X6) tile_cfg = (tile_cfg & ~FH_WINO_BF16X6) == 3 ? -1 : tile_cfg & ~FH_WINO_BF16X6;
+  if (tile_cfg & FH_WINO_BF16X6) {           // bf16 x 6: 96- and 64-row blocks
+    const int id = tile_cfg & ~FH_WINO_BF16X6;
+    tile_cfg = (id == 1 || id == 2) ? id : -1;
+  }
   return tile_cfg == 0 ? 128 : tile_cfg == 1 ? 96 : tile_cfg == 2 ? 64 : tile_cfg == 3 ? 48 : -1;
 }
 extern "C" int fh_wino54_tile_n(void) { return V_OUT; }
 
-// bf16 x 6 instantiations (conv_wino54_bf.hip): mt = 4 / 3 / 2 row tiles of 32
+// bf16 x 6 instantiations (conv_wino54_bf.hip): mt = 3 / 2 row tiles of 32
 int fh_internal_wino54_bf(const fh_wino_group* groups, int n_groups, int batch, int cout_pad, int len, int dilation, int pm, int mt,
                           bool vl, hipStream_t st, const int* run_map, int n_runs);
 
@@ -24,7 +27,7 @@ int wino54_dispatch(const fh_wino_group* groups, int n_groups, int batch, int co
   FH_CHECK_ARG(len < (1 << 24) - 4096, "fh_conv_wino54_f32: rows of %d samples: at most %d", len, (1 << 24) - 4097);
   if (tile_cfg & FH_WINO_BF16X6) {
     const int id = tile_cfg & ~FH_WINO_BF16X6;
-    FH_CHECK_ARG(id >= 0 && id <= 2, "fh_conv_wino54_f32: tile_cfg %d has no bf16 x 6 form (tiles 0 / 1 / 2 only)", id);
+    FH_CHECK_ARG(id == 1 || id == 2, "fh_conv_wino54_f32: tile_cfg %d has no bf16 x 6 form (96- and 64-row blocks only: 1, 2)", id);
     return fh_internal_wino54_bf(groups, n_groups, batch, cout_pad, len, dilation, pm, 4 - id, vl, st, run_map, n_runs);
   }
 #define FH_W54_CASE(id, MT)                                                                                         \

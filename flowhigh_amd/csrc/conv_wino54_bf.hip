@@ -10,8 +10,7 @@ int fh_internal_wino54_bf(const fh_wino_group* groups, int n_groups, int batch, 
   case MT:                                                                                                                      \
     return vl ? launch_wino54<MT, true, false, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs)  \
               : launch_wino54<MT, false, false, true>(groups, n_groups, batch, cout_pad, len, dilation, pm, st, run_map, n_runs);
-  switch (mt) {
-    FH_W54BF_CASE(4)
+  switch (mt) {          // (the 128-row block would need 257 registers: not built)
     FH_W54BF_CASE(3)
     FH_W54BF_CASE(2)
   }

@@ -35,9 +35,10 @@ REPO_ID = "ResembleAI/FlowHigh"
 CKPT_FILES = ("bigvgan_48khz_256band.json", "bigvgan_48khz_256band.pt", "FLowHigh_basic_400k.pt")
 
 
-def weights_bf16x6():
-    from .vocoder import use_bf16x6
-    return use_bf16x6()
+def weights_conv_form():
+    """The conv form the environment asks for ('auto' resolved to the default form): what convert.py packs."""
+    from .planner import resolve_conv_form
+    return resolve_conv_form()[0]
 
 
 def read_checkpoints(ckpt_dir):
@@ -187,7 +188,7 @@ class FLowHigh:
     """Device-resident weights of the vector-field net + its mel codec (the reference's
     `FLowHigh` with `audio_enc_dec = MelVoco`, models/flow.py:54-142, models/melvoco.py:16-46)."""
 
-    def __init__(self, state_dict, vocoder_config, device="cuda", depth=2, conv_bf16x6=None, store=None):
+    def __init__(self, state_dict, vocoder_config, device="cuda", depth=2, conv_bf16x6=None, store=None, conv_form=None):
         device = torch.device(device)
         if device.type != "cuda":
             raise hip.HipError(f"flowhigh_amd runs on MI355X only (got device '{device}'); there is no CPU path")
@@ -206,11 +207,51 @@ class FLowHigh:
                 raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
         with hip.device_guard(device):
             self.net = FlowNet(state_dict, device, depth=depth, store=store)
-            # conv_bf16x6 (None: FH_CONV_BF16X6, default off): the vocoder's Winograd convs on the BF16 matrix cores
-            # with every fp32 operand split exactly into three bf16 pieces (vocoder.use_bf16x6)
-            self.vocoder = Vocoder(self.vocoder_config, state_dict, device, bf16x6=conv_bf16x6, store=store)
+            # conv_form: the arithmetic form of the vocoder's convs, 'auto' | 'winograd' | 'bf16x6' | 'direct'
+            # (planner.resolve_conv_form; None: FH_CONV_FORM / the older switches, else 'auto'.  conv_bf16x6: the boolean keyword
+            # of rounds 2-5.)  'auto' = the default form, checked once against the direct form through THESE weights when the
+            # checkpoint is at hand (probe_conv_form below): a model whose weights amplify the Winograd transforms' rounding is
+            # rebuilt in the direct form.
+            self.vocoder = Vocoder(self.vocoder_config, state_dict, device, bf16x6=conv_bf16x6, store=store, conv_form=conv_form)
+            self.conv_form_probe = None
+            if self.vocoder.form_auto and state_dict is not None and os.environ.get("FH_CONV_PROBE", "1") != "0":
+                self.probe_conv_form(state_dict)
             self.logmel = LogMel(device)
         self.n_mels = self.net.dim_in
+
+    @property
+    def conv_form(self):
+        return self.vocoder.form
+
+    def probe_conv_form(self, state_dict, frames=20, limit=None):
+        """The load-time estimate behind conv_form='auto': the vocoder in its default form against the direct form (no Winograd
+        transform anywhere: its distance to a float64 run is the reference's own fp32 noise, profiles/r05_regime_sweep.txt), both
+        through the loaded weights on a `frames`-frame random mel.  max |difference| is logged and kept (conv_form_probe); above
+        `limit` (planner.PROBE_LIMIT = 3e-5: a third of the 1e-4 bar) the model keeps the direct-form vocoder instead.
+        Oracle-free; costs one packing of the direct-form weights (a reshape) and two 0.2 s forwards."""
+        import logging
+        from .planner import PROBE_LIMIT
+        limit = PROBE_LIMIT if limit is None else limit
+        g = torch.Generator().manual_seed(175)
+        mel = (torch.randn(1, frames, self.vocoder.true_mels, generator=g) * 2.0 - 3.0).to(self.device)
+        direct = Vocoder(self.vocoder_config, state_dict, self.device, conv_form="direct", act_blocks=self.vocoder.act_blocks)
+        a = self.vocoder.forward(mel).clone()
+        b = direct.forward(mel)
+        est = float((a - b).abs().max())
+        peak = float(b.abs().max())
+        self.conv_form_probe = dict(estimate=est, peak=peak, limit=limit, default=self.vocoder.form, frames=frames)
+        log = logging.getLogger("flowhigh_amd")
+        if est > limit:
+            log.warning("conv_form='auto': the %s form is %.2e from the direct form on a %d-frame probe (|wav| <= %.2f; limit %.0e): "
+                        "using the direct form", self.vocoder.form, est, frames, peak, limit)
+            self.vocoder = direct
+            self.conv_form_probe["chosen"] = "direct"
+        else:
+            log.info("conv_form='auto': the %s form is %.2e from the direct form on a %d-frame probe (|wav| <= %.2f; limit %.0e): kept",
+                     self.vocoder.form, est, frames, peak, limit)
+            self.conv_form_probe["chosen"] = self.vocoder.form
+            del direct
+        return self.conv_form_probe
 
 
 class FlowHighSR:
@@ -263,7 +304,12 @@ class FlowHighSR:
         return pkg
 
     @classmethod
-    def from_local(cls, ckpt_dir, device='cuda', **kwargs) -> 'FlowHighSR':
+    def from_local(cls, ckpt_dir, device='cuda', conv_form=None, **kwargs) -> 'FlowHighSR':
+        """from_local of the reference (flowhighsr.py:110-137) + conv_form = 'auto' (default) | 'winograd' | 'bf16x6' | 'direct': the
+        arithmetic form of the vocoder's convs (planner.resolve_conv_form; the environment's
+        FH_CONV_FORM overrides nothing a caller passes here)."""
+        from .planner import resolve_conv_form
+        form, form_auto = resolve_conv_form(conv_form)
         ckpt_dir = Path(ckpt_dir)
         dev = device if torch.device(device).type == 'cuda' else 'cuda'        # the reference always .cuda()s
         # A weight blob next to the checkpoints (python -m flowhigh_amd.convert <ckpt_dir>; FH_BLOB = another path, FH_BLOB=0 =
@@ -273,21 +319,32 @@ class FlowHighSR:
         blob = os.environ.get("FH_BLOB", str(ckpt_dir / weights.BLOB_NAME))
         if blob != "0" and Path(blob).exists():
             srcs = {f: weights.file_digest(ckpt_dir / f) for f in CKPT_FILES} if os.environ.get("FH_BLOB_VERIFY", "1") != "0" else None
-            store = weights.WeightStore.open(blob, hip.norm_device(dev), expect_format=weights.format_tag(weights_bf16x6()), sources=srcs)
+            # ('auto': a blob of the default form is taken as it is -- the probe needs the checkpoint; a blob written by
+            # `python -m flowhigh_amd.convert --probe` on a GPU box already holds the form the probe chose)
+            tags = [weights.format_tag(form)] + ([weights.format_tag("direct")] if form_auto else [])
+            store = None
+            for tag in tags:
+                store = weights.WeightStore.open(blob, hip.norm_device(dev), expect_format=tag, sources=srcs)
+                if store is not None:
+                    form = json.loads(tag)["form"]
+                    break
             if store is not None:
-                return cls(flowhigh=FLowHigh(None, store.cfg, dev, store=store), **kwargs)
+                try:
+                    return cls(flowhigh=FLowHigh(None, store.cfg, dev, store=store, conv_form=form), **kwargs)
+                except (RuntimeError, KeyError, ValueError) as e:          # a damaged or stale blob must not stop the load
+                    weights.WeightStore.why = f"{type(e).__name__}: {e}"
             import logging
             logging.getLogger("flowhigh_amd").warning("weight blob %s not used (%s): reading the checkpoints", blob, weights.WeightStore.why)
         sd, cfg = read_checkpoints(ckpt_dir)
-        return cls(flowhigh=FLowHigh(sd, cfg, dev), **kwargs)
+        return cls(flowhigh=FLowHigh(sd, cfg, dev, conv_form="auto" if form_auto else form), **kwargs)
 
     @classmethod
-    def from_pretrained(cls, device='cuda', **kwargs) -> 'FlowHighSR':
+    def from_pretrained(cls, device='cuda', conv_form=None, **kwargs) -> 'FlowHighSR':
         from huggingface_hub import hf_hub_download
         for fpath in ["FLowHigh_basic_400k.json", "bigvgan_48khz_256band.json",
                       "FLowHigh_basic_400k.pt", "bigvgan_48khz_256band.pt"]:
             local_path = hf_hub_download(repo_id=REPO_ID, filename=fpath)
-        return cls.from_local(Path(local_path).parent, device, **kwargs)
+        return cls.from_local(Path(local_path).parent, device, conv_form=conv_form, **kwargs)
 
     # ---- host pre-step (flowhighsr.py:59-86) -----------------------------------------------------
     def _upload(self, t):

@@ -20,7 +20,7 @@ CONV_MAX_TAPS = 16
 CONV_MAX_SEG = 3
 CONV_MAX_HALO = 64
 
-ABI_VERSION = 3            # FH_ABI_VERSION of include/flowhigh_hip.h
+ABI_VERSION = 4            # FH_ABI_VERSION of include/flowhigh_hip.h
 EPI_LINEAR, EPI_GEGLU, EPI_MAG, EPI_LOGCLAMP = 0, 1, 2, 3
 
 
@@ -54,8 +54,7 @@ class ActGroup(C.Structure):
 
 
 class AmpSeg(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("u", C.c_void_p), ("alpha", C.c_void_p), ("inv_beta", C.c_void_p),
-                ("up_taps", C.c_float * 12), ("down_taps", C.c_float * 12), ("ngrp", C.c_int32), ("center", C.c_int32)]
+    _fields_ = [("x", C.c_void_p), ("u", C.c_void_p), ("ngrp", C.c_int32), ("center", C.c_int32)]
 
 
 class AmpGroup(C.Structure):
@@ -99,7 +98,6 @@ _SIGS = {
     "fh_conv_post_tanh_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_f32": [_P, _I, _I, _I, _I, _P],
     "fh_act1d_grouped_pm_f32": [_P, _I, _I, _I, _I, _I, _I, _P],
-    "fh_act_post_conv_tanh_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_act_tile_len": [],
     "fh_act_set_blocks_per_cu": [_I],
     "fh_act_get_blocks_per_cu": [],

@@ -26,17 +26,56 @@ WINO_NARROW = (96, 48)
 WINO_UPS_MIN_CIN = 768
 
 
-def use_wino(c, d):
+# ---- which arithmetic form the vocoder's convs run in (round 6: a constructor keyword of the drop-in class) ---------------------
+#   'winograd'  Winograd F(5,4) / F(4,3) on the fp32 matrix instructions (v_mfma_f32_32x32x2_f32): the default of rounds 3-5
+#   'bf16x6'    the same Winograd contractions on the BF16 matrix cores with every fp32 operand split EXACTLY into three bf16
+#               pieces and six piece-pair MFMAs per k-block (fp32 in / out / accumulate, fp32-grade products: the dropped pairs are
+#               <= 2^-24 |a b|); the narrow stages and the four direct-kernel upsamplers stay on the fp32 matrix instructions
+#   'direct'    no Winograd anywhere: the direct implicit-GEMM kernel (fp32 MFMA), ~20 % closer to a float64 run where the
+#               weights' gain is high (profiles/r05_regime_sweep.txt) and ~2 x slower
+#   'auto'      DEFAULT_CONV_FORM, unless a load-time probe through the loaded weights (Vocoder.probe_conv_form: the default
+#               form against the direct form on a 20-frame random mel) differs by more than PROBE_LIMIT: then 'direct'
+# Keyword > environment (FH_CONV_FORM; the older switches FH_WINO=0 -> direct, FH_CONV_BF16X6=1 / 0 -> bf16x6 / winograd) > 'auto'.
+CONV_FORMS = ("auto", "winograd", "bf16x6", "direct")
+DEFAULT_CONV_FORM = "bf16x6"
+PROBE_LIMIT = 3e-5
+
+
+def resolve_conv_form(conv_form=None, bf16x6=None):
+    """-> (form, from_auto): one of 'winograd' / 'bf16x6' / 'direct', and whether it came from 'auto' (a probe may still change
+    it).  conv_form: the keyword (None: ask the environment); bf16x6: the older boolean keyword (True / False / None)."""
+    form = conv_form
+    if form is None and bf16x6 is not None:
+        form = "bf16x6" if bf16x6 else "winograd"
+    if form is None:
+        form = os.environ.get("FH_CONV_FORM", "").strip().lower() or None
+    if form is None and os.environ.get("FH_WINO", "1") == "0":
+        form = "direct"
+    if form is None and os.environ.get("FH_CONV_BF16X6", "") in ("0", "1"):
+        form = "bf16x6" if os.environ["FH_CONV_BF16X6"] == "1" else "winograd"
+    if form is None:
+        form = "auto"
+    if form not in CONV_FORMS:
+        raise ValueError(f"conv_form must be one of {CONV_FORMS}, got {form!r}")
+    return (DEFAULT_CONV_FORM, True) if form == "auto" else (form, False)
+
+
+def _wino_on(form):
+    """Winograd kernels allowed?  form None: the environment (FH_WINO=0 / FH_CONV_FORM=direct switch them off)."""
+    return (resolve_conv_form()[0] if form is None else form) != "direct"
+
+
+def use_wino(c, d, form=None):
     """Residual-stack convs [c -> c, dilation d] that run as Winograd F(4,3) (conv_wino.hip) instead of the direct
     implicit GEMM: c a multiple of 16 and >= WINO_MIN_C or one of WINO_NARROW, at every dilation (a dilated conv works
     on phase-major tensors written / read by the neighbouring activation launches: contiguous runs instead of stride-d
-    access).  FH_WINO=0 switches the path off (direct kernel everywhere: parity debugging)."""
-    return os.environ.get("FH_WINO", "1") != "0" and c % 16 == 0 and (c >= WINO_MIN_C or c in WINO_NARROW)
+    access).  form 'direct' (FH_WINO=0) switches the path off (direct kernel everywhere)."""
+    return _wino_on(form) and c % 16 == 0 and (c >= WINO_MIN_C or c in WINO_NARROW)
 
 
-def wino_conv_ok(c, d, k):
+def wino_conv_ok(c, d, k, form=None):
     """use_wino for a k-tap conv: kernels longer than 4 tap groups run on the direct kernel."""
-    return use_wino(c, d) and k <= WINO_MAX_K
+    return use_wino(c, d, form) and k <= WINO_MAX_K
 
 
 def pick_tile_cfg(cout):
@@ -111,7 +150,8 @@ _WINO_RUN = 8                      # W_RUN of conv_wino.hip
 # work keep the loop issue-bound (ablations: no weight loads -10 %, no split -10 %, neither and no slab -35 %)
 _WINO_BF_SPEED = {0: 0.75, 1: 0.76, 4: 0.72, 5: 0.94, 6: 0.75,
                   # F(5,4) bf16 x 6 blocks (round 6; 96- and 64-row blocks: the 128-row one spills): tools/wino54_cost_fit.py ... bf
-                  WINO_F54 | 0: 0.62, WINO_F54 | 1: 0.62, WINO_F54 | 2: 0.66}
+                  # (round 6, tools/wino54_cost_fit.py bf: 2.20 / 1.80-1.93 us per K step against 2.87-3.13 / 2.44-2.58)
+                  WINO_F54 | 1: 0.72, WINO_F54 | 2: 0.74}
 # F(5,4) tiles that have a bf16 x 6 form the planner may pick
 _WINO54_BF_TILES = (WINO_F54 | 1, WINO_F54 | 2)
 
@@ -216,20 +256,20 @@ def pick_wino54_tile(c, bf=False):
 WINO54_MIN_C = 96
 
 
-def use_wino54(c):
+def use_wino54(c, form=None):
     """... and at the odd multiples of 48 channels below it (C = 48: the 48-row block has no padding rows, the F(4,3) kernel's
     64-row tile a quarter; FH_WINO54_H16=0: not there)."""
-    if os.environ.get("FH_WINO54", "1") == "0" or not use_wino(c, 1):
+    if os.environ.get("FH_WINO54", "1") == "0" or not use_wino(c, 1, form):
         return False
     return c >= int(os.environ.get("FH_WINO54_MIN_C", WINO54_MIN_C)) or (c % 48 == 0 and os.environ.get("FH_WINO54_H16", "1") != "0")
 
 
-def use_amp(c, ks, dils):
+def use_amp(c, ks, dils, form=None):
     """Residual-stack convs of a stage that run on the narrow-stage kernel (amp_fused.hip, conv-only form: the activation stays
     a launch of its own): at most 48 channels (a multiple of 8), odd kernels of at most 11 taps, dilations of at most 6.
     A property of the STAGE (channel count and checkpoint configuration), never of the length or the batch.  FH_AMP=0 switches
     it off (those stages then run as in round 4: F(5,4) 48-row blocks / the direct kernel)."""
-    if os.environ.get("FH_AMP", "1") == "0" or os.environ.get("FH_WINO", "1") == "0":
+    if os.environ.get("FH_AMP", "1") == "0" or not _wino_on(form):
         return False
     cmax = max((k - 1) // 2 for k in ks)
     return (c % 8 == 0 and 8 <= c <= 48 and all(k % 2 == 1 and k <= 11 for k in ks)
@@ -237,16 +277,15 @@ def use_amp(c, ks, dils):
             and all(cmax - (k - 1) // 2 + 4 * -(-k // 4) + 3 <= 16 for k in ks))
 
 
-def ups_fused_ok(st, mode=None):
+def ups_fused_ok(st, enabled=True):
     """A stage's direct-kernel ConvTranspose1d runs with all its output phases in one block (conv_mfma.hip, PH = 2): stride 2
     with an even k - u, 16-channel chunks, one of the tile shapes that have the form, and an even number of K steps per phase
-    (the kernel's two weight register sets alternate per step).  A per-stage property; FH_UPS_FUSE=0: one group per phase with
-    strided stores, as until round 4 (same bits); FH_UPS_FUSE=3: stride 3 as well (the kernel has the form; measured 275 us
-    against 139 us for the 384 -> 192 stage at batch 1: a third of the blocks, 1.2 per CU: profiles/r05_upsampler_phases.txt)."""
-    mode = os.environ.get("FH_UPS_FUSE", "1") if mode is None else mode
-    if mode == "0":
+    (the kernel's two weight register sets alternate per step).  A per-stage property; FH_UPS_FUSE=0 (enabled=False): one group per
+    phase with strided stores, as until round 4 (same bits).  (The stride-3 form of round 5 -- 275 us against 139 us for the
+    384 -> 192 stage at batch 1, profiles/r05_upsampler_phases.txt -- left the library in round 6.)"""
+    if not enabled:
         return False
-    return (st["u"] in ((2, 3) if mode == "3" else (2,)) and st["extra"] == 0 and st["up_ck"] == 16 and st["tile_cfg"] in (3, 4, 6)
+    return (st["u"] == 2 and st["extra"] == 0 and st["up_ck"] == 16 and st["tile_cfg"] in (3, 4, 6)
             and len(st["up_phases"]) <= hip.CONV_MAX_SEG
             and all((st["cin"] // 16 * len(ph["offs"])) % 2 == 0 for ph in st["up_phases"]))
 
@@ -256,16 +295,8 @@ def plan_switches():
     of that model: a model's launches (and, for FH_WINO_SPLITK, its bits) do not change when the environment does while it
     lives.  (The switches that decide which kernel a stage's weights are packed for -- FH_WINO, FH_WINO54*, FH_AMP,
     FH_CONV_BF16X6 -- are read at construction as well, by use_wino / use_wino54 / use_amp / use_bf16x6.)"""
-    return dict(splitk=os.environ.get("FH_WINO_SPLITK", "1") != "0", ups_fuse=os.environ.get("FH_UPS_FUSE", "1"),
-                amp_fuse_act=os.environ.get("FH_AMP_FUSE_ACT", "0") == "1", fuse_tail=os.environ.get("FH_FUSE_TAIL", "0") == "1",
+    return dict(splitk=os.environ.get("FH_WINO_SPLITK", "1") != "0", ups_fuse=os.environ.get("FH_UPS_FUSE", "1") != "0",
                 amp_interleave=os.environ.get("FH_AMP_INTERLEAVE", "1") != "0")
-
-
-def amp_fuses_act():
-    """FH_AMP_FUSE_ACT=1: the narrow-stage launches also run the Activation1d in front of their conv (one launch per
-    act -> conv pair, the activated tensor never leaves LDS).  Off by default: measured slower than the two launches
-    (both are bound by the fp32 ALUs, which the matrix and the vector instructions share)."""
-    return os.environ.get("FH_AMP_FUSE_ACT", "0") == "1"
 
 
 def amp_tile_len(d):
@@ -276,17 +307,11 @@ def amp_tile_len(d):
 AMP_MAX_D = 6             # F_MAX_D of amp_fused.hip
 
 
-def make_amp_seg(x, u, act, k, center=None):
-    """One K segment of a narrow-stage group: conv weights `u` (pack_amp_weight) applied to Activation1d(x) with the
-    parameters `act` (dict alpha, inv_beta, up, down: Vocoder.act_params), or to x itself when act is None."""
+def make_amp_seg(x, u, k, center=None):
+    """One K segment of a narrow-stage group: conv weights `u` (pack_amp_weight) applied to x."""
     s = hip.AmpSeg()
     s.x, s.u, s.ngrp = _addr(x), _addr(u), -(-k // 4)
     s.center = (k - 1) // 2 if center is None else center
-    if act is not None:
-        s.alpha, s.inv_beta = hip.ptr(act["alpha"]), hip.ptr(act["inv_beta"])
-        for i in range(12):
-            s.up_taps[i] = act["up"][i]
-            s.down_taps[i] = act["down"][i]
     return s
 
 
@@ -351,10 +376,10 @@ WINO_MAX_K = 12           # the kernel instantiates 1..4 tap groups of 3
 
 
 def use_bf16x6():
-    """FH_CONV_BF16X6=1: the Winograd convs contract on the BF16 matrix cores with every fp32 operand split exactly into
-    three bf16 pieces (6 bf16 MFMAs per 16-channel k-block, fp32 accumulation): fp32-grade products at 0.375 of the
-    matrix-pipe cycles.  Off by default: the headline numbers are measured on the fp32 MFMA form."""
-    return os.environ.get("FH_CONV_BF16X6", "0") == "1"
+    """Does the environment (FH_CONV_FORM / FH_CONV_BF16X6 / FH_WINO, else the default form) ask for the bf16 x 6 form: the
+    Winograd convs on the BF16 matrix cores with every fp32 operand split exactly into three bf16 pieces (6 bf16 MFMAs per
+    16-channel k-block, fp32 accumulation), fp32-grade products at 0.375 of the matrix-pipe cycles.  (resolve_conv_form)"""
+    return resolve_conv_form()[0] == "bf16x6"
 
 
 def _addr(t):
@@ -461,6 +486,7 @@ class _PlanBuilder:
         self.key = None                                       # position key of the steps being added
         self.executed = 0.0     # FLOPs issued to the matrix cores by all conv launches (Winograd: 1.5 G / k of the algorithmic)
         self.direct = 0.0       # ... of which by the direct-kernel launches
+        self.conv_launches = []  # (kernel family, executed FLOPs, algorithmic FLOPs) of every conv launch, launch order (bench.py)
         self.L = n_frames                                     # current stage length
         self.Lref = ref_frames                                # ... of the whole clip (== L unless this plan is a chunk)
         self.parts = None                                     # split-K partial outputs, allocated on first use
@@ -499,6 +525,7 @@ class _PlanBuilder:
         flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * self.B for g in groups for i in range(g.nseg))
         self.executed += flops
         self.direct += flops
+        self.conv_launches.append(("direct", flops, flops))
         self.add(("conv", d, len(groups), cpad, n_len, tcfg, ck, flops), groups)
 
     def convt(self, groups, cpad, n_len, tcfg, phases):
@@ -508,6 +535,7 @@ class _PlanBuilder:
         flops = sum(2.0 * g.cout * g.seg[i].cin * g.seg[i].ntaps * n_len * self.B for g in groups for i in range(g.nseg))
         self.executed += flops
         self.direct += flops
+        self.conv_launches.append(("direct", flops, flops))
         self.add(("convt", d, len(groups), cpad, n_len, tcfg, phases, flops), groups)
 
     def wino(self, groups, wpad, length, dil, wcfg, pm=False, flops=None, batch=None, novl=False):
@@ -532,19 +560,22 @@ class _PlanBuilder:
                         for g in groups for i in range(g.nseg))
         # multiply-adds the matrix cores actually execute: 6 per 4 outputs per group of 3 taps, or 8 per 5 per group of 4
         per_out = 1.6 if wcfg & WINO_F54 else 1.5
-        self.executed += sum(2.0 * g.cout * g.seg[i].cin * per_out * g.seg[i].ngrp * length * B
-                             for g in groups for i in range(g.nseg))
+        ex = sum(2.0 * g.cout * g.seg[i].cin * per_out * g.seg[i].ngrp * length * B for g in groups for i in range(g.nseg))
+        self.executed += ex
+        self.conv_launches.append((("wino54" if wcfg & WINO_F54 else "wino43") + ("_bf16x6" if self.v.bf else ""), ex, flops))
         self.add(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B), groups)
 
-    def amp(self, groups, c, length, dil, fused_act):
-        """Narrow-stage launch (fh_amp_actconv_f32): the groups' convs, with their activation in front when fused_act."""
+    def amp(self, groups, c, length, dil):
+        """Narrow-stage launch (fh_amp_actconv_f32): the groups' convs."""
         B = self.B
         tiles = amp_tile_list([g.len for g in groups], B, dil, self.v.sw["amp_interleave"]).to(self.v.device)
         d = hip.to_device_struct_array(groups, self.v.device)
         self.keep += [d, tiles]
         flops = sum(2.0 * c * c * (2 * g.seg[i].center + 1) * length * B for g in groups for i in range(g.nseg))
-        self.executed += sum(2.0 * c * c * 1.6 * g.seg[i].ngrp * length * B for g in groups for i in range(g.nseg))
-        flags = int(all(g.len % 4 == 0 for g in groups)) | (0 if fused_act else 2)
+        ex = sum(2.0 * c * c * 1.6 * g.seg[i].ngrp * length * B for g in groups for i in range(g.nseg))
+        self.executed += ex
+        self.conv_launches.append(("amp", ex, flops))
+        flags = int(all(g.len % 4 == 0 for g in groups)) | 2
         self.add(("amp", d, len(groups), tiles, tiles.shape[0], c, dil, amp_max_center(groups), flags, flops), groups)
 
     def act(self, groups, c, length, din=1, dout=1):
@@ -552,16 +583,15 @@ class _PlanBuilder:
         self.keep.append(d)
         self.add(("act", d, len(groups), c, length, din, dout), groups)
 
-    def res_conv(self, st, ents, xs_in, ks, dil, outs, res, pm=False, defer_sum=False, acts=None):
+    def res_conv(self, st, ents, xs_in, ks, dil, outs, res, pm=False, defer_sum=False):
         """One launch of the same conv position in the nk AMP blocks (one group per block) at the current stage
         length.  Returns, per block, the tensors whose sum is the conv's output (more than one: input-channel slices
         whose partial outputs the caller adds, defer_sum)."""
         c, cpad, wpad, L, B = st["c"], st["cpad"], st["wpad"], self.L, self.B
         biases = [e["b"] for e in ents]
         if all("ua" in e for e in ents):               # narrow stage: plain tensors whatever the dilation
-            # (acts: the Activation1d in front of each block's conv runs inside the launch: FH_AMP_FUSE_ACT=1)
-            self.amp([make_amp_group([make_amp_seg(xs_in[i], ents[i]["ua"], acts[i] if acts else None, ks[i])], biases[i], res[i],
-                                     outs[i], L) for i in range(len(ents))], c, L, dil, acts is not None)
+            self.amp([make_amp_group([make_amp_seg(xs_in[i], ents[i]["ua"], ks[i])], biases[i], res[i],
+                                     outs[i], L) for i in range(len(ents))], c, L, dil)
             return [[o] for o in outs]
         all_wino = all("u" in e for e in ents)
         nsplit = wino_split_k(ks, c, wpad, self.Lref, dil, st["wcfg"], self.v.bf, self.v.sw["splitk"]) if all_wino else 1
@@ -707,21 +737,6 @@ class _PlanBuilder:
             pm = same_d and 1 < d1 <= 16 and all("u" in b_["c1"][m] for b_ in blks)
             dpm = d1 if pm else 1
             ents = [b_["c1"][m] for b_ in blks]
-            ents2 = [b_["c2"][m] for b_ in blks]
-            if v.sw["amp_fuse_act"] and all("ua" in e for e in ents + ents2):
-                # opt-in: every act -> conv pair of the position in ONE narrow-stage launch (the activated tensors stay in LDS)
-                self.at(i, m, 1, 0)
-                self.res_conv(st, ents, [xin[j] for j in order], ks, d1, [T2[j] for j in order], [[] for _ in blks],
-                              acts=[b_["acts"][2 * m] for b_ in blks])
-                self.at(i, m, 4, 0)
-                acts2 = [b_["acts"][2 * m + 1] for b_ in blks]
-                if m < v.nm - 1:
-                    self.res_conv(st, ents2, [T2[j] for j in order], ks, 1, [Y[j][m % 2] for j in order],
-                                  [[xin[j]] for j in order], acts=acts2)
-                    xin = [Y[j][m % 2] for j in range(v.nk)]
-                else:
-                    self.closing_conv(i, m, ents2, ks, [1] * v.nk, xin, acts=acts2, xs_in=[T2[j] for j in order])
-                continue
             self.at(i, m, 0, 0)
             self.act([make_act_group(xin[j], T1[j], st["blocks"][j]["acts"][2 * m]) for j in order], c, L, dout=dpm)
             self.at(i, m, 1, 0)
@@ -768,7 +783,7 @@ class _PlanBuilder:
             if m == v.nm - 1:            # xs / num_kernels, block order = the reference's xs += order
                 self.average(xin, self.S, self.B * c * L, 1.0 / v.nk, key=(i, m, 6, 0))
 
-    def closing_conv(self, i, m, ents, ks, ds, xin, acts=None, xs_in=None):
+    def closing_conv(self, i, m, ents, ks, ds, xin):
         """The stage-closing conv position: xs = sum over blocks of (conv(T1_j) + x_j); S = xs / num_kernels
         (models.py:181-187).  Fused form: ONE group with nk K segments, the blocks are summed in the accumulator and
         / nk is the epilogue scale.  Unfused form: nk groups (more blocks for the 256 CUs) + one averaging pass; whichever
@@ -781,10 +796,8 @@ class _PlanBuilder:
         fusable = v.nk <= hip.CONV_MAX_SEG          # (K segments of one group; more blocks: one group each + one averaging pass)
         if all("ua" in e for e in ents) and fusable and all(d == ds[0] for d in ds):
             # narrow stage: always the fused form (its blocks are short whatever the length: nothing to decide per clip)
-            src = xs_in if xs_in is not None else [T1[j] for j in order]
-            segs = [make_amp_seg(src[n], e["ua"], acts[n] if acts else None, k) for n, (e, k) in enumerate(zip(ents, ks))]
-            self.amp([make_amp_group(segs, st["last_bias"], [xin[j] for j in order], S, L, scale=scale)], c, L, ds[0],
-                     acts is not None)
+            segs = [make_amp_seg(T1[j], e["ua"], k) for j, e, k in zip(order, ents, ks)]
+            self.amp([make_amp_group(segs, st["last_bias"], [xin[j] for j in order], S, L, scale=scale)], c, L, ds[0])
             return
         if all("u" in e for e in ents):
             ksteps = [c // 16 * -(-k // st["taps"]) for k in ks]
@@ -810,7 +823,7 @@ class _PlanBuilder:
         if not fusable or all("ua" in e for e in ents):
             outs, res = [Y[j][m % 2] for j in order], [[xin[j]] for j in order]
             if all(d == ds[0] for d in ds):
-                self.res_conv(st, ents, xs_in if xs_in is not None else [T1[j] for j in order], ks, ds[0], outs, res, acts=acts)
+                self.res_conv(st, ents, [T1[j] for j in order], ks, ds[0], outs, res)
             else:
                 self.mixed_dilation_conv(st, order, ents, ks, ds, [T1[j] for j in order], outs, res)
             self.average([Y[j][m % 2] for j in range(v.nk)], S, B * c * L, scale, key=(i, m, 6, 0))
@@ -825,20 +838,16 @@ class _PlanBuilder:
         v, B, L = self.v, self.B, self.L
         c_last = v.stages[-1]["c"]
         wav = torch.empty(B, L, **self.f32)
-        if L % 4 == 0 and v.post_k == 7 and v.sw["fuse_tail"]:
-            # opt-in: activation_post -> conv_post -> tanh as one launch (act1d.hip: act_post_conv_tanh_kernel; the bits of the
-            # two).  Off by default: 66 us against 20 + 13 us at batch 1 -- 477 blocks that each walk 24 channels serially are
-            # 1.9 blocks per CU where the activation launch alone has 11 340 (profiles/r05_summary.md)
-            self.add(("tail", cur, wav, c_last, L), key=(99, 0, 1, 0))
-        else:
-            post_t = self.pool[2, :B * c_last * L].view(B, c_last, L)
-            self.at(99, 0, 0, 0)
-            self.act([make_act_group(cur, post_t, v.post_act)], c_last, L)
-            self.add(("post", post_t, wav, c_last, L), key=(99, 0, 1, 0))
+        # (activation_post -> conv_post -> tanh as ONE launch was built in round 5: 66 us against 20 + 13 us at batch 1, 477 blocks
+        # that each walk 24 channels serially; it left the library in round 6)
+        post_t = self.pool[2, :B * c_last * L].view(B, c_last, L)
+        self.at(99, 0, 0, 0)
+        self.act([make_act_group(cur, post_t, v.post_act)], c_last, L)
+        self.add(("post", post_t, wav, c_last, L), key=(99, 0, 1, 0))
         # algorithmic HBM bytes of the Activation1d launches: every site reads and writes its [B, C, L] tensor once
         act_bytes = sum(8.0 * s_[2] * B * s_[3] * s_[4] for s_ in self.steps if s_[0] == "act")
         return dict(steps=self.steps, meta=self.meta, keep=self.keep, mel_in=self.mel_in, wav=wav, B=B, N=self.N, L=L,
-                    conv_executed_flops=self.executed, conv_direct_flops=self.direct, act_bytes=act_bytes,
+                    conv_executed_flops=self.executed, conv_direct_flops=self.direct, conv_launches=self.conv_launches, act_bytes=act_bytes,
                     n_act=sum(s_[0] == "act" for s_ in self.steps))
 
 
@@ -878,7 +887,7 @@ def merge_ragged(voc, frames):
     for k in sorted(by_key):
         items = by_key[k]
         # (a mean is a 2-3 term sum job; the fused tail launch and conv_post share a position: both run per clip)
-        kinds = {{"mean": "sum", "tail": "post"}.get(it[1][0], it[1][0]) for it in items}
+        kinds = {{"mean": "sum"}.get(it[1][0], it[1][0]) for it in items}
         if len(kinds) != 1:
             raise NotImplementedError(f"launch position {k}: kinds {kinds} cannot be merged")
         kind = kinds.pop()
@@ -991,7 +1000,7 @@ def merge_ragged(voc, frames):
                     raise NotImplementedError("partial-sum job shape")
                 jobs.append(j)
             merged.append(("rsum", blob(jobs), len(jobs), max(j.n for j in jobs)))
-        elif kind in ("post", "tail"):
+        elif kind == "post":
             for ci, st_, _ in items:
                 merged.append(st_)
         else:

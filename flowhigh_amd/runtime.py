@@ -8,15 +8,15 @@ import os
 import torch
 
 from . import hip
-from .packing import pack_wino54_weight, pack_wino_weight
+from .packing import pack_wino54_weight_any, pack_wino_weight_any
 from .planner import (WINO_F54, amp_max_center, amp_tile_list, make_act_group, make_wino_group, make_wino_seg, pick_wino54_tile,
                       pick_wino_tile, use_wino54)
 
-def amp_actconv(groups, batch, channels, dilation, device, act=True):
+def amp_actconv(groups, batch, channels, dilation, device):
     """Upload descriptors and enqueue one narrow-stage launch (test / one-off use)."""
     tiles = amp_tile_list([g.len for g in groups], batch, dilation).to(device)
     d = hip.to_device_struct_array(groups, device)
-    flags = int(all(g.len % 4 == 0 for g in groups)) | (0 if act else 2)
+    flags = int(all(g.len % 4 == 0 for g in groups)) | 2
     hip.check(hip.lib().fh_amp_actconv_f32(d.data_ptr(), len(groups), tiles.data_ptr(), tiles.shape[0], channels, dilation,
                                            amp_max_center(groups), flags, hip.stream()), "fh_amp_actconv_f32")
     return d, tiles
@@ -62,6 +62,7 @@ def act1d_grouped(groups, batch, channels, length, device, din=1, dout=1):
 # is too slow then (512))
 ACT_BLOCKS_CHOICES = (0, 3, 4)          # 0 = no cap; 4 is enough on one kind of affected box (and costs the activation less), 3 on both
 _act_blocks = {}                        # device ordinal -> setting in force
+_act_choice = {}                        # (device ordinal, bf16 x 6 convs?) -> setting chosen for models of that form
 
 
 def pick_act_blocks(pair_us, slack=0.98):
@@ -114,24 +115,27 @@ def decide_act_blocks(measure, group=None, collective=False):
     return box[0][1], box[0][2]
 
 
-def sync_act_blocks(device, group=None):
+def sync_act_blocks(device, group=None, bf=None):
     """One setting for all ranks of `group` (default: the world; pass a per-node group when the nodes differ): call it on EVERY
     rank, before the models are built; it returns the setting and puts it in force (and in the per-device cache, so that the
     constructors measure nothing).  FH_ACT_BLOCKS still overrides.  Without an initialised process group: the local calibration."""
     import torch.distributed as dist
     dev = hip.norm_device(device)
+    if bf is None:                                   # (the conv form the environment's models will have)
+        from .planner import use_bf16x6
+        bf = use_bf16x6()
     fixed = parse_act_blocks(os.environ.get("FH_ACT_BLOCKS"))
     if fixed is not None or not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
-        return calibrate_act_occupancy(dev)
+        return calibrate_act_occupancy(dev, bf=bf)
 
     def measure():
-        return [{b: measure_act_conv_pair(dev, b) for b in ACT_BLOCKS_CHOICES} for _ in range(2)]
+        return [{b: measure_act_conv_pair(dev, b, bf=bf) for b in ACT_BLOCKS_CHOICES} for _ in range(2)]
     choice, passes = decide_act_blocks(measure, group=group, collective=True)
     calibrate_act_occupancy.last_measurement = passes
-    return calibrate_act_occupancy(dev, force=True, act_blocks=choice)
+    return calibrate_act_occupancy(dev, force=True, act_blocks=choice, bf=bf)
 
 
-def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100):
+def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100, bf=False):
     """Average us of one (activation launch, Winograd launch) pair of a mid-network stage's size with the activation capped
     at `blocks` per CU (synthetic tensors; the launches are the model's: 3 groups, k = 11 / 7 / 3)."""
     dev = hip.norm_device(device)
@@ -143,9 +147,13 @@ def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100
         outs = [torch.empty(1, c, length, device=dev) for _ in ks]
         bias = torch.zeros(c, device=dev)
         # (the conv launch of the model at this width: the F(5,4) kernel unless it is switched off)
-        f54 = use_wino54(c)
-        wcfg, wpad = pick_wino54_tile(c) if f54 else pick_wino_tile(c)
-        pack = pack_wino54_weight if f54 else pack_wino_weight
+        # (bf: the conv of the pair in the bf16 x 6 form -- the cap exists for what the activation launch does to the clock of the
+        # conv launch behind it, and that differs between the fp32 and the bf16 matrix instructions: round 6 measured a cap that
+        # pays in front of fp32-MFMA convs and costs in front of bf16 x 6 ones on the same box)
+        f54 = use_wino54(c, "bf16x6" if bf else "winograd")
+        wcfg, wpad = pick_wino54_tile(c, bf) if f54 else pick_wino_tile(c)
+        pack = (lambda w_, p_: pack_wino54_weight_any(w_, p_, bf)) if f54 else (lambda w_, p_: pack_wino_weight_any(w_, p_, bf))
+        flag = 16 if bf else 0                         # FH_WINO_BF16X6
         us = [pack(torch.randn(c, c, k, generator=g) * 0.02, wpad).to(dev) for k in ks]
         gw = hip.to_device_struct_array([make_wino_group([make_wino_seg(ys[i], us[i], c, k, taps=4 if f54 else 3)], bias, [],
                                                          outs[i], c, wpad, length) for i, k in enumerate(ks)], dev)
@@ -159,9 +167,9 @@ def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100
             def pair():
                 hip.check(lib.fh_act1d_grouped_pm_f32(ga.data_ptr(), len(ks), 1, c, length, 1, 1, st), "fh_act1d_grouped_pm_f32")
                 if f54:
-                    hip.check(lib.fh_conv_wino54_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg & 15, st), "fh_conv_wino54_f32")
+                    hip.check(lib.fh_conv_wino54_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, (wcfg & 15) | flag, st), "fh_conv_wino54_f32")
                 else:
-                    hip.check(lib.fh_conv_wino_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg, st), "fh_conv_wino_f32")
+                    hip.check(lib.fh_conv_wino_f32(gw.data_ptr(), len(ks), 1, wpad, length, 1, 0, wcfg | flag, st), "fh_conv_wino_f32")
             for _ in range(warm):
                 pair()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -175,7 +183,7 @@ def measure_act_conv_pair(device, blocks, c=192, length=60000, warm=60, reps=100
         return e0.elapsed_time(e1) * 1e3 / reps
 
 
-def calibrate_act_occupancy(device, force=False, act_blocks=None):
+def calibrate_act_occupancy(device, force=False, act_blocks=None, bf=False):
     """Choose and set the activation launches' blocks per CU on `device` (once per device and process).
     act_blocks (Vocoder(act_blocks=)) or FH_ACT_BLOCKS = auto | 0 | 2..5 override the measurement -- a deployment that
     knows its boxes, or a launcher that wants every rank alike, passes the number.  No communication here: ranks that want one
@@ -185,25 +193,38 @@ def calibrate_act_occupancy(device, force=False, act_blocks=None):
     if dev.type != "cuda" or not torch.cuda.is_available():
         return 0
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, bool(bf))                            # one measured choice per device and conv form (bf: see measure_act_conv_pair)
     fixed = parse_act_blocks(act_blocks)
     if fixed is None:
         fixed = parse_act_blocks(os.environ.get("FH_ACT_BLOCKS"))
-    if idx in _act_blocks and not force and (fixed is None or fixed == _act_blocks[idx]):
-        return _act_blocks[idx]
-    if fixed is not None:
+    if key in _act_choice and not force and (fixed is None or fixed == _act_choice[key]):
+        choice = _act_choice[key]
+    elif fixed is not None:
         choice = fixed
     else:
         def measure():                               # two alternating passes: the chip's state drifts over the first 100 ms
-            return [{b: measure_act_conv_pair(dev, b) for b in ACT_BLOCKS_CHOICES} for _ in range(2)]
+            return [{b: measure_act_conv_pair(dev, b, bf=bf) for b in ACT_BLOCKS_CHOICES} for _ in range(2)]
         choice, passes = decide_act_blocks(measure)
         calibrate_act_occupancy.last_measurement = passes
         import logging
-        logging.getLogger("flowhigh_amd").info("activation occupancy on cuda:%d: %s blocks per CU; (activation, conv) pair us per pass: %s",
-                                               idx, choice or "uncapped (7)", passes)
-    with hip.device_guard(dev):
-        hip.check(hip.lib().fh_act_set_blocks_per_cu(choice), "fh_act_set_blocks_per_cu")
-    _act_blocks[idx] = choice
+        logging.getLogger("flowhigh_amd").info("activation occupancy on cuda:%d (%s convs): %s blocks per CU; (activation, conv) pair us per pass: %s",
+                                               idx, "bf16 x 6" if bf else "fp32-MFMA", choice or "uncapped (7)", passes)
+    _act_choice[key] = choice
+    ensure_act_blocks(dev, choice)
     return choice
+
+
+def ensure_act_blocks(device, choice):
+    """Put `choice` in force on `device` if another one is (the library holds ONE setting per device; models of both conv forms
+    in one process -- bench.py builds both -- each ask for theirs in front of their launches: a host-side integer, no GPU work)."""
+    dev = hip.norm_device(device)
+    if dev.type != "cuda":
+        return
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if _act_blocks.get(idx) != choice:
+        with hip.device_guard(dev):
+            hip.check(hip.lib().fh_act_set_blocks_per_cu(choice), "fh_act_set_blocks_per_cu")
+        _act_blocks[idx] = choice
 
 
 calibrate_act_occupancy.last_measurement = None
@@ -272,12 +293,6 @@ def launch_step(voc, s, B, st):
         if timing is not None:
             e1.record()
             timing.append((e0, e1))
-    elif s[0] == "tail":
-        _, x, wav, c, length = s
-        pa = voc.post_act
-        hip.check(L.fh_act_post_conv_tanh_f32(x.data_ptr(), pa["alpha"].data_ptr(), pa["inv_beta"].data_ptr(), voc.post_taps.data_ptr(),
-                                              voc.post_w.data_ptr(), voc.post_b.data_ptr(), wav.data_ptr(), B, c, length,
-                                              voc.post_k, st), "fh_act_post_conv_tanh_f32")
     else:
         _, x, wav, c, length = s
         hip.check(L.fh_conv_post_tanh_f32(x.data_ptr(), voc.post_w.data_ptr(), voc.post_b.data_ptr(),

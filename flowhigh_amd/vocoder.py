@@ -30,13 +30,13 @@ from .packing import (  # noqa: F401
 from .planner import (  # noqa: F401
     AMP_MAX_D, WINO54_MIN_C, WINO_BF16X6, WINO_BM, WINO_F54, WINO_MAX_K, WINO_MIN_C, WINO_NARROW, WINO_NOVL,
     WINO_UPS_MIN_CIN, WINO_XCD_RANGES, _PlanBuilder, _TILE_PREF, _WINO_BF_SPEED, _WINO_COST, _WINO_RUN,
-    _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_fuses_act, amp_max_center,
+    _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_max_center,
     amp_tile_len, amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,
     make_conv_seg, make_wino_group, make_wino_seg, merge_ragged, pick_tile_cfg, pick_wino54_tile,
-    pick_wino_tile, plan_switches, ups_fused_ok, use_amp, use_bf16x6, use_wino, use_wino54, wino_block_mapping,
+    pick_wino_tile, plan_switches, resolve_conv_form, ups_fused_ok, use_amp, use_bf16x6, use_wino, use_wino54, wino_block_mapping,
     wino_conv_ok, wino_launch_cost, wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
 from .runtime import (  # noqa: F401
-    ACT_BLOCKS_CHOICES, _act_blocks, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped,
+    ACT_BLOCKS_CHOICES, _act_blocks, _act_choice, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped, ensure_act_blocks,
     conv_wino, decide_act_blocks, launch_step, measure_act_conv_pair, parse_act_blocks, pick_act_blocks,
     run_ragged_steps, run_steps, sync_act_blocks)
 
@@ -46,7 +46,7 @@ VOC = "flowhigh.audio_enc_dec.vocoder."
 class Vocoder:
     """Device-resident BigVGAN weights + per-shape launch plans."""
 
-    def __init__(self, cfg, sd, device, prefix=VOC, bf16x6=None, act_blocks=None, store=None):
+    def __init__(self, cfg, sd, device, prefix=VOC, bf16x6=None, act_blocks=None, store=None, conv_form=None):
         if isinstance(cfg, (str, bytes)) or hasattr(cfg, "read_text"):
             cfg = json.loads(open(cfg).read())
         self.cfg = dict(cfg)
@@ -56,9 +56,12 @@ class Vocoder:
         if cfg["activation"] not in ("snake", "snakebeta"):
             raise NotImplementedError(cfg["activation"])
         self.device = hip.norm_device(device)
-        # bf16x6: the Winograd convs contract on the BF16 matrix cores, operands split into three bf16 pieces
-        # (None: FH_CONV_BF16X6; see use_bf16x6)
-        self.bf = use_bf16x6() if bf16x6 is None else bool(bf16x6)
+        # conv_form: 'winograd' | 'bf16x6' | 'direct' | 'auto' (planner.resolve_conv_form: keyword > FH_CONV_FORM and the older
+        # switches > 'auto' = the default form; bf16x6 = the boolean keyword of rounds 2-5).  'auto' is resolved HERE to the default
+        # form; a caller that holds the checkpoint may then probe it against the direct form (FLowHigh, probe_conv_form).
+        self.form, self.form_auto = resolve_conv_form(conv_form, bf16x6)
+        # bf: the Winograd convs contract on the BF16 matrix cores, operands split into three bf16 pieces
+        self.bf = self.form == "bf16x6"
         # plan-shaping environment switches, read once: every plan of this model uses this snapshot (planner.plan_switches)
         self.sw = plan_switches()
         self.rates = list(cfg["upsample_rates"])
@@ -96,6 +99,9 @@ class Vocoder:
         # weight blob (weights.py; `sd` may then be None) -- taken from the uploaded file without touching the checkpoint
         from .weights import WeightStore
         W = store if store is not None else WeightStore(dev)
+        if getattr(W, "form", None) not in (None, self.form):
+            # (a blob's tensors are laid out for ONE form: fp32 Winograd tensors read as three-piece bf16 would be garbage)
+            raise ValueError(f"the weight blob was packed for conv_form={W.form!r}, this model is being built for {self.form!r}")
 
         def g(name):
             """Checkpoint tensor, channel dimensions zero-padded to the counts above."""
@@ -160,7 +166,7 @@ class Vocoder:
         if sd is not None and g("conv_pre.weight").shape[-1] != 7:
             raise NotImplementedError("conv_pre kernel size other than 7")            # (models.py:134 fixes 7)
         self.pre_u = None
-        if use_wino(self.c0, 1) and self.num_mels % 16 == 0 and self.c0 % 64 == 0:
+        if use_wino(self.c0, 1, self.form) and self.num_mels % 16 == 0 and self.c0 % 64 == 0:
             self.pre_wcfg, self.pre_wpad = pick_wino_tile(self.c0)
             self.pre_u = W.dev("v.conv_pre.u", lambda: pack_wino_weight_any(g("conv_pre.weight"), self.pre_wpad, self.bf))
         self.stages = []
@@ -173,18 +179,18 @@ class Vocoder:
             # Winograd residual stack only if every block's kernel fits its 4 tap groups (one launch per position)
             wino_k = max(self.ks) <= WINO_MAX_K
             for kk, dl in zip(self.ks, self.dil):
-                if not (wino_k and use_wino(c, 1)) and (kk > hip.CONV_MAX_TAPS or (kk - 1) * max(dl) > hip.CONV_MAX_HALO):
+                if not (wino_k and use_wino(c, 1, self.form)) and (kk > hip.CONV_MAX_TAPS or (kk - 1) * max(dl) > hip.CONV_MAX_HALO):
                     raise NotImplementedError(f"resblock kernel {kk} x dilation {max(dl)} exceeds the direct kernel's "
                                               f"{hip.CONV_MAX_TAPS} taps / {hip.CONV_MAX_HALO} samples of reach")
             # residual stack: F(5,4) kernel from WINO54_MIN_C channels on, else F(4,3); the
             # transposed conv's phase groups always run in the F(4,3) kernel (strided outputs)
             st["up_wcfg"], st["up_wpad"] = pick_wino_tile(c)
-            st["w54"] = use_wino54(c) and max(self.ks) <= WINO_MAX_K
+            st["w54"] = use_wino54(c, self.form) and max(self.ks) <= WINO_MAX_K
             st["wcfg"], st["wpad"] = pick_wino54_tile(c, self.bf) if st["w54"] else (st["up_wcfg"], st["up_wpad"])
             st["taps"] = 4 if st["w54"] else 3
             # narrow stages (<= 48 channels): the residual-stack convs run on the narrow-stage kernel (planner.use_amp)
             # (also in the bf16 x 6 form, which has no narrow-stage kernel of its own: those stages keep the fp32 one)
-            st["amp"] = use_amp(c, self.ks, self.dil)
+            st["amp"] = use_amp(c, self.ks, self.dil, self.form)
             pack_res = (lambda w_: pack_wino54_weight_any(w_, st["wpad"], self.bf)) if st["w54"] else \
                 (lambda w_: pack_wino_weight_any(w_, st["wpad"], self.bf))
             wt = lambda i=i: g(f"ups.{i}.0.weight")               # [cin, c, k]
@@ -197,7 +203,7 @@ class Vocoder:
                 st["up_phases"].append(dict(w=W.dev(f"v.ups.{i}.phase{r_}.w", phase_w), offs=[o for _, o in taps]))
             # the same transposed conv as Winograd phase groups (strided output) where the tile shapes fit
             st["up_wino"] = None
-            if use_wino(max(c, 48), 1) and c % 16 == 0 and c >= 48 and st["cin"] % 16 == 0 and st["cin"] >= WINO_UPS_MIN_CIN:
+            if use_wino(max(c, 48), 1, self.form) and c % 16 == 0 and c >= 48 and st["cin"] % 16 == 0 and st["cin"] >= WINO_UPS_MIN_CIN:
                 st["up_wino"] = []
                 for r_, taps in enumerate(transposed_conv_phases(k, u)):
                     # (taps ordered by input offset: a stride-1 correlation of len(taps) taps, center = - smallest offset)
@@ -215,7 +221,7 @@ class Vocoder:
                         w = lambda kn=kn: g(kn + ".weight")
                         if st["amp"] and all(self.dil[jj][m] == d for jj in range(self.nk)):
                             ent["ua"] = W.dev(f"v.{kn}.ua", lambda w=w: pack_amp_weight(w(), c))
-                        elif wino_k and use_wino(c, d) and all(self.dil[jj][m] == d for jj in range(self.nk)):
+                        elif wino_k and use_wino(c, d, self.form) and all(self.dil[jj][m] == d for jj in range(self.nk)):
                             ent["u"] = W.dev(f"v.{kn}.u", lambda w=w: pack_res(w()))
                         else:
                             ent["w"] = W.dev(f"v.{kn}.w", lambda w=w: pack_conv_weight(w(), cpad, st["ck"]))
@@ -232,7 +238,7 @@ class Vocoder:
                         same_d = tag == "convs2" or all(self.dil[jj][m] == d for jj in range(self.nk))
                         if st["amp"] and same_d:
                             ent["ua"] = W.dev(f"v.{kn}.ua", lambda w=w: pack_amp_weight(w(), c))
-                        elif wino_k and use_wino(c, d) and same_d:
+                        elif wino_k and use_wino(c, d, self.form) and same_d:
                             ent["u"] = W.dev(f"v.{kn}.u", lambda w=w: pack_res(w()))
                         else:
                             ent["w"] = W.dev(f"v.{kn}.w", lambda w=w: pack_conv_weight(w(), cpad, st["ck"]))
@@ -257,7 +263,7 @@ class Vocoder:
         self.act_timing = None
         # blocks per CU of the activation launches on this device (measured once per device and process: see above)
         # (act_blocks: 'auto' / None = measure unless FH_ACT_BLOCKS says otherwise; 0 or 2..5 = take that, no measurement)
-        self.act_blocks = calibrate_act_occupancy(self.device, act_blocks=act_blocks)
+        self.act_blocks = calibrate_act_occupancy(self.device, act_blocks=act_blocks, bf=self.bf)
 
     def stage_lengths(self, n_frames):
         """Samples per row after every upsampling stage: L_i = u_i L_(i-1) + (k_i - u_i) % 2 (models.py:141-146,179)."""
@@ -319,6 +325,7 @@ class Vocoder:
 
     @hip.on_device
     def run_ragged(self, rp):
+        ensure_act_blocks(self.device, self.act_blocks)
         run_ragged_steps(self, rp)
 
     @hip.on_device
@@ -417,4 +424,5 @@ class Vocoder:
 
     @hip.on_device
     def run(self, p):
+        ensure_act_blocks(self.device, self.act_blocks)       # (this model's activation occupancy cap: runtime.ensure_act_blocks)
         run_steps(self, p["steps"], p["B"], hip.stream())

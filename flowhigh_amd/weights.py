@@ -25,11 +25,20 @@ _ALIGN = 256
 _DTYPES = {"float32": torch.float32, "float64": torch.float64, "int16": torch.int16, "int32": torch.int32}
 
 
-def format_tag(bf16x6=False):
-    """Everything that decides WHICH layouts the constructors pack: a blob made under other switches is not used."""
+def format_tag(form="winograd"):
+    """Everything that decides WHICH layouts the constructors pack: a blob made under other decisions is not used.
+    form: the RESOLVED conv form ('winograd' | 'bf16x6' | 'direct', planner.resolve_conv_form); the remaining layout switches as
+    normalised booleans / numbers (unset and "1" are the same setting), and a fingerprint of the packers' and the planner's source
+    (tile choices, thresholds and fragment layouts live there: a code change must not silently reuse a key with another layout)."""
     from . import hip
-    env = {k: os.environ.get(k, "") for k in ("FH_WINO", "FH_WINO54", "FH_WINO54_MIN_C", "FH_WINO54_H16", "FH_AMP")}
-    return json.dumps(dict(abi=hip.ABI_VERSION, layout=2, bf16x6=bool(bf16x6), env=env), sort_keys=True)
+    pkg = Path(__file__).resolve().parent
+    fp = hashlib.blake2b(digest_size=8)
+    for name in ("packing.py", "planner.py", "vocoder.py", "flow.py"):
+        fp.update((pkg / name).read_bytes())
+    on = lambda k: os.environ.get(k, "1") != "0"
+    sw = dict(wino54=on("FH_WINO54"), wino54_h16=on("FH_WINO54_H16"), amp=on("FH_AMP"),
+              wino54_min_c=int(os.environ.get("FH_WINO54_MIN_C", "0") or 0))
+    return json.dumps(dict(abi=hip.ABI_VERSION, layout=3, form=str(form), switches=sw, packers=fp.hexdigest()), sort_keys=True)
 
 
 def file_digest(path):
@@ -40,6 +49,20 @@ def file_digest(path):
     except ImportError:
         h = hashlib.blake2b(digest_size=16)
     with open(path, "rb") as f:
+        while True:
+            b = f.read(1 << 24)
+            if not b:
+                break
+            h.update(b)
+    return h.hexdigest()
+
+
+def file_digest_region(path, offset):
+    """Digest of a file from `offset` to its end (the tensor bytes of a blob: header['data_digest'], checked with FH_BLOB_VERIFY=2
+    and by `python -m flowhigh_amd.convert --verify`)."""
+    h = hashlib.blake2b(digest_size=16)
+    with open(path, "rb") as f:
+        f.seek(offset)
         while True:
             b = f.read(1 << 24)
             if not b:
@@ -60,6 +83,7 @@ class WeightStore:
         self.items = {}             # key -> (cpu tensor, host flag), insertion order = file order
         self._blob = None
         self.cfg = None
+        self.form = None            # (blob mode) the conv form the blob was packed for
 
     # ---- build mode / common -----------------------------------------------------------------------------------------
     def dev(self, key, fn):
@@ -104,8 +128,12 @@ class WeightStore:
                     return None
                 (hlen,) = struct.unpack("<Q", f.read(8))
                 header = json.loads(f.read(hlen).decode())
-        except (OSError, ValueError) as e:
-            cls.why = str(e)
+                need = ("format", "sources", "cfg", "tensors", "host_offset", "data_offset")
+                if not isinstance(header, dict) or any(k not in header for k in need):
+                    cls.why = "header incomplete"
+                    return None
+        except (OSError, ValueError, struct.error) as e:
+            cls.why = str(e) or type(e).__name__
             return None
         if expect_format is not None and header["format"] != expect_format:
             cls.why = "made under other layout switches"
@@ -114,9 +142,27 @@ class WeightStore:
             cls.why = "made from other checkpoint files"
             return None
         data0 = header["data_offset"]
+        # a truncated or partly copied file must not open: every tensor has to lie inside it
+        try:
+            end = max([e["offset"] + e["nbytes"] for e in header["tensors"].values()], default=0)
+            size = path.stat().st_size
+        except (OSError, KeyError, TypeError) as e:
+            cls.why = f"tensor index unreadable ({type(e).__name__})"
+            return None
+        if size < data0 + end:
+            cls.why = f"truncated: {size} bytes, the tensor index needs {data0 + end}"
+            return None
+        if os.environ.get("FH_BLOB_VERIFY", "1") == "2" and header.get("data_digest"):
+            if file_digest_region(path, data0) != header["data_digest"]:
+                cls.why = "tensor bytes do not match the header's digest"
+                return None
         mm = np.memmap(path, dtype=np.uint8, mode="c", offset=data0)         # (copy-on-write: torch wants a writable array)
         self = cls(device)
         self.cfg = header["cfg"]
+        try:
+            self.form = json.loads(header["format"]).get("form")      # the conv form the tensors were packed for
+        except (ValueError, AttributeError):
+            self.form = None
         split = header["host_offset"]                    # [0, split): device tensors, [split, end): host tensors
         whole = torch.from_numpy(np.asarray(mm))         # zero-copy view of the mapping
         dev_part = whole[:split]
@@ -153,7 +199,11 @@ class WeightStore:
             off += len(raw) + pad
         if host_offset is None:
             host_offset = off
-        header = dict(format=fmt, sources=sources, cfg=cfg, tensors=tensors, host_offset=host_offset, data_offset=0)
+        dg = hashlib.blake2b(digest_size=16)
+        for c in chunks:
+            dg.update(c)
+        header = dict(format=fmt, sources=sources, cfg=cfg, tensors=tensors, host_offset=host_offset, data_offset=0,
+                      data_digest=dg.hexdigest())
         for _ in range(2):                                # (data_offset depends on the header's own length)
             h = json.dumps(header).encode()
             header["data_offset"] = -(-(len(MAGIC) + 8 + len(h) + 32) // 4096) * 4096

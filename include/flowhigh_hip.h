@@ -27,7 +27,7 @@ extern "C" {
 #define FH_E_ARG (-1)     /* bad argument / unsupported shape */
 #define FH_E_LAUNCH (-2)  /* HIP launch error */
 
-#define FH_ABI_VERSION 3
+#define FH_ABI_VERSION 4
 
 int fh_abi_version(void);
 const char* fh_last_error(void);
@@ -276,14 +276,6 @@ int fh_act1d_grouped_pm_f32(const fh_act_group* groups, int n_groups, int batch,
  * total_tiles = groups[n-1].tile_base + C * ceil(groups[n-1].len / fh_act_tile_len()).  Same arithmetic per
  * sample as the launches above (replicate padding at each clip's own ends).  all_len_mult4: every group's len is a
  * multiple of 4 (rows 16-byte aligned: vector accesses). */
-/* The generator's tail in one launch: activation_post -> conv_post (7 taps, cin -> 1) -> tanh, models/bigvgan/models.py:189-192.
- * x [B, C, len], taps = the activation's 24 filter taps (12 up, then 12 down) in DEVICE memory, w [C, 7], bias [1], out [B, len].
- * Needs len % 4 == 0 and 16-byte aligned x / out (FH_E_ARG otherwise: the caller then runs fh_act1d_grouped_f32 +
- * fh_conv_post_tanh_f32).  Same bits as those two launches: same expressions in the same order; the [B, C, len] tensor between
- * them is never written. */
-int fh_act_post_conv_tanh_f32(const float* x, const float* alpha, const float* inv_beta, const float* taps,
-                              const float* w, const float* bias, float* out, int batch, int channels, int len,
-                              int ksz, void* stream);
 int fh_act_tile_len(void);
 int fh_act1d_ragged_f32(const fh_act_group* groups, int n_groups, int channels, int din, int dout,
                         long long total_tiles, int all_len_mult4, void* stream);
@@ -297,17 +289,17 @@ int fh_act_set_blocks_per_cu(int blocks);
 int fh_act_get_blocks_per_cu(void);
 
 /* ------------------------------------------------------------------------------------
- * Narrow stages (C <= 48 channels): Activation1d and the Conv1d behind it in ONE launch.
- * Replaces one `xt = self.activations[i](x); xt = conv(xt)` pair of an AMP block,
- *   models/bigvgan/models.py:63-72 (AMPBlock1: acts1 -> convs1[dilated] and acts2 -> convs2 "+ x") and :108-117
- *   (AMPBlock2), Activation1d = alias_free_torch/act.py:23-28, incl. the "xs / num_kernels" average of the stage's
- *   blocks (:181-187) as K segments of one group:
+ * Narrow stages (C <= 48 channels): the Conv1d of an AMP block behind its Activation1d, shaped for few channels.
+ * Replaces the `xt = conv(xt)` half of one `xt = self.activations[i](x); xt = conv(xt)` pair of an AMP block,
+ *   models/bigvgan/models.py:63-72 (AMPBlock1: convs1[dilated] and convs2 "+ x") and :108-117 (AMPBlock2), incl. the
+ *   "xs / num_kernels" average of the stage's blocks (:181-187) as K segments of one group:
  *     out[b, co, t] = scale * ( bias[co] + sum_r res[r][b, co, t]
- *                               + sum_seg sum_ci sum_{j<k} w_seg[co, ci, j] * act_seg(x_seg)[b, ci, t + (j - center) * dilation] )
- *   with act_seg(x) read as 0 outside [0, len) (the conv's zero padding) and the activation's own replicate padding at
- *   the row ends (fh_act_group above).  The activated tensor exists in LDS only; all tensors are plain [B, C, len]
- *   whatever the dilation.  The conv is evaluated in the Winograd F(5,4) form (fh_conv_wino54_f32): k <= 12 odd,
+ *                               + sum_seg sum_ci sum_{j<k} w_seg[co, ci, j] * x_seg[b, ci, t + (j - center) * dilation] )
+ *   with x_seg read as 0 outside [0, len) (the conv's zero padding).  All tensors are plain [B, C, len] whatever the
+ *   dilation.  The conv is evaluated in the Winograd F(5,4) form (fh_conv_wino54_f32): k <= 12 odd,
  *   dilation <= 6, (max_center - center) + 4 ngrp + 3 <= 16 for every segment.
+ *   (ABI 3 also had the form with the Activation1d inside the launch -- flags bit 1 clear, activation parameters in the segment:
+ *   measured slower than the pair of launches, it left the library with ABI 4.)
  * u = host-transformed weights (flowhigh_amd/packing.py: pack_amp_weight), float
  *   [C/8 chunks][ngrp][ blockA: [8 points][64 lanes][4]  (ceil(C/16) >= 2)  |  blockB: [8 points][64 lanes][2]  (ceil(C/16) odd) ]
  *   lane l = 16 kq + r: blockA[xi][l][2 m + s] = U[g][xi][co = 16 m + r][ci = 8 chunk + 2 kq + s] for the row tiles m = 0, 1,
@@ -319,15 +311,11 @@ int fh_act_get_blocks_per_cu(void);
  * max_center: the largest `center` of any segment of the launch (<= 5): it places the samples in the kernel's LDS slabs, the same
  *        for every block.  The launch runs 2 x (CUs of the device) persistent blocks that walk the tile list with stride gridDim.
  * flags: bit 0 = every row of every group is 16-byte aligned (len % 4 == 0: vector accesses; same bits without);
- *        bit 1 = no activation (act_seg = identity: the conv alone; alpha / inv_beta / taps are not read).
+ *        bit 1 = must be set (the conv alone; FH_E_ARG otherwise).
  * --------------------------------------------------------------------------------- */
 typedef struct {
-  const float* x;        /* [B, C, len]: the activation's input */
+  const float* x;        /* [B, C, len]: the conv's input */
   const float* u;        /* transformed weights, layout above */
-  const float* alpha;    /* [C] */
-  const float* inv_beta; /* [C] */
-  float up_taps[12];
-  float down_taps[12];
   int32_t ngrp;          /* ceil(k / 4) */
   int32_t center;        /* (k - 1) / 2 */
 } fh_amp_seg;

@@ -1,5 +1,6 @@
-"""GPU: the narrow-stage kernel (amp_fused.hip: Activation1d + the conv behind it in one launch) against the CPU
-oracle's activation (oracle/ref_cpu.py) followed by the float64 definition of the conv, through the C ABI."""
+"""GPU: the narrow-stage conv kernel (amp_fused.hip: the AMP-block convs of the stages with <= 48 channels) against the float64
+definition of the conv, through the C ABI.  (The form with the Activation1d inside the launch, and its tests against the oracle's
+activation, left with ABI 4: `git show 60fcf48:tests/test_hip_amp.py`.)"""
 import sys
 from pathlib import Path
 
@@ -8,13 +9,11 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-from flowhigh_amd import hip, synth          # noqa: E402
+from flowhigh_amd import hip                 # noqa: E402,F401
 from flowhigh_amd import vocoder as V        # noqa: E402
-from oracle import ref_cpu                   # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-H = {"activation": "snakebeta", "snake_logscale": True}
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -24,16 +23,6 @@ def rnd(*shape, seed=0, scale=1.0):
 
 def maxdiff(a, b):
     return float((a.double() - b.double()).abs().max())
-
-
-def act_case(C, seed):
-    """Snakebeta parameters in the oracle's state-dict form and in the kernel's form."""
-    filt = synth.kaiser_sinc_filter()
-    al, be = rnd(C, seed=seed, scale=0.4), rnd(C, seed=seed + 1, scale=0.4)
-    sd = {"a.act.alpha": al, "a.act.beta": be, "a.upsample.filter": filt, "a.downsample.lowpass.filter": filt}
-    p = dict(alpha=torch.exp(al).to(DEV), inv_beta=(1.0 / (torch.exp(be) + 1e-9)).to(DEV), up=filt.flatten().tolist(),
-             down=filt.flatten().tolist())
-    return sd, p
 
 
 def conv_ref(a, w, d):
@@ -52,31 +41,27 @@ def test_amp_conv_only(C, k, d, L, B):
     xd, rd, bd = x.to(DEV), r1.to(DEV), b.to(DEV)
     out = torch.full_like(xd, float("nan"))
     ud = V.pack_amp_weight(w, C).to(DEV)
-    g = V.make_amp_group([V.make_amp_seg(xd, ud, None, k)], bd, [rd], out, L, scale=0.5)
-    keep = V.amp_actconv([g], B, C, d, DEV, act=False)
+    g = V.make_amp_group([V.make_amp_seg(xd, ud, k)], bd, [rd], out, L, scale=0.5)
+    keep = V.amp_actconv([g], B, C, d, DEV)
     torch.cuda.synchronize()
     assert maxdiff(out.cpu(), ref) <= 2e-5
     del keep
 
 
-@pytest.mark.parametrize("C,k,d,L,B", [(24, 11, 1, 1000, 1), (24, 7, 3, 1201, 2), (48, 11, 5, 2000, 1), (48, 3, 1, 644, 2),
-                                       (8, 3, 1, 5, 1), (16, 11, 3, 900, 1), (32, 7, 2, 1283, 1), (48, 11, 1, 321, 2),
-                                       (24, 11, 5, 13, 1), (24, 3, 1, 1, 1)])
-def test_amp_actconv(C, k, d, L, B):
-    """Activation1d -> Conv1d(k, dilation d) in one launch against the oracle's activation + the float64 conv; three groups
-    (the AMP blocks of a stage) with their own parameters, inputs and residuals."""
+@pytest.mark.parametrize("C,k,d,L,B", [(24, 11, 1, 1000, 1), (24, 7, 3, 1201, 2), (48, 11, 5, 2000, 1), (8, 3, 1, 5, 1),
+                                       (32, 7, 2, 1283, 1), (24, 3, 1, 1, 1)])
+def test_amp_three_groups_in_one_launch(C, k, d, L, B):
+    """Three groups (the AMP blocks of a stage) with their own weights, inputs and residuals in one launch."""
     groups, keep, refs, outs = [], [], [], []
     for j in range(3):
-        sd, p = act_case(C, 10 * j)
         x, w, b = rnd(B, C, L, seed=20 + j, scale=1.5), rnd(C, C, k, seed=30 + j, scale=1.0 / (C * k) ** 0.5), rnd(C, seed=40 + j)
         r1 = rnd(B, C, L, seed=50 + j)
-        a = ref_cpu.activation1d(sd, "a.", x, H)
-        refs.append((conv_ref(a, w, d) + b.double()[None, :, None] + r1.double()).float())
+        refs.append((conv_ref(x, w, d) + b.double()[None, :, None] + r1.double()).float())
         xd, rd, bd, ud = x.to(DEV), r1.to(DEV), b.to(DEV), V.pack_amp_weight(w, C).to(DEV)
         out = torch.full_like(xd, float("nan"))
-        keep += [p, xd, rd, bd, ud]
+        keep += [xd, rd, bd, ud]
         outs.append(out)
-        groups.append(V.make_amp_group([V.make_amp_seg(xd, ud, p, k)], bd, [rd], out, L))
+        groups.append(V.make_amp_group([V.make_amp_seg(xd, ud, k)], bd, [rd], out, L))
     keep.append(V.amp_actconv(groups, B, C, d, DEV))
     torch.cuda.synchronize()
     for j in range(3):
@@ -84,19 +69,18 @@ def test_amp_actconv(C, k, d, L, B):
 
 
 def test_amp_three_segments_fused_average():
-    """The stage-closing position: one group, three K segments (k = 11 / 7 / 3 on three activated inputs), three residuals,
+    """The stage-closing position: one group, three K segments (k = 11 / 7 / 3 on three inputs), three residuals,
     scale 1 / 3 (models.py:181-187)."""
     C, L, B = 24, 1100, 2
     segs, keep, total = [], [], 0.0
     res = [rnd(B, C, L, seed=70 + j) for j in range(3)]
     bias = rnd(C, seed=60)
     for j, k in enumerate((3, 11, 7)):
-        sd, p = act_case(C, 100 + 10 * j)
         x, w = rnd(B, C, L, seed=80 + j, scale=1.5), rnd(C, C, k, seed=90 + j, scale=1.0 / (C * k) ** 0.5)
-        total = total + conv_ref(ref_cpu.activation1d(sd, "a.", x, H), w, 1)
+        total = total + conv_ref(x, w, 1)
         xd, ud = x.to(DEV), V.pack_amp_weight(w, C).to(DEV)
-        keep += [p, xd, ud]
-        segs.append(V.make_amp_seg(xd, ud, p, k))
+        keep += [xd, ud]
+        segs.append(V.make_amp_seg(xd, ud, k))
     ref = ((total + bias.double()[None, :, None] + sum(r.double() for r in res)) / 3.0).float()
     rd = [r.to(DEV) for r in res]
     out = torch.full((B, C, L), float("nan"), device=DEV)
@@ -107,12 +91,22 @@ def test_amp_three_segments_fused_average():
     assert maxdiff(out.cpu(), ref) <= 3e-5
 
 
+def test_amp_refuses_the_form_that_left_with_abi_4():
+    """flags bit 1 clear asked for the Activation1d inside the launch: FH_E_ARG with a message, not a silent conv."""
+    C, k, L = 24, 3, 320
+    xd, ud = rnd(1, C, L, seed=1).to(DEV), V.pack_amp_weight(rnd(C, C, k, seed=2), C).to(DEV)
+    out = torch.empty_like(xd)
+    g = hip.to_device_struct_array([V.make_amp_group([V.make_amp_seg(xd, ud, k)], None, [], out, L)], DEV)
+    tiles = V.amp_tile_list([L], 1, 1).to(DEV)
+    rc = hip.lib().fh_amp_actconv_f32(g.data_ptr(), 1, tiles.data_ptr(), tiles.shape[0], C, 1, 1, 1, hip.stream())
+    assert rc != 0 and "left the library" in hip.lib().fh_last_error().decode()
+
+
 @pytest.mark.parametrize("d", [1, 3, 5])
 def test_amp_ragged_groups_and_alignment_give_the_same_bits(d):
     """Groups of different lengths in one launch (ragged batches), a clip inside a batch, and rows that are not 16-byte
     aligned (4-byte accesses): every clip gets the bits of its own single-group, aligned launch."""
     C, k = 24, 7
-    sd, p = act_case(C, 5)
     w, b = rnd(C, C, k, seed=6, scale=0.1), rnd(C, seed=7)
     ud, bd = V.pack_amp_weight(w, C).to(DEV), b.to(DEV)
     lens = [1203, 320, 2000, 17]
@@ -120,7 +114,7 @@ def test_amp_ragged_groups_and_alignment_give_the_same_bits(d):
 
     def run(items, batch=1):
         outs = [torch.full_like(x, float("nan")) for x in items]
-        gs = [V.make_amp_group([V.make_amp_seg(x, ud, p, k)], bd, [x], o, x.shape[-1]) for x, o in zip(items, outs)]
+        gs = [V.make_amp_group([V.make_amp_seg(x, ud, k)], bd, [x], o, x.shape[-1]) for x, o in zip(items, outs)]
         keep = V.amp_actconv(gs, batch, C, d, DEV)
         torch.cuda.synchronize()
         del keep
@@ -136,25 +130,5 @@ def test_amp_ragged_groups_and_alignment_give_the_same_bits(d):
     # a chunk of the clip that starts on a block boundary of every dilation: its inner samples keep their bits
     s = 1200
     tail = run([xs[2][..., s:].contiguous()])[0]
-    halo = 8 + ((k - 1) // 2 + 5) * d         # activation reach + taps + the other inputs of an F(5,4) tile (rounding)
+    halo = ((k - 1) // 2 + 5) * d             # taps + the other inputs of an F(5,4) tile (rounding)
     assert torch.equal(tail[..., halo:], alone[2][..., s + halo:])
-
-
-def test_amp_huge_arguments_take_the_accurate_sine():
-    C, k, L = 24, 3, 700
-    sd, p = act_case(C, 3)
-    x = rnd(1, C, L, seed=9, scale=1.5)
-    x[0, 2, 100] = 3.0e5
-    w = rnd(C, C, k, seed=10, scale=0.1)
-    a = ref_cpu.activation1d(sd, "a.", x, H)
-    ref = conv_ref(a, w, 1).float()
-    xd, ud = x.to(DEV), V.pack_amp_weight(w, C).to(DEV)
-    out = torch.full_like(xd, float("nan"))
-    keep = V.amp_actconv([V.make_amp_group([V.make_amp_seg(xd, ud, p, k)], None, [], out, L)], 1, C, 1, DEV)
-    torch.cuda.synchronize()
-    got = out.cpu()
-    far = torch.ones(L, dtype=torch.bool)
-    far[85:116] = False
-    assert maxdiff(got[..., far], ref[..., far]) <= 3e-5
-    assert bool(torch.isfinite(got).all())
-    del keep

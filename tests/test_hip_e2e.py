@@ -15,16 +15,17 @@ TOL_WAVEFORM = 1e-4
 _MODELS = {}
 
 
-def model_for(cfg, seed, method="euler", cfm_method="basic_cfm", sigma=0.0, upsampling="scipy", bf16x6=False, fresh=False):
-    """fresh: build a model now (under the environment as it is now) instead of taking the cached one."""
-    key = (repr(sorted(cfg.items())), seed, bf16x6)
+def model_for(cfg, seed, method="euler", cfm_method="basic_cfm", sigma=0.0, upsampling="scipy", form=None, fresh=False):
+    """form: conv_form of the model (None = what a deployment gets: 'auto' -> the default form, probed against the direct form at
+    load).  fresh: build a model now (under the environment as it is now) instead of taking the cached one."""
+    key = (repr(sorted(cfg.items())), seed, form)
     if fresh:
         sd = synth.make_state_dict(cfg, seed)
-        fh = FLowHigh(sd, cfg, "cuda", conv_bf16x6=bf16x6)
+        fh = FLowHigh(sd, cfg, "cuda", conv_form=form)
         return FlowHighSR(fh, sigma=sigma, cfm_method=cfm_method, torchdiffeq_ode_method=method, upsampling_method=upsampling), sd
     if key not in _MODELS:
         sd = synth.make_state_dict(cfg, seed)
-        _MODELS[key] = (FLowHigh(sd, cfg, "cuda", conv_bf16x6=bf16x6), sd)
+        _MODELS[key] = (FLowHigh(sd, cfg, "cuda", conv_form=form), sd)
     fh, sd = _MODELS[key]
     m = FlowHighSR(fh, sigma=sigma, cfm_method=cfm_method, torchdiffeq_ode_method=method,
                    upsampling_method=upsampling)
@@ -484,15 +485,18 @@ def test_generate_many_ragged_batch_equals_single_calls_bitwise(cfgname, method,
 
 
 # ------------------------------------------------------------------------------------------
-# Opt-in bf16 x 6 form of the Winograd convs (FLowHigh(..., conv_bf16x6=True) / FH_CONV_BF16X6=1): every fp32 operand
-# split exactly into three bf16 pieces, six bf16 MFMAs per 16-channel k-block, fp32 accumulation.  Same tolerances as
-# the fp32-MFMA form everywhere; same bitwise invariants (batch / ragged / chunked against a clip alone).
+# The conv forms a deployer can ask for by name (FlowHighSR.from_local(..., conv_form=) / FLowHigh(..., conv_form=)): 'bf16x6' (the
+# default of round 6: every fp32 operand of the Winograd convs split exactly into three bf16 pieces, six bf16 MFMAs per 16-channel
+# k-block, fp32 accumulation) and 'winograd' (the fp32-MFMA Winograd forms, the default of rounds 3-5).  Same tolerances, same
+# bitwise invariants (batch / ragged / chunked against a clip alone) in both; every test above runs the DEFAULT form.
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("form", ["bf16x6", "winograd"])
 @pytest.mark.parametrize("name", E2E_CASES)
-def test_bf16x6_generate_matches_reference_golden(name):
+def test_named_conv_form_generate_matches_reference_golden(name, form):
     g = load_golden(name)
-    m, _ = model_for(g["cfg"], g["seed"], g["method"], g["cfm_method"], g["sigma"], bf16x6=True)
-    assert m.flowhigh.vocoder.bf and m.flowhigh.vocoder.wino_flag == 16
+    m, _ = model_for(g["cfg"], g["seed"], g["method"], g["cfm_method"], g["sigma"], form=form)
+    voc = m.flowhigh.vocoder
+    assert voc.form == form and voc.bf == (form == "bf16x6") and voc.wino_flag == (16 if voc.bf else 0)
     out, st = m.generate_batch([g["audio"]], g["sr_in"], 48000, g["steps"], noise=torch.from_numpy(g["noise"]),
                                return_stages=True)
     assert int(st["cr"][0].item()) == g["cr"]
@@ -506,8 +510,8 @@ def test_bf16x6_full_size_vs_oracle_and_vs_fp32_form():
     of the same size and the two forms differ by rounding only)."""
     torch.set_num_threads(min(16, max(1, torch.get_num_threads())))
     cfg = synth.SYNTH_CFG
-    m16, sd = model_for(cfg, 0, "euler", bf16x6=True)
-    m32, _ = model_for(cfg, 0, "euler")
+    m16, sd = model_for(cfg, 0, "euler", form="bf16x6")
+    m32, _ = model_for(cfg, 0, "euler", form="winograd")
     audio = synth.lowres_clip(0, 10.0, 12000)
     noise = synth.prior_noise(0, 1000)
     o16, s16 = m16.generate_batch([audio], 12000, 48000, 1, noise=noise, return_stages=True)
@@ -522,9 +526,10 @@ def test_bf16x6_full_size_vs_oracle_and_vs_fp32_form():
     assert e16 <= 3.0 * e32 + 2e-6                  # fp32-grade, not merely inside the bar
 
 
-def test_bf16x6_batch_ragged_and_chunked_invariants_bitwise():
+@pytest.mark.parametrize("form", ["bf16x6", "winograd"])
+def test_named_conv_form_batch_ragged_and_chunked_invariants_bitwise(form):
     cfg = synth.SYNTH_CFG
-    m, _ = model_for(cfg, 0, "euler", bf16x6=True)
+    m, _ = model_for(cfg, 0, "euler", form=form)
     secs = [0.5, 1.31, 0.5, 2.2]
     clips = [synth.lowres_clip(240 + i, s_, 12000) for i, s_ in enumerate(secs)]
     noise = [synth.prior_noise(240 + i, (len(c) * 4) // 480) for i, c in enumerate(clips)]
@@ -557,16 +562,23 @@ def test_bench_prints_one_contract_line(args, workload):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "roofline_hbm", "cpu_baseline"):
         assert k in line, k
-    assert workload in line["config"]["workload"] and line["n_gpus"] == 1 and line["dtype"] == "f32"
+    form = line["config"]["conv_form"]
+    assert workload in line["config"]["workload"] and line["n_gpus"] == 1
+    assert line["dtype"] == "f32" if form != "bf16x6" else line["dtype"].startswith("f32 in / out / accumulate")
     clips = line["config"]["clips_per_gpu"]
     assert abs(line["value"] - clips * 10.0 / (line["ms_per_step"] / 1e3)) / line["value"] < 0.02
     rl, rh = line["roofline"], line["roofline_hbm"]
-    assert rl["bound"] == "mfma" and 0.2 < rl["frac"] <= 1.0 and abs(rl["frac"] - rl["achieved"] / 157.3) < 1e-3
-    assert rl["achieved"] < rl["algorithmic_equiv"] and rl["conv_ms_per_step"] < line["ms_per_step"]
+    assert rl["bound"] == "mfma" and 0.1 < rl["frac"] <= 1.0 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+    assert rl["peak"] in (157.3, 2500.0) and rl["conv_ms_per_step"] < line["ms_per_step"]
+    fam = rl["by_family"]
+    assert fam and next(iter(fam)) in ("wino54", "wino54_bf16x6") and all(0.0 < f["frac"] <= 1.0 for f in fam.values())
+    assert abs(sum(f["ms_per_step"] for f in fam.values()) - rl["conv_ms_per_step"]) < 0.05 * rl["conv_ms_per_step"]
+    assert sum(f["launches_per_step"] for f in fam.values()) == rl["all_conv"]["launches_per_step"]
+    assert rl["all_conv"]["executed_fp32_equiv_tflops"] < rl["all_conv"]["algorithmic_equiv"]
     assert rh["bound"] == "hbm" and 0.1 < rh["frac"] <= 1.0 and rh["act_ms_per_step"] < line["ms_per_step"]
     if "--config" not in args:
-        alt = line["alt_conv_bf16x6"]
-        assert alt["max_abs_diff_vs_fp32_mfma_waveform"] <= 5e-5 and alt["value"] > 0
+        alt = line["alt_conv_form"]
+        assert alt["conv_form"] != form and alt["max_abs_diff_vs_headline_waveform"] <= 5e-5 and alt["value"] > 0
 
 
 # ------------------------------------------------------------------------------------------

@@ -1,7 +1,8 @@
 """GPU: parity headroom across weight regimes (trained-weight parity cannot be pinned: SURVEY.md 8c "Weights").  For every
 regime the oracle's float32 run is compared with its float64 run -- the reference's own rounding noise -- and every conv
 form of the HIP vocoder must stay within 3 x that noise of the float64 oracle wherever the noise is below 3e-5 (where it is
-not, the reference itself does not reproduce its float64 result to the 1e-4 bar).  Full table: profiles/r05_regime_sweep.txt
+not, the reference itself does not reproduce its float64 result to the 1e-4 bar).  Forms: bf16x6 (default), winograd, f43, direct.
+Full table: profiles/r06_regime_sweep.txt
 (tests/tools/regime_sweep.py)."""
 import sys
 from pathlib import Path

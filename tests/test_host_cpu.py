@@ -342,7 +342,7 @@ def test_weight_blob_gives_the_packers_tensors_bit_for_bit(tmp_path, cfgname, mo
     sd, cfg_read = read_checkpoints(tmp_path)
     ref_net, ref_voc = FlowNet(sd, "cpu"), Vocoder(cfg_read, sd, "cpu")
     srcs = {f: weights.file_digest(tmp_path / f) for f in CKPT_FILES}
-    store = weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(False), sources=srcs)
+    store = weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(info["form"]), sources=srcs)
     assert store is not None and store.cfg == cfg_read
     net, voc = FlowNet(None, "cpu", store=store), Vocoder(store.cfg, None, "cpu", store=store)
     for a, b in ((ref_net, net), (ref_voc, voc)):
@@ -357,26 +357,38 @@ def test_weight_blob_gives_the_packers_tensors_bit_for_bit(tmp_path, cfgname, mo
     # other checkpoint content, other layout switches: not used
     assert weights.WeightStore.open(info["blob"], "cpu", sources=dict(srcs, **{CKPT_FILES[1]: "0" * 32})) is None
     monkeypatch.setenv("FH_WINO54", "0")
-    assert weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(False)) is None
+    assert weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(info["form"])) is None
     assert "layout switches" in weights.WeightStore.why
+    monkeypatch.delenv("FH_WINO54")
+    # ... another conv form: not used either; a truncated copy does not open at all; --verify finds nothing wrong with the original
+    other = "winograd" if info["form"] != "winograd" else "direct"
+    assert weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(other)) is None
+    cut = tmp_path / "cut.blob"
+    cut.write_bytes(Path(info["blob"]).read_bytes()[:-4096])
+    assert weights.WeightStore.open(cut, "cpu") is None and "truncated" in weights.WeightStore.why
+    (tmp_path / "short.blob").write_bytes(weights.MAGIC + b"\x10\x00")
+    assert weights.WeightStore.open(tmp_path / "short.blob", "cpu") is None
+    assert convert.verify(tmp_path) == []
+    raw = bytearray(Path(info["blob"]).read_bytes())
+    raw[-5000] ^= 1                                   # one flipped bit in the tensor bytes
+    (tmp_path / "rot.blob").write_bytes(bytes(raw))
+    assert any("digest" in p for p in convert.verify(tmp_path, tmp_path / "rot.blob"))
 
 
 def test_plan_switches_are_read_when_the_model_is_built(monkeypatch):
-    """FH_WINO_SPLITK / FH_UPS_FUSE / FH_FUSE_TAIL / FH_AMP_FUSE_ACT / FH_AMP_INTERLEAVE shape launch plans (the first one also the
-    order of additions of short clips): a model takes them as they are when it is BUILT (Vocoder.sw) and plans with that
-    snapshot for its whole life, whatever the environment says later."""
-    for var in ("FH_WINO_SPLITK", "FH_UPS_FUSE", "FH_FUSE_TAIL", "FH_AMP_FUSE_ACT", "FH_AMP_INTERLEAVE"):
+    """FH_WINO_SPLITK / FH_UPS_FUSE / FH_AMP_INTERLEAVE shape launch plans (the first one also the order of additions of short
+    clips): a model takes them as they are when it is BUILT (Vocoder.sw) and plans with that snapshot for its whole life,
+    whatever the environment says later.  (FH_FUSE_TAIL and FH_AMP_FUSE_ACT left with the forms they switched on: round 6.)"""
+    for var in ("FH_WINO_SPLITK", "FH_UPS_FUSE", "FH_AMP_INTERLEAVE"):
         monkeypatch.delenv(var, raising=False)
     voc = _cpu_vocoder("SYNTH_CFG")
-    assert voc.sw == dict(splitk=True, ups_fuse="1", amp_fuse_act=False, fuse_tail=False, amp_interleave=True)
+    assert voc.sw == dict(splitk=True, ups_fuse=True, amp_interleave=True)
     kinds = [s_[0] for s_ in voc.plan(1, 50)["steps"]]
-    assert "sum" in kinds and "convt" in kinds and "tail" not in kinds and kinds.count("act") == 37
+    assert "sum" in kinds and "convt" in kinds and kinds.count("act") == 37
     monkeypatch.setenv("FH_WINO_SPLITK", "0")
     monkeypatch.setenv("FH_UPS_FUSE", "0")
-    monkeypatch.setenv("FH_FUSE_TAIL", "1")
-    monkeypatch.setenv("FH_AMP_FUSE_ACT", "1")
     voc._plans.clear()
     assert [s_[0] for s_ in voc.plan(1, 50)["steps"]] == kinds                 # the living model does not follow the environment
     voc2 = _cpu_vocoder("SYNTH_CFG")
     kinds2 = [s_[0] for s_ in voc2.plan(1, 50)["steps"]]
-    assert "sum" not in kinds2 and "convt" not in kinds2 and "tail" in kinds2 and kinds2.count("act") == 36 - 12
+    assert "sum" not in kinds2 and "convt" not in kinds2 and kinds2.count("act") == 37

@@ -3,11 +3,13 @@ look like (trained-weight parity cannot be pinned here: SURVEY.md 8c "Weights").
 
 For every regime -- convs2 gain x snake log-parameter spread x conv_post scale (flowhigh_amd/synth.py:
 make_vocoder_state_dict) -- the oracle's vocoder (oracle/ref_cpu.py) runs in float32 and in float64 on the CPU; their
-difference is the REFERENCE'S OWN rounding noise in that regime.  The HIP vocoder runs in its three conv forms
+difference is the REFERENCE'S OWN rounding noise in that regime.  The HIP vocoder runs in its four conv forms
 
-    default   F(5,4) Winograd (>= 96 channels) + the narrow-stage F(5,4) kernel (<= 48 channels)
-    f43       FH_WINO54=0 FH_AMP=0: F(4,3) Winograd everywhere it applies
-    direct    FH_WINO=0: the direct implicit-GEMM form everywhere
+    bf16x6    conv_form='bf16x6' (the default since round 6): the Winograd convs of the wide stages, conv_pre and the first two
+              upsamplers on the BF16 matrix cores over exact three-piece splits; the narrow-stage kernel in fp32
+    winograd  conv_form='winograd': F(5,4) Winograd (>= 96 channels) + the narrow-stage F(5,4) kernel (<= 48 channels), fp32 MFMA
+    f43       ... with FH_WINO54=0 FH_AMP=0: F(4,3) Winograd everywhere it applies
+    direct    conv_form='direct': the direct implicit-GEMM form everywhere
 
 and every form's max-abs distance to the float64 oracle is printed next to that noise.
 
@@ -25,7 +27,8 @@ from flowhigh_amd import synth          # noqa: E402
 from oracle import ref_cpu              # noqa: E402
 
 GAINS, BOUNDS, POSTS = (0.2, 0.4, 0.6), (0.5, 1.5, 2.5), (0.3, 1.0)
-FORMS = {"default": {}, "f43": {"FH_WINO54": "0", "FH_AMP": "0"}, "direct": {"FH_WINO": "0"}}
+FORMS = {"bf16x6": {"FH_CONV_FORM": "bf16x6"}, "winograd": {"FH_CONV_FORM": "winograd"},
+         "f43": {"FH_CONV_FORM": "winograd", "FH_WINO54": "0", "FH_AMP": "0"}, "direct": {"FH_CONV_FORM": "direct"}}
 
 
 def oracle_pair(cfg, sd, mel):
@@ -76,11 +79,11 @@ def main():
     torch.set_num_threads(16)
     print(f"# regime sweep, {width}-CFG (C0 = {cfg['upsample_initial_channel']}), {frames} frames, vocoder output (pre post-processing)")
     print("# max |.| over the waveform: oracle fp32 vs fp64 (its own noise), then HIP form vs oracle fp64; bar = 1e-4")
-    print(f"{'gain':>5} {'snake':>6} {'post':>5} {'|wav|':>7} {'noise':>9} {'default':>9} {'f43':>9} {'direct':>9}  default/noise")
+    print(f"{'gain':>5} {'snake':>6} {'post':>5} {'|wav|':>7} {'noise':>9} {'bf16x6':>9} {'winograd':>9} {'f43':>9} {'direct':>9}  bf16x6/noise")
     for r in sweep(cfg, frames):
-        ratio = r["default"] / max(r["noise"], 1e-12)
-        print(f"{r['gain']:5.1f} {r['bound']:6.1f} {r['post']:5.1f} {r['amp']:7.3f} {r['noise']:9.2e} {r['default']:9.2e} {r['f43']:9.2e} "
-              f"{r['direct']:9.2e}  {ratio:6.1f}", flush=True)
+        ratio = r["bf16x6"] / max(r["noise"], 1e-12)
+        print(f"{r['gain']:5.1f} {r['bound']:6.1f} {r['post']:5.1f} {r['amp']:7.3f} {r['noise']:9.2e} {r['bf16x6']:9.2e} {r['winograd']:9.2e} "
+              f"{r['f43']:9.2e} {r['direct']:9.2e}  {ratio:6.1f}", flush=True)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 float64 F.conv1d.  python tests/tools/wino_fuzz.py [n_cases] [seed] [bf | f54 | f54bf]
 bf: the three-piece bf16 form (tile_cfg | FH_WINO_BF16X6, weights split by vocoder.split_bf3), same tolerance.
 f54: fh_conv_wino54_f32 (the F(5,4) kernel: groups of 4 taps, 128 / 96 / 64-row tiles), same tolerance.
-f54bf: the F(5,4) kernel in the three-piece bf16 form (round 6: 128 / 96 / 64-row tiles), the F(5,4) tolerance."""
+f54bf: the F(5,4) kernel in the three-piece bf16 form (round 6: 96 / 64-row tiles), the F(5,4) tolerance."""
 import sys, random, torch, torch.nn.functional as F
 sys.path.insert(0, '.')
 from flowhigh_amd import hip, vocoder as V
@@ -33,7 +33,7 @@ for case in range(n_cases):
     wcfg, cpad = V.pick_wino54_tile(c, BF) if F54 else V.pick_wino_tile(c)
     if F54 and rng.random() < 0.3:                                  # (any tile height that divides cout_pad)
         wcfg = rng.choice([t for t in (V.WINO_F54, V.WINO_F54 | 1, V.WINO_F54 | 2, V.WINO_F54 | 3) if cpad % V._WINO_TILES[t][0] == 0
-                           and not (t == V.WINO_F54 | 3 and (cpad % 96 == 0 or BF))])      # (the 48-row block: only where no 96-row block fits; no bf16 x 6 form)
+                           and not (t == V.WINO_F54 | 3 and (cpad % 96 == 0 or BF)) and not (BF and t == V.WINO_F54)])      # (the 48-row block: only where no 96-row block fits; no bf16 x 6 form)
     if wcfg == 0 and rng.random() < 0.3:
         wcfg = rng.choice([4, 5, 6] if cpad % 128 == 0 else [4, 5])
     pack = V.pack_wino54_weight if F54 else V.pack_wino_weight

@@ -12,8 +12,8 @@ for (C,k,d,L,B) in [(48,11,5,2000,1),(48,3,1,644,2),(40,9,4,777,1),(48,11,1,320,
     xd, rd, bd = x.to(DEV), r1.to(DEV), b.to(DEV)
     out = torch.full_like(xd, float("nan"))
     ud = V.pack_amp_weight(w, C).to(DEV)
-    g = V.make_amp_group([V.make_amp_seg(xd, ud, None, k)], bd, [rd], out, L, scale=0.5)
-    keep = V.amp_actconv([g], B, C, d, DEV, act=False)
+    g = V.make_amp_group([V.make_amp_seg(xd, ud, k)], bd, [rd], out, L, scale=0.5)
+    keep = V.amp_actconv([g], B, C, d, DEV)
     torch.cuda.synchronize()
     err = (out.cpu()-ref).abs()
     bad = (err > 2e-5) | torch.isnan(err)

@@ -12,7 +12,7 @@ for (c, k, d, L, B, pm) in [(192, 11, 1, 3932, 2, False), (192, 11, 1, 3933, 2, 
     ref = F.conv1d(x.double(), w.double(), b.double(), dilation=d, padding=(k - 1) // 2 * d).float()
     xd = (V.to_phase_major(x, d) if pm else x).to(DEV)
     u = V.pack_wino54_weight(w, c)
-    for cfg, uu in ((V.WINO_F54 | 1, u), (V.WINO_F54 | 0 | V.WINO_BF16X6, V.split_bf3(u)), (V.WINO_F54 | 1 | V.WINO_BF16X6, V.split_bf3(u)),
+    for cfg, uu in ((V.WINO_F54 | 1, u), (V.WINO_F54 | 1 | V.WINO_BF16X6, V.split_bf3(u)),
                     (V.WINO_F54 | 2 | V.WINO_BF16X6, V.split_bf3(u))):
         if c % V._WINO_TILES[cfg & (V.WINO_F54 | 15)][0]:
             continue

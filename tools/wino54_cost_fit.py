@@ -32,7 +32,7 @@ def block_time(c, tile, k=11, bf=False):
 
 for bf in ([False, True] if "bf" in sys.argv[1:] else [False]):
     res = {}
-    for tile in (0, 1, 2):
+    for tile in ((1, 2) if bf else (0, 1, 2)):
         t1, t2 = block_time(384, tile, bf=bf), block_time(768, tile, bf=bf)
         k1, k2 = 384 // 16 * 3, 768 // 16 * 3
         a = (t2 - t1) / (k2 - k1)
