@@ -45,7 +45,7 @@ typedef __bf16 v_bf16x2 __attribute__((ext_vector_type(2)));
 // ---- BF = true: the same contraction on the BF16 matrix cores, fp32-grade (round 6) --------------------------------------------
 // Every fp32 operand is split EXACTLY into three bf16 pieces, x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m),
 // round to nearest even, both subtractions exact in fp32), and a 16-channel k-block is six v_mfma_f32_32x32x16_bf16 over the piece
-// pairs (l h), (h l), (m m), (m h), (h m), (h h) into the same fp32 accumulator: 6 x 32 matrix-pipe cycles against 8 x 64 of the
+// pairs (h h), (h m), (h l), (m h), (m m), (l h) into the same fp32 accumulator: 6 x 32 matrix-pipe cycles against 8 x 64 of the
 // fp32 form; the dropped pairs are <= 2^-24 |a b| (conv_wino.hip, tools/micro/bf16x6.hip).  The weights arrive pre-split
 // (packing.split_bf3 of pack_wino54_weight: [cin/16][tap group][8][cout_pad][3 pieces][16] bf16 = 96 bytes per row and chunk), the
 // B operands are transformed exactly as in the fp32 form (same fma chain per element: same V bits) and split in registers.
@@ -365,11 +365,12 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
   // model loop and costs 12 MT registers the 96 / 128-row blocks do not have (tools/micro/bf54.hip)
   u32x4 a3[BF ? MT : 1][3];
   const int a3_lane = (l31 * V_A3 + lh * 4) * 4;
-  auto load_a3 = [&](const VSeg& S, int chunk, int g, bool valid) {
+  // pieces = bit mask of the pieces to request (1 h, 2 m, 4 l)
+  auto load_a3 = [&](const VSeg& S, int chunk, int g, bool valid, int pieces = 7) {
     const float* up = uni(S.u + ((size_t)((chunk * S.ngrp + g) * 8 + xi) * cout_pad + co0) * V_A3);
     const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? BM * V_A3 * 4 : 0);
     // (the lane offset passes through an empty asm: the 3 MT offsets are then immediates of the loads (row tile 2 on: one add),
-    // not 3 MT loop-invariant registers carried -- and, in the 96-row block of the 4-byte loader, spilled -- through the K loop)
+    // not 3 MT loop-invariant registers carried through the K loop)
     int o = a3_lane;
     asm volatile("" : "+v"(o));
 #pragma unroll
@@ -377,7 +378,8 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
       const int om = mt < 2 ? o : o + 2 * 32 * V_A3 * 4;
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc)
-        a3[mt][pc] = __builtin_amdgcn_raw_buffer_load_b128(r, om + (mt & 1) * 32 * V_A3 * 4 + 32 * pc, 0, 0);
+        if (pieces & (1 << pc))
+          a3[mt][pc] = __builtin_amdgcn_raw_buffer_load_b128(r, om + (mt & 1) * 32 * V_A3 * 4 + 32 * pc, 0, 0);
     }
   };
   // L2 warm-up of the A tiles of the NEXT chunk (all its tap groups, this wave's xi), as in conv_wino.hip
@@ -463,18 +465,23 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
             }
             v_bf16x8 bh, bm, bl;
             v_split8(v, bh, bm, bl);
-            // (piece pairs outermost, row tiles inside: MT independent accumulators between two MFMAs on the same one)
+            // (piece pairs outermost, row tiles inside: MT independent accumulators between two MFMAs on the same one.  The
+            // weights' pieces are used in the order h h h m m l, and each is requested for the NEXT tap group as soon as the group's
+            // second column is through with it -- h three pairs, m one pair ahead of the end of the MFMAs, and in the order the next
+            // group needs them: one register set, yet most of the L2 round trip runs under this group's matrix work)
+            const bool same_chunk = g + 1 < GC;
+            const int nc = same_chunk ? c : c + 1, ng = same_chunk ? g + 1 : 0;
+            const bool nv = same_chunk || has_next;
 #pragma unroll
             for (int pp = 0; pp < 6; ++pp) {
-              constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};      // small terms first
+              constexpr int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {0, 1, 2, 0, 1, 0};      // (h h) (h m) (h l) (m h) (m m) (l h)
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v_bf16x8, a3[mt][pa[pp]]),
                                                                       pb[pp] == 0 ? bh : pb[pp] == 1 ? bm : bl, acc[mt][nt], 0, 0, 0);
+              if (nt == 1 && (pp == 2 || pp == 4 || pp == 5)) load_a3(S, nc, ng, nv, pp == 2 ? 1 : pp == 4 ? 2 : 4);
             }
           }
-          const bool same_chunk = g + 1 < GC;        // the A registers are free: request the next tap group's pieces
-          load_a3(S, same_chunk ? c : c + 1, same_chunk ? g + 1 : 0, same_chunk || has_next);
         }
       } else {
       fetch(0);

@@ -322,12 +322,15 @@ class FlowHighSR:
             # ('auto': a blob of the default form is taken as it is -- the probe needs the checkpoint; a blob written by
             # `python -m flowhigh_amd.convert --probe` on a GPU box already holds the form the probe chose)
             tags = [weights.format_tag(form)] + ([weights.format_tag("direct")] if form_auto else [])
-            store = None
+            store, why = None, None
             for tag in tags:
                 store = weights.WeightStore.open(blob, hip.norm_device(dev), expect_format=tag, sources=srcs)
                 if store is not None:
                     form = json.loads(tag)["form"]
                     break
+                why = why or weights.WeightStore.why          # (the reason the blob is not one of the FIRST form asked for)
+            if store is None:
+                weights.WeightStore.why = why
             if store is not None:
                 try:
                     return cls(flowhigh=FLowHigh(None, store.cfg, dev, store=store, conv_form=form), **kwargs)

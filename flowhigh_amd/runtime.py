@@ -125,12 +125,20 @@ def sync_act_blocks(device, group=None, bf=None):
         from .planner import use_bf16x6
         bf = use_bf16x6()
     fixed = parse_act_blocks(os.environ.get("FH_ACT_BLOCKS"))
-    if fixed is not None or not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return calibrate_act_occupancy(dev, bf=bf)
 
+    # EVERY rank enters the collective, whatever its own FH_ACT_BLOCKS says (a variable exported on some ranks only must not
+    # leave the others waiting in the broadcast: ADVICE r05): rank 0 of the group decides -- its FH_ACT_BLOCKS if it has one,
+    # else its measurement -- and every rank takes that.
     def measure():
+        if fixed is not None:
+            return [{0: 1.0, fixed: 0.5}] * 2 if fixed != 0 else [{0: 1.0}] * 2        # (pick_act_blocks -> `fixed`)
         return [{b: measure_act_conv_pair(dev, b, bf=bf) for b in ACT_BLOCKS_CHOICES} for _ in range(2)]
     choice, passes = decide_act_blocks(measure, group=group, collective=True)
+    if fixed is not None and fixed != choice:
+        import logging
+        logging.getLogger("flowhigh_amd").warning("FH_ACT_BLOCKS=%s on this rank, rank 0 of the group chose %s: taking rank 0's", fixed, choice)
     calibrate_act_occupancy.last_measurement = passes
     return calibrate_act_occupancy(dev, force=True, act_blocks=choice, bf=bf)
 

@@ -359,11 +359,13 @@ class Vocoder:
         # 3 more (decimated) samples per side and conv.  Such rounding-level influence is almost always absorbed by the
         # next layer's own rounding -- chunks with the taps-only halo matched bit for bit in every fp32 test -- but
         # "almost" is not the contract (and the bf16 x 6 form, with more rounding steps, did show it): the halo covers it.
-        # (F(4,3): 6 inputs per 4 outputs, 3 beyond the taps; F(5,4): 8 per 5, 4 beyond)
+        # (F(4,3): 6 inputs per 4 outputs, 3 beyond the taps.  F(5,4): 8 per 5; its odd kernels are packed into ceil(k / 4) groups of
+        # 4 taps with the zero tap at the END, so a tile reads inputs 5 n - center .. 5 n + 4 ngrp + 3 - center: output 5 n's rounding
+        # depends on up to 5 samples past its last real tap on the right (4 on the left): 5 per conv, not 4 -- ADVICE r05)
         reach1 = sum((d + 1) if self.resblock == "1" else d for d in dmax)
         h = 3.0 + 6.0                                   # conv_post (7 taps) + activation_post, in output samples
         for i in reversed(range(len(self.rates))):
-            h += per_stage + (4 if self.stages[i]["w54"] or self.stages[i]["amp"] else 3) * reach1      # residual stack at this stage's rate
+            h += per_stage + (5 if self.stages[i]["w54"] or self.stages[i]["amp"] else 3) * reach1      # residual stack at this stage's rate
             h = h / self.rates[i] + self.up_k[i] / self.rates[i] + 1.0 + 3.0     # ... seen from the transposed conv's input
         h += 3.0 + 3.0                                  # conv_pre
         align, rate = 4, 1

@@ -183,6 +183,39 @@ def test_from_local_reads_reference_checkpoint_files(tmp_path):
         FlowHighSR.from_local(tmp_path, "cuda")
 
 
+def test_conv_form_auto_probes_the_loaded_weights(caplog):
+    """conv_form='auto' (the default of from_local / from_pretrained, reference flowhighsr.py:110-149): on a checkpoint whose
+    convs2 gain is 0.6 and conv_post scale 1.0 -- the hardest regime of the sweep that still has a meaningful fp32 reference -- the
+    load-time probe logs its estimate (default form against direct form on a 20-frame mel), keeps the default form or switches to
+    the direct one by the 3e-5 rule, and the model it leaves stays under the 1e-4 bar against the FLOAT64 oracle."""
+    import logging
+    cfg = synth.SYNTH_CFG
+    sd = synth.make_state_dict(cfg, 0)
+    voc_sd = synth.make_vocoder_state_dict(cfg, seed=1, convs2_gain=0.6, snake_bound=0.5, post_gain=1.0)
+    sd.update(voc_sd)
+    with caplog.at_level(logging.INFO, logger="flowhigh_amd"):
+        fh = FLowHigh(sd, cfg, "cuda", conv_form="auto")
+    pr = fh.conv_form_probe
+    assert pr is not None and 0.0 < pr["estimate"] < 1e-3 and pr["limit"] == 3e-5 and pr["frames"] == 20
+    assert pr["chosen"] == ("direct" if pr["estimate"] > pr["limit"] else pr["default"]) == fh.conv_form
+    assert any("conv_form='auto'" in r.getMessage() and "probe" in r.getMessage() for r in caplog.records)
+    print(f"probe: {pr}")
+    mel = torch.randn(1, 20, 256, generator=torch.Generator().manual_seed(175)) * 2.0 - 3.0
+    wav = fh.vocoder.forward(mel.cuda()).cpu()
+    torch.set_num_threads(min(16, max(1, torch.get_num_threads())))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in voc_sd.items()}
+    o64 = ref_cpu.bigvgan_forward(sd64, cfg, mel.transpose(1, 2).contiguous().double()).squeeze(1)
+    err = float((wav.double() - o64).abs().max())
+    print(f"'auto' -> {fh.conv_form}: {err:.2e} from the float64 oracle")
+    assert err <= TOL_WAVEFORM
+    # a limit of zero forces the switch: the model then runs the direct form (no Winograd launch in its plan)
+    fh.vocoder = __import__("flowhigh_amd").vocoder.Vocoder(cfg, sd, "cuda", conv_form="bf16x6", act_blocks=fh.vocoder.act_blocks)
+    assert fh.probe_conv_form(sd, limit=0.0)["chosen"] == "direct" == fh.conv_form
+    assert {n for n, _, _ in fh.vocoder.plan(1, 20)["conv_launches"]} == {"direct"}
+    # no probe for a named form
+    assert FLowHigh(sd, cfg, "cuda", conv_form="winograd").conv_form_probe is None
+
+
 def test_unsupported_options_raise():
     m, _ = model_for(synth.TINY_CFG, 0)
     audio = synth.lowres_clip(0, 0.3, 12000)

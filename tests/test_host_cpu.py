@@ -375,6 +375,56 @@ def test_weight_blob_gives_the_packers_tensors_bit_for_bit(tmp_path, cfgname, mo
     assert any("digest" in p for p in convert.verify(tmp_path, tmp_path / "rot.blob"))
 
 
+def test_conv_form_keyword_and_environment(monkeypatch):
+    """conv_form = 'auto' | 'winograd' | 'bf16x6' | 'direct' (FlowHighSR.from_local / FLowHigh / Vocoder keyword, reference
+    constructor flowhighsr.py:110-137): keyword > FH_CONV_FORM > the older switches > 'auto' = the default form; the form
+    decides which kernels a model's weights are packed for, and a blob of another form is refused."""
+    from flowhigh_amd import planner as P, weights
+    from flowhigh_amd.vocoder import Vocoder
+    for var in ("FH_CONV_FORM", "FH_WINO", "FH_CONV_BF16X6"):
+        monkeypatch.delenv(var, raising=False)
+    assert P.resolve_conv_form() == (P.DEFAULT_CONV_FORM, True) == P.resolve_conv_form("auto")
+    assert P.resolve_conv_form("direct") == ("direct", False) and P.resolve_conv_form(None, bf16x6=False) == ("winograd", False)
+    monkeypatch.setenv("FH_CONV_FORM", "winograd")
+    assert P.resolve_conv_form() == ("winograd", False) and P.resolve_conv_form("bf16x6") == ("bf16x6", False)     # keyword wins
+    monkeypatch.delenv("FH_CONV_FORM")
+    monkeypatch.setenv("FH_WINO", "0")
+    assert P.resolve_conv_form() == ("direct", False) and not P.use_wino(768, 1) and P.use_wino(768, 1, "winograd")
+    monkeypatch.delenv("FH_WINO")
+    monkeypatch.setenv("FH_CONV_BF16X6", "0")
+    assert P.resolve_conv_form() == ("winograd", False)
+    monkeypatch.delenv("FH_CONV_BF16X6")
+    with pytest.raises(ValueError):
+        P.resolve_conv_form("fp8")
+    cfg, sd = synth.SYNTH_CFG, synth.make_vocoder_state_dict(synth.SYNTH_CFG, 1)
+    forms = {f: Vocoder(cfg, sd, "cpu", conv_form=f) for f in ("winograd", "bf16x6", "direct")}
+    for f, voc in forms.items():
+        assert voc.form == f and not voc.form_auto and voc.bf == (f == "bf16x6")
+        wide, narrow = voc.stages[0], voc.stages[-1]
+        e = wide["blocks"][0]["c1"][0]
+        assert ("u" in e) == (f != "direct") and ("w" in e) == (f == "direct")
+        assert ("ua" in narrow["blocks"][0]["c1"][0]) == (f != "direct")            # the narrow-stage kernel: fp32 in both Winograd forms
+        if f != "direct":
+            assert e["u"].dtype == (torch.int16 if f == "bf16x6" else torch.float32)
+            assert wide["w54"] and wide["wcfg"] == (P.WINO_F54 | 1 if f == "bf16x6" else P.WINO_F54 | 0)
+    assert Vocoder(cfg, sd, "cpu").form == P.DEFAULT_CONV_FORM and Vocoder(cfg, sd, "cpu").form_auto
+    # the bf16 x 6 launch plan: wide stages on the F(5,4) bf16 x 6 kernel (96- / 64-row blocks only), narrow ones on the amp kernel
+    fams = {n for n, _, _ in forms["bf16x6"].plan(1, 100)["conv_launches"]}
+    assert fams == {"wino54_bf16x6", "wino43_bf16x6", "amp", "direct"}
+    assert {n for n, _, _ in forms["winograd"].plan(1, 100)["conv_launches"]} == {"wino54", "wino43", "amp", "direct"}
+    assert {n for n, _, _ in forms["direct"].plan(1, 100)["conv_launches"]} == {"direct"}
+    # a store that holds another form's tensors is refused at construction
+    st = weights.WeightStore("cpu")
+    st.form = "winograd"
+    with pytest.raises(ValueError, match="packed for"):
+        Vocoder(cfg, sd, "cpu", conv_form="bf16x6", store=st)
+    assert weights.format_tag("bf16x6") != weights.format_tag("winograd") != weights.format_tag("direct")
+    monkeypatch.setenv("FH_AMP", "1")
+    tag = weights.format_tag("bf16x6")
+    monkeypatch.delenv("FH_AMP")
+    assert tag == weights.format_tag("bf16x6")                # unset and "1" are the same setting
+
+
 def test_plan_switches_are_read_when_the_model_is_built(monkeypatch):
     """FH_WINO_SPLITK / FH_UPS_FUSE / FH_AMP_INTERLEAVE shape launch plans (the first one also the order of additions of short
     clips): a model takes them as they are when it is BUILT (Vocoder.sw) and plans with that snapshot for its whole life,

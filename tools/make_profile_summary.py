@@ -26,11 +26,16 @@ o = [f"# Round {rnd} profile summary (1 x MI355X, B = {bsuf[1:]}, 10 s clips, 12
      f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {prof['steps']} --warmup {prof['warmup']} --no-cpu-baseline --no-alt`",
      f"(raw: `{tag}_kernel_stats_bench_{bsuf}.csv`; HBM traffic PMC passes `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of `bench.py --steps 1 --warmup 1`:",
      "`conv_hbm_bytes_per_launch.json`, `act_hbm_bytes_per_launch.json`; reproduce with `tools/profile_round.sh` on the GPU box).", "",
+     f"* conv form `{line['config'].get('conv_form')}` (dtype: {line['dtype']}).  Dominant kernel family `{next(iter(rl['by_family']))}`: {rl['kernel']}: "
+     f"{rl['launches_per_step']} launches per step, {rl['avg_launch_us']} us each (HIP events, un-profiled run; profiled run: {prl['avg_launch_us']} us) "
+     f"-> **{rl['achieved']} TFLOP/s on its matrix instructions = {rl['frac']} of the {rl['peak']} TFLOP/s peak**.",
      f"* all conv launches (conv_wino54_kernel + amp_actconv_kernel + conv_wino_kernel + conv_mfma_kernel): {ccalls} launches, average duration **{ctot / ccalls / 1e3:.1f} us** under the "
-     f"profiler; bench.py HIP events in the same run: {prl['avg_launch_us']} us; un-profiled bench run: {rl['avg_launch_us']} us "
-     f"-> **{rl['achieved']} TFLOP/s executed on the matrix cores = {rl['frac']} of the 157.3 TFLOP/s fp32 MFMA peak** "
-     f"({rl['executed_gflop_per_launch']} GFLOP per launch; direct-form equivalent {rl['algorithmic_equiv']} TFLOP/s = {rl['algorithmic_equiv_frac']}: "
+     f"profiler; bench.py HIP events in the same run: {prl['all_conv']['avg_launch_us']} us; un-profiled bench run: {rl['all_conv']['avg_launch_us']} us "
+     f"-> {rl['all_conv']['executed_fp32_equiv_tflops']} TFLOP/s executed in fp32-equivalent FLOPs = {rl['all_conv']['frac_of_fp32_mfma_peak']} of the 157.3 TFLOP/s fp32 MFMA peak "
+     f"({rl['all_conv']['executed_gflop_per_launch']} GFLOP per launch; direct-form equivalent {rl['all_conv']['algorithmic_equiv']} TFLOP/s = {rl['all_conv']['algorithmic_equiv_frac']}: "
      f"the Winograd launches do 1.6 ceil(k/4) (F(5,4)) or 1.5 ceil(k/3) (F(4,3)) instead of k multiply-adds per output).",
+     "* by kernel family (un-profiled bench run, HIP events): " + "; ".join(
+         f"`{k}` {v['launches_per_step']} launches {v['ms_per_step']} ms {v['matrix_tflops']} TFLOP/s ({v['matrix_instructions']}) = {v['frac']} of {v['peak']}" for k, v in rl['by_family'].items()) + ".",
      f"* HBM traffic per conv launch (PMC, corrected as the guide prescribes): {tconv['bytes_per_launch'] / 1e6:.1f} MB.",
      f"* all Activation1d launches (act1d_strip_kernel): {acalls} launches, average duration **{atot / acalls / 1e3:.1f} us** under the profiler; "
      f"bench.py HIP events in the same run: {prh['avg_launch_us']} us; un-profiled: {rh['avg_launch_us']} us -> "
