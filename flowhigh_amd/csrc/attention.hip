@@ -37,8 +37,8 @@ struct Stream {
 };
 
 __device__ __forceinline__ void merge_streams(Stream& a, const float (&b0)[16], const float (&b1)[16], float mb, float lb) {
-  const float m = fmaxf(a.m, mb);
-  const float c0 = expf(a.m - m), c1 = expf(mb - m);      // exp(-inf) = 0: a stream that saw no key contributes nothing
+  const float m = fmaxf(a.m, mb);                          // (maxima are in the base-2 domain of the tile loop)
+  const float c0 = __builtin_amdgcn_exp2f(a.m - m), c1 = __builtin_amdgcn_exp2f(mb - m);      // exp2(-inf) = 0: a stream that saw no key contributes nothing
   a.l = __fmaf_rn(lb, c1, __fmul_rn(a.l, c0));
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -105,31 +105,44 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
       for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[qq][e], s, 0, 0, 0);
     }
-    // online softmax for this lane's query; key of reg r = k0 + (r&3) + 8 (r>>2) + 4 lh
+    // online softmax for this lane's query, in base 2 (scores arrive multiplied by scale * log2(e): one v_exp_f32 per
+    // probability instead of the libm expf's ~10 instructions -- matrix and vector instructions share the fp32 ALUs, so every
+    // one of the ~420 vector instructions per tile cost matrix time: round 6); key of reg r = k0 + (r&3) + 8 (r>>2) + 4 lh
     float mx = -INFINITY;
+    if (k0 + 32 <= n) {                              // (whole tile: no key mask -- wave-uniform)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float v = __fmul_rn(s[r], scale);
-      v = key < n ? v : -INFINITY;
-      s[r] = v;
-      mx = fmaxf(mx, v);
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __fmul_rn(s[r], scale);
+        mx = fmaxf(mx, s[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = key < n ? __fmul_rn(s[r], scale) : -INFINITY;
+        s[r] = v;
+        mx = fmaxf(mx, v);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(S.m, mx);            // finite: every tile has >= 1 valid key
-    const float corr = expf(S.m - m_new);          // exp(-inf) = 0 on the first tile
+    const float corr = __builtin_amdgcn_exp2f(S.m - m_new);        // exp2(-inf) = 0 on the first tile
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float p = expf(s[r] - m_new);
+      const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
       s[r] = p;
       psum += p;
     }
     psum += __shfl_xor(psum, 32, 64);
     S.l = __fmaf_rn(S.l, corr, psum);
     S.m = m_new;
+    // (the running maximum settles after a few tiles: when no lane's changed, the 32 multiplications by 1 are skipped --
+    // x * 1 is exact, so the bits are those of the multiplied form)
+    if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { S.o0[r] *= corr; S.o1[r] *= corr; }
+      for (int r = 0; r < 16; ++r) { S.o0[r] *= corr; S.o1[r] *= corr; }
+    }
     // O^T += V^T P^T
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -218,6 +231,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 
 namespace {
 int launch_attention(const float* qkv, float* out, const int* seg, int batch, int n, int heads, float scale, void* stream) {
+  scale *= 1.44269504088896340736f;        // the kernel's softmax runs in base 2: exp(x) = exp2(x log2(e))
   if ((long long)fh_cdiv(n, 128) * heads * batch >= 512) {
     dim3 grid(fh_cdiv(n, 128), heads, batch);
     hipLaunchKernelGGL((attention_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, n, heads, scale, seg);

@@ -261,7 +261,7 @@ def use_wino54(c, form=None):
     64-row tile a quarter; FH_WINO54_H16=0: not there)."""
     if os.environ.get("FH_WINO54", "1") == "0" or not use_wino(c, 1, form):
         return False
-    return c >= int(os.environ.get("FH_WINO54_MIN_C", WINO54_MIN_C)) or (c % 48 == 0 and os.environ.get("FH_WINO54_H16", "1") != "0")
+    return c >= WINO54_MIN_C or (c % 48 == 0 and os.environ.get("FH_WINO54_H16", "1") != "0")
 
 
 def use_amp(c, ks, dils, form=None):
@@ -295,8 +295,7 @@ def plan_switches():
     of that model: a model's launches (and, for FH_WINO_SPLITK, its bits) do not change when the environment does while it
     lives.  (The switches that decide which kernel a stage's weights are packed for -- FH_WINO, FH_WINO54*, FH_AMP,
     FH_CONV_BF16X6 -- are read at construction as well, by use_wino / use_wino54 / use_amp / use_bf16x6.)"""
-    return dict(splitk=os.environ.get("FH_WINO_SPLITK", "1") != "0", ups_fuse=os.environ.get("FH_UPS_FUSE", "1") != "0",
-                amp_interleave=os.environ.get("FH_AMP_INTERLEAVE", "1") != "0")
+    return dict(splitk=os.environ.get("FH_WINO_SPLITK", "1") != "0", ups_fuse=os.environ.get("FH_UPS_FUSE", "1") != "0")
 
 
 def amp_tile_len(d):
@@ -331,17 +330,15 @@ def make_amp_group(segs, bias, res, out, length, scale=1.0):
     return g
 
 
-def amp_tile_list(lens, batch, dilation, interleave=None):
+def amp_tile_list(lens, batch, dilation, interleave=True):
     """The work list of a narrow-stage launch (fh_amp_tile: group, batch item, first output, len): int32 tensor [tiles, 4].
     The launch's persistent blocks take tiles b, b + grid, b + 2 grid, ... of this list.  Order: the groups' tiles dealt
     round-robin (group 0's first tile, group 1's first, ...), so that blocks with neighbouring ids work on tiles of DIFFERENT
     length at any moment: with all tiles of the heaviest group first, every block of the chip ran the same K loop and then
     stored its outputs in the same microseconds (no stores for 10 us, then 138 MB at once: the epilogue's HBM traffic cost a
-    quarter of the launch, tools/exp/amp_ab.sh).  A block still gets the same share of every group.  FH_AMP_INTERLEAVE=0: group
+    quarter of the launch, tools/exp/amp_ab.sh).  A block still gets the same share of every group.  interleave=False: group
     after group (heavy first).  (Both orders, and a layout that deals the tiles to the blocks by weight, longest first, measure
-    the same to +-0.1 %: profiles/r05_amp_ablation.txt item 9.)"""
-    if interleave is None:
-        interleave = os.environ.get("FH_AMP_INTERLEAVE", "1") != "0"
+    the same to +-0.1 %: profiles/r05_amp_ablation.txt item 9; the environment switch for it left in round 6.)"""
     tb = amp_tile_len(dilation)
     per_group = []
     for gi, length in enumerate(lens):
@@ -568,7 +565,7 @@ class _PlanBuilder:
     def amp(self, groups, c, length, dil):
         """Narrow-stage launch (fh_amp_actconv_f32): the groups' convs."""
         B = self.B
-        tiles = amp_tile_list([g.len for g in groups], B, dil, self.v.sw["amp_interleave"]).to(self.v.device)
+        tiles = amp_tile_list([g.len for g in groups], B, dil).to(self.v.device)
         d = hip.to_device_struct_array(groups, self.v.device)
         self.keep += [d, tiles]
         flops = sum(2.0 * c * c * (2 * g.seg[i].center + 1) * length * B for g in groups for i in range(g.nseg))
@@ -964,7 +961,7 @@ def merge_ragged(voc, frames):
                 allg = [g for groups in lst for g in groups]
                 # heavy groups first (the persistent blocks walk the tile list in order), then long ones
                 allg.sort(key=lambda g: (-sum(g.seg[i].ngrp for i in range(g.nseg)), -g.len))
-                tl = amp_tile_list([g.len for g in allg], 1, dil, voc.sw["amp_interleave"])
+                tl = amp_tile_list([g.len for g in allg], 1, dil)
                 off_t = sum(len(b) for b in blobs)
                 raw = tl.numpy().tobytes()
                 blobs.append(raw + bytes(-len(raw) % 16))

@@ -294,7 +294,7 @@ def test_f54_tile_family_is_fixed_by_the_channel_count(monkeypatch):
     16-row MFMA tiles: another summation order than the 32-row-tile blocks) is never an alternative of the launch model where
     a 96-row block fits, so a conv's bits do not depend on batch or length (conv_wino54.hip, vocoder._choose_wino_cfg)."""
     from flowhigh_amd import vocoder as V
-    for var in ("FH_WINO54", "FH_WINO54_MIN_C", "FH_WINO54_H16", "FH_WINO"):
+    for var in ("FH_WINO54", "FH_WINO54_H16", "FH_WINO", "FH_CONV_FORM"):
         monkeypatch.delenv(var, raising=False)
     assert V.pick_wino54_tile(768) == (V.WINO_F54 | 0, 768) and V.pick_wino54_tile(96) == (V.WINO_F54 | 1, 96)
     assert V.pick_wino54_tile(48) == (V.WINO_F54 | 3, 48) and V.pick_wino54_tile(144) == (V.WINO_F54 | 3, 144)
@@ -426,13 +426,13 @@ def test_conv_form_keyword_and_environment(monkeypatch):
 
 
 def test_plan_switches_are_read_when_the_model_is_built(monkeypatch):
-    """FH_WINO_SPLITK / FH_UPS_FUSE / FH_AMP_INTERLEAVE shape launch plans (the first one also the order of additions of short
+    """FH_WINO_SPLITK / FH_UPS_FUSE shape launch plans (the first one also the order of additions of short
     clips): a model takes them as they are when it is BUILT (Vocoder.sw) and plans with that snapshot for its whole life,
-    whatever the environment says later.  (FH_FUSE_TAIL and FH_AMP_FUSE_ACT left with the forms they switched on: round 6.)"""
-    for var in ("FH_WINO_SPLITK", "FH_UPS_FUSE", "FH_AMP_INTERLEAVE"):
+    whatever the environment says later.  (FH_FUSE_TAIL, FH_AMP_FUSE_ACT and FH_AMP_INTERLEAVE left with the forms they switched: round 6.)"""
+    for var in ("FH_WINO_SPLITK", "FH_UPS_FUSE"):
         monkeypatch.delenv(var, raising=False)
     voc = _cpu_vocoder("SYNTH_CFG")
-    assert voc.sw == dict(splitk=True, ups_fuse=True, amp_interleave=True)
+    assert voc.sw == dict(splitk=True, ups_fuse=True)
     kinds = [s_[0] for s_ in voc.plan(1, 50)["steps"]]
     assert "sum" in kinds and "convt" in kinds and kinds.count("act") == 37
     monkeypatch.setenv("FH_WINO_SPLITK", "0")

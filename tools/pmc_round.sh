@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 blocks=$(python3 -c "
 import sys; sys.path.insert(0, '.')
 from flowhigh_amd import vocoder as V
-print(V.calibrate_act_occupancy('cuda:0'))" 2> gpurun_out/calibrate_$tag.err | tail -1)
+print(V.calibrate_act_occupancy('cuda:0', bf=V.use_bf16x6()))" 2> gpurun_out/calibrate_$tag.err | tail -1)
 case "$blocks" in
   0|2|3|4|5) export FH_ACT_BLOCKS=$blocks ;;
   *) echo "calibration failed (got '$blocks', see gpurun_out/calibrate_$tag.err): every run calibrates by itself" >&2; unset FH_ACT_BLOCKS ;;
