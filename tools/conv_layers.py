@@ -22,7 +22,9 @@ p["mel_in"].copy_(mel.transpose(1, 2).to('cuda:0'))
 for _ in range(3):
     voc.run(p)
 torch.cuda.synchronize()
-convs = [s for s in p['steps'] if s[0] in ('conv', 'wino')]
+convs = [s for s in p['steps'] if s[0] in ('conv', 'wino', 'convt', 'amp')]
+launches = p["conv_launches"]                     # (family, executed FLOPs, algorithmic FLOPs) per conv launch: planner
+assert len(convs) == len(launches)
 acc = [0.0] * len(convs)
 R = 10
 for _ in range(R):
@@ -32,19 +34,22 @@ for _ in range(R):
     for i, (a, b) in enumerate(voc.conv_timing):
         acc[i] += a.elapsed_time(b) * 1e3 / R
 voc.conv_timing = None
-tot_f = tot_t = 0.0
-print(f"{'#':>3} {'tile':>8} {'grp':>3} {'cpad':>5} {'n_len':>7} {'blocks':>6} {'GFLOP':>8} {'us':>8} {'TF/s':>7}")
-for i, s in enumerate(convs):
+tot_f = tot_e = tot_t = 0.0
+print(f"{'#':>3} {'family':>14} {'tile':>8} {'grp':>3} {'cpad':>5} {'n_len':>7} {'d':>2} {'blocks':>6} {'alg GFLOP':>9} {'exec GFLOP':>10} {'us':>8} {'exec TF/s':>9}")
+for i, (s, (fam, ex, fl)) in enumerate(zip(convs, launches)):
+    d_ = 1
     if s[0] == 'wino':
-        _, d, ng, cpad, n_len, dil, fl, wcfg, _pm = s[:9]
-        xr, f54, wcfg = wcfg & 32, wcfg & V.WINO_F54, wcfg & 15
+        _, d, ng, cpad, n_len, d_, _fl, wcfg, _pm = s[:9]
+        f54, wcfg = wcfg & V.WINO_F54, wcfg & 15
         bm, bn = V._WINO_TILES[wcfg | f54]
-        blocks = ng * s[9] * (cpad // bm) * V.wino_n_tiles(wcfg | f54, n_len, dil, _pm)
+        blocks = ng * s[9] * (cpad // bm) * V.wino_n_tiles(wcfg | f54, n_len, d_, _pm)
+    elif s[0] == 'amp':
+        _, d, ng, tiles, nt, c, d_ = s[:7]
+        bm, bn, cpad, n_len, blocks = c, V.amp_tile_len(d_), c, p["L"] if False else 0, nt
     else:
-        xr = f54 = 0
-        _, d, ng, cpad, n_len, tcfg, ck, fl = s
+        _, d, ng, cpad, n_len, tcfg = s[:6]
         bm, bn = TILES[tcfg]
         blocks = ng * B * (cpad // bm) * -(-n_len // bn)
-    tot_f += fl; tot_t += acc[i]
-    print(f"{i:3d} {(('R' if xr else 'V' if f54 else 'W') if s[0] == 'wino' else ' ')}{bm:>3}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {blocks:6d} {fl/1e9:8.2f} {acc[i]:8.1f} {fl/acc[i]/1e6:7.1f}")
-print(f"total {tot_f/1e9:.1f} GFLOP {tot_t/1e3:.3f} ms {tot_f/tot_t/1e6:.1f} TF/s")
+    tot_f += fl; tot_e += ex; tot_t += acc[i]
+    print(f"{i:3d} {fam:>14} {bm:>4}x{bn:<3} {ng:3d} {cpad:5d} {n_len:7d} {d_:2d} {blocks:6d} {fl/1e9:9.2f} {ex/1e9:10.2f} {acc[i]:8.1f} {ex/acc[i]/1e6:9.1f}")
+print(f"total {tot_f/1e9:.1f} GFLOP algorithmic, {tot_e/1e9:.1f} executed, {tot_t/1e3:.3f} ms: {tot_e/tot_t/1e6:.1f} TF/s executed (fp32-equivalent)")
