@@ -15,10 +15,13 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # would re-pack it into v_pk_*_f32, which stall a bf16 MFMA (conv_wino54_kernel.h)
 # (conv_wino.hip as a whole: its bf16 x 6 instantiations need it for the same reason, and without it the 128 x 256 one spills)
 EXTRA_FLAGS = {"conv_wino54_bf.hip": ["-fno-slp-vectorize"], "conv_wino.hip": ["-fno-slp-vectorize"]}
-# every kernel's resources are read from the compiler's remarks: a kernel that needs scratch (spilled registers) fails the build.
-# The conv kernels place their waits by counting the loads in flight and fill every register they are given; the two times a
-# variant spilled in round 6 (F(5,4) bf16 x 6 with the 4-byte loader, F(4,3) bf16 x 6 at 128 x 256) its results were wrong.
+# every kernel's resources are read from the compiler's remarks: a kernel that spills more than a few registers fails the build.
+# The conv kernels fill every register they are given; a variant that spills a hundred (it happened three times in round 6: the
+# scheduler hoisting the next tile column's work until the file is full) runs its K loop through scratch.  (Round 6 also found
+# such variants computing garbage: an inline-asm prefetch wrote a register the compiler had meanwhile given to something else --
+# fixed at the source, conv_wino.hip: prefetch_a; the limit here is about speed.)
 RESOURCE_FLAGS = ["-Rpass-analysis=kernel-resource-usage"]
+MAX_SCRATCH_BYTES = 16          # per lane: up to 4 spilled registers (prologue / epilogue values) are tolerated and reported
 HEADERS = ["fh_common.h", "conv_wino54_kernel.h"]
 
 
@@ -88,12 +91,15 @@ def build(force=False, verbose=True):
             print("\n".join(rest), file=sys.stderr, flush=True)
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-        bad = [(k, r) for k, r in kernels.items() if r.get("ScratchSize", 0) > 0]
+        for k, r in kernels.items():
+            if verbose and 0 < r.get("ScratchSize", 0) <= MAX_SCRATCH_BYTES:
+                print(f"note: {s}: {k} spills {r.get('VGPRs Spill', '?')} registers ({r['ScratchSize']} bytes of scratch per lane)", flush=True)
+        bad = [(k, r) for k, r in kernels.items() if r.get("ScratchSize", 0) > MAX_SCRATCH_BYTES]
         if bad:
             obj.unlink(missing_ok=True)
             spilled += [f"{s}: {k} needs {r['ScratchSize']} bytes of scratch per lane ({r.get('VGPRs Spill', '?')} VGPRs spilled)" for k, r in bad]
     if spilled:
-        raise RuntimeError("kernels that spill registers are not built (their results cannot be trusted):\n  " + "\n  ".join(spilled))
+        raise RuntimeError(f"kernels that need more than {MAX_SCRATCH_BYTES} bytes of scratch per lane are not built:\n  " + "\n  ".join(spilled))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(objdir / (s + ".o")) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -351,19 +351,24 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
   // prefetch above is only half a step deep, enough for an L2 hit but not for HBM, and the blocks
   // that share a weight panel run in lockstep, so without this every tile is a first touch for all
   // of them.  One lane per 128-byte line, lanes 0-31 tap group 2j, lanes 32-63 group 2j + 1; the
-  // result is never read (pf stays live so that its register is not reused under the late write).
-  unsigned pf = 0;
+  // result is never used.  The loads are ordinary builtin loads into two registers that the NEXT prefetch "reads" (an empty asm)
+  // before it overwrites them: the compiler then knows when they land.  (Until round 6 this was an inline-asm load into one
+  // register the compiler knew nothing about -- correct only while the allocator happened to keep that register for the
+  // kernel's whole life: every instantiation that spilled moved it, the late write then hit whatever lived there, and the
+  // result was garbage that changed from run to run: tools/exp/ragged_bf_debug.py)
+  unsigned pf[2] = {0u, 0u};
   auto prefetch_a = [&](const WSeg& S, int chunk, bool valid) {
     constexpr int ROWF = BF ? W_A3 : W_CK;                                 // floats per weight row and chunk
     const float* up = uni(S.u + ((size_t)(chunk * S.ngrp * 6 + xi) * cout_pad + co0) * ROWF);
     const unsigned gstride = 6u * (unsigned)cout_pad * ROWF * 4u;          // bytes between tap groups
     const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? (unsigned)(S.ngrp - 1) * gstride + W_BM * ROWF * 4 : 0u);
+    asm volatile("" :: "v"(pf[0]), "v"(pf[1]));          // the previous prefetch has landed before its registers are reused
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       // (lanes past the tile's lines: out of range; the 96-byte rows of the BF form are 0.75 W_BM lines, the first
       // 32 lanes' worth of which is touched: enough to start the L2 fill of the tile)
       const unsigned off = l31 < W_BM * ROWF / 32 ? (unsigned)(2 * j + lh) * gstride + (unsigned)l31 * 128u : 0x80000000u;
-      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pf) : "v"(off), "s"(r) : "memory");
+      pf[j] = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
     }
   };
 
@@ -728,8 +733,7 @@ void conv_wino_kernel(const fh_wino_group* __restrict__ groups, int n_groups, in
       }
     }
   }
-  // (keeps pf alive: the prefetch loads above are never read; never true for finite weights)
-  if (pf == 0x7fc12345u) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" :: "v"(pf[0]), "v"(pf[1]));            // (the last prefetch: waited for, never used)
 }
 
 // out = ((a + b) + c) * scale, 4 elements per thread (the reference's xs += ...; xs / n order)

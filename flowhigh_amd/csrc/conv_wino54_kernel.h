@@ -383,18 +383,21 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
     }
   };
   // L2 warm-up of the A tiles of the NEXT chunk (all its tap groups, this wave's xi), as in conv_wino.hip
-  unsigned pf = 0;
+  // (ordinary loads into two registers that the next prefetch "reads" before it overwrites them -- not the untracked inline-asm
+  // load of rounds 2-5, whose late write hit a reused register in every instantiation that spilled: conv_wino.hip)
+  unsigned pf[2] = {0u, 0u};
   auto prefetch_a = [&](const VSeg& S, int chunk, bool valid) {
     constexpr int ROWF = BF ? V_A3 : V_CK;                                 // floats per weight row and chunk
     const float* up = uni(S.u + ((size_t)(chunk * S.ngrp * 8 + xi) * cout_pad + co0) * ROWF);
     const unsigned gstride = 8u * (unsigned)cout_pad * ROWF * 4u;          // bytes between tap groups
     const __amdgpu_buffer_rsrc_t r = make_rsrc(up, valid ? (unsigned)(S.ngrp - 1) * gstride + BM * ROWF * 4 : 0u);
+    asm volatile("" :: "v"(pf[0]), "v"(pf[1]));          // the previous prefetch has landed before its registers are reused
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       // (lanes past the tile's lines: out of range; the 96-byte rows of the BF form are 0.75 BM lines, the first 32 lanes' worth
       // of which is touched: enough to start the L2 fill of the tile)
       const unsigned off = l31 < BM * ROWF / 32 ? (unsigned)(2 * j + lh) * gstride + (unsigned)l31 * 128u : 0x80000000u;
-      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pf) : "v"(off), "s"(r) : "memory");
+      pf[j] = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
     }
   };
 
@@ -763,8 +766,7 @@ void conv_wino54_kernel(const fh_wino_group* __restrict__ groups, int n_groups, 
       }
     }
   }
-  // (keeps pf alive: the prefetch loads above are never read; never true for finite weights)
-  if (pf == 0x7fc12345u) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" :: "v"(pf[0]), "v"(pf[1]));            // (the last prefetch: waited for, never used)
 }
 
 // 320-output blocks of a row: per phase in the plain layout, over the concatenated tile slots of all phases in the phase-major one

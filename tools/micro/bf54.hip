@@ -249,7 +249,7 @@ void loop54(const float* __restrict__ A3, const float* __restrict__ X, float* __
 
   load_a(0, 0);
   unsigned long long tr_prep = 0, tr_mul = 0, tr_sync = 0;
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   int xbuf = 0, grp = 0;
   if constexpr (!PIPE) {
     if (X2) stage_load(1, 1);
@@ -333,7 +333,7 @@ void loop54(const float* __restrict__ A3, const float* __restrict__ X, float* __
       }
     }
   }
-  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -342,7 +342,7 @@ void loop54(const float* __restrict__ A3, const float* __restrict__ X, float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += acc[i][j][r];
   out[(size_t)blockIdx.x * THREADS + tid] = s + __uint_as_float((xqs[0][0][0] ^ xqs[1][0][0]) & 1u);
-  if (tid == 0) clk[blockIdx.x] = t1 - t0;
+  if (tid == 0) { clk[blockIdx.x] = t1 - t0; clk[256 + 256 * 6 + blockIdx.x] = r1 - r0; }
   if (TRACE && lane == 0 && (xi == 0 || xi == 7)) {
     unsigned long long* q = clk + 256 + (blockIdx.x * 2 + (xi == 7)) * 3;
     q[0] = tr_prep; q[1] = tr_mul; q[2] = tr_sync;
@@ -382,6 +382,12 @@ static void run(const char* what, int chunks) {
   double cyc = 0;
   for (auto c : clk) cyc += (double)c;
   cyc /= blocks;
+  std::vector<unsigned long long> rt(blocks);
+  CHECK(hipMemcpy(rt.data(), dClk + 256 + 256 * 6, blocks * 8, hipMemcpyDeviceToHost));
+  double rtt = 0;
+  for (auto c : rt) rtt += (double)c;
+  rtt /= blocks;
+  const double ghz = cyc / (rtt / 100e6) / 1e9;            // s_memtime ticks per second of s_memrealtime (100 MHz)
   const double mfma = (double)chunks * GC * 2 * 6 * MT;                    // per wave
   const double floor_cyc = mfma * 32 * 2;                                   // 2 waves per SIMD share the pipe
   const double tf = 2.0 * 32 * 32 * 16 * mfma / 6.0 * 8 * blocks / (ms * 1e-3) / 1e12;     // fp32-equivalent (6 MFMAs = 1 product)
@@ -396,8 +402,8 @@ static void run(const char* what, int chunks) {
     printf("      trace, ticks per item: wave 0 prep %.0f mul %.0f sync %.0f | wave 7 prep %.0f mul %.0f sync %.0f\n", a[0] / items, a[1] / items,
            a[2] / items, a[3] / items, a[4] / items, a[5] / items);
   }
-  printf("MT %d GC %d %-30s %8.3f ms  %7.1f fp32-eq TFLOP/s incl. launch  | loop: %5.0f ticks per item, matrix pipe busy %.3f\n", MT, GC,
-         what, ms, tf, cyc / (chunks * GC * 2), floor_cyc / 2 / cyc);
+  printf("MT %d GC %d %-30s %8.3f ms  %7.1f fp32-eq TFLOP/s incl. launch  | loop: %5.0f ticks per item, %.2f G ticks/s, loop %.3f ms\n", MT, GC,
+         what, ms, tf, cyc / (chunks * GC * 2), ghz, rtt / 100e3);
 }
 
 int main(int argc, char** argv) {
@@ -406,7 +412,7 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&dA, a_floats * 4));
   CHECK(hipMalloc(&dX, (size_t)256 * 64 * 16 * 512 * 4 + 65536));
   CHECK(hipMalloc(&dOut, (size_t)256 * THREADS * 4));
-  CHECK(hipMalloc(&dClk, (256 + 256 * 6) * 8));
+  CHECK(hipMalloc(&dClk, (256 + 256 * 6 + 256) * 8));
   {
     std::vector<unsigned> h(a_floats);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c003b80u + (unsigned)((i * 2654435761u) >> 20 & 0x00ff00ffu);
@@ -416,18 +422,11 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(dX, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
   }
 #define RUNS(MT, GC)                                                            \
-  run<MT, 1 | 16384, GC>("A2 PIN", chunks);                                     \
-  run<MT, 1 | 16384 | 65536, GC>("A2 PIN ALAY", chunks);                        \
-  run<MT, 16384 | 65536, GC>("PIN ALAY (A behind)", chunks);                    \
-  run<MT, 1 | 16384 | 65536 | 1024, GC>("A2 PIN ALAY NOBAR", chunks);           \
-  run<MT, 1 | 16384 | 65536 | 256, GC>("A2 PIN ALAY PK", chunks);               \
-  run<MT, 1 | 2 | 65536, GC>("A2 PIPE ALAY", chunks);                           \
-  run<MT, 2 | 65536, GC>("PIPE ALAY (A behind)", chunks);                       \
-  run<MT, 1 | 16384 | 65536 | 2048, GC>("A2 PIN ALAY PRIO", chunks);            \
-  run<MT, 1 | 4 | 8 | 16 | 32 | 64, GC>("MFMA only", chunks);
+  run<MT, 16384 | 65536, GC>("product form (A behind, PIN ALAY)", chunks);      \
+  run<MT, 16384, GC>("product form, row-major weights", chunks);                \
+  run<MT, 1 | 4 | 8 | 16 | 32 | 64, GC>("MFMA only", chunks);                   \
+  run<MT, 1 | 128 | 16384, GC>("everything but the MFMAs", chunks);
   RUNS(3, 2)
   RUNS(2, 2)
-  RUNS(3, 1)
-  RUNS(3, 3)
   return 0;
 }
