@@ -349,6 +349,129 @@ void loop54(const float* __restrict__ A3, const float* __restrict__ X, float* __
   }
 }
 
+static float *dA, *dX, *dOut;
+static unsigned long long* dClk;
+
+template <typename F>
+static double time_ms(F launch, int reps);
+
+// ---- the same loop with SIXTEEN waves per block: wave = (point, tile column), 4 waves per SIMD at <= 128 registers -------------------------
+// (does the loop's latency chain -- LDS round trips, dependent FMA / split chains, L2 waits -- hide under twice the waves?)
+template <int MT, int GC>
+__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void loop54w16(const float* __restrict__ A3, const float* __restrict__ X, float* __restrict__ out, int chunks, int a_panel_floats) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xi = wave & 7, nt = wave >> 3;
+  for (int i = tid; i < 2 * SLAB; i += 1024) lds[i] = 0.001f * (float)((i * 7 + blockIdx.x) % 113) - 0.05f;
+  __syncthreads();
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float co[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) co[j] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(0.25f * (float)(j + 1) - 0.5f * (float)(xi & 3))));
+  const int lane_base = (2 * lh) * QROW + l31 * 4 + nt * 128;
+  const float* a_base = A3 + (size_t)(blockIdx.x & 7) * a_panel_floats;
+  u32x4 a3[MT][3];
+  auto load_a = [&](int grp) {
+    const float* up = a_base + ((size_t)grp * 8 + xi) * (32 * MT * 24);
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(up, 32 * MT * 24 * 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) a3[mt][pc] = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16 + (mt * 3 + pc) * 1024, 0, 0);
+  };
+  u32x4 xq[2];
+  int wofs[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int w = ((wave >> 2) * 64 + lane) * 4 + e;
+    const int wc = w < 5 * P ? w : 0;
+    wofs[e] = (wc % 5) * PLANE + (wave & 3) * QROW + (wc / 5) * 4;
+  }
+  auto stage_load = [&](int chunk) {
+    const float* xp = X + ((size_t)((blockIdx.x >> 3) * 64 + (chunk & 63)) * 16 + 4 * (wave & 3)) * 512 + ((wave >> 2) & 1) * 256 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) xq[r] = *reinterpret_cast<const u32x4*>(xp + (r + 2 * (wave >> 3)) * 512);
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      *reinterpret_cast<f32x2*>(lds + buf * SLAB + wofs[e] + 2 * (wave >> 3)) = (f32x2){__uint_as_float(xq[0][e]), __uint_as_float(xq[1][e])};
+  };
+  load_a(0);
+  int xbuf = 0, grp = 0;
+  for (int c = 0; c < chunks; ++c) {
+    stage_load(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < GC; ++g) {
+      float v[8];
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        f32x4 x[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int cc = 4 * g + j + 1;
+          x[j] = *reinterpret_cast<const f32x4*>(lds + xbuf * SLAB + lane_base + hq * QROW + (cc % 5) * PLANE + (cc / 5) * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = x[5][e];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) t = __builtin_fmaf(co[j], x[j][e], t);
+          v[4 * hq + e] = t;
+        }
+      }
+      u32x4 pc[3];
+      split8<false>(v, pc[0], pc[1], pc[2]);
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, pc[0]), bm = __builtin_bit_cast(bf16x8, pc[1]), bl = __builtin_bit_cast(bf16x8, pc[2]);
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) {
+        constexpr int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3[mt][pa[pp]]), pb[pp] == 0 ? bh : pb[pp] == 1 ? bm : bl,
+                                                            acc[mt], 0, 0, 0);
+      }
+      load_a(grp + 1);
+      ++grp;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stage_store(xbuf ^ 1);
+    __syncthreads();
+    xbuf ^= 1;
+  }
+  float s_ = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_ += acc[i][r];
+  out[(size_t)blockIdx.x * 1024 + tid] = s_;
+}
+
+template <int MT, int GC>
+static void run16(int chunks) {
+  const int blocks = 256;
+  const int panel = (chunks + 2) * GC * 8 * 32 * MT * 24;
+  CHECK(hipFuncSetAttribute((const void*)loop54w16<MT, GC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLAB * 4 + 64));
+  float* out16;
+  CHECK(hipMalloc(&out16, (size_t)blocks * 1024 * 4));
+  const double ms = time_ms([&] {
+    hipLaunchKernelGGL((loop54w16<MT, GC>), dim3(blocks), dim3(1024), 2 * SLAB * 4 + 64, 0, dA, dX, out16, chunks, panel);
+  }, 150);
+  CHECK(hipGetLastError());
+  const double mfma = (double)chunks * GC * 6 * MT;                       // per wave (one column)
+  const double tf = 2.0 * 32 * 32 * 16 * mfma / 6.0 * 16 * blocks / (ms * 1e-3) / 1e12;
+  printf("MT %d GC %d 16 waves = (point, column), 4 per SIMD    %8.3f ms  %7.1f fp32-eq TFLOP/s  (%.3f us per tap group of %d rows x 2 columns)\n",
+         MT, GC, ms, tf, ms * 1e3 / (chunks * GC), 32 * MT);
+  CHECK(hipFree(out16));
+}
+
 template <typename F>
 static double time_ms(F launch, int reps) {
   hipEvent_t e0, e1;
@@ -364,9 +487,6 @@ static double time_ms(F launch, int reps) {
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   return ms / reps;
 }
-
-static float *dA, *dX, *dOut;
-static unsigned long long* dClk;
 
 template <int MT, int MASK, int GC>
 static void run(const char* what, int chunks) {
@@ -428,5 +548,9 @@ int main(int argc, char** argv) {
   run<MT, 1 | 128 | 16384, GC>("everything but the MFMAs", chunks);
   RUNS(3, 2)
   RUNS(2, 2)
+  run16<2, 2>(chunks);
+  run16<3, 2>(chunks);
+  run16<2, 1>(chunks);
+  run16<2, 3>(chunks);
   return 0;
 }
