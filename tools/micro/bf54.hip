@@ -546,6 +546,20 @@ int main(int argc, char** argv) {
   run<MT, 16384, GC>("product form, row-major weights", chunks);                \
   run<MT, 1 | 4 | 8 | 16 | 32 | 64, GC>("MFMA only", chunks);                   \
   run<MT, 1 | 128 | 16384, GC>("everything but the MFMAs", chunks);
+  if (argc > 2 && argv[2][0] == 'x') {        // where the non-MFMA work's time goes: one ingredient out at a time, with the phase trace
+    run<3, 16384 | 65536 | 32768, 2>("product form + trace", chunks);
+    run<3, 16384 | 65536 | 32768 | 1024, 2>("... no barrier (racy) + trace", chunks);
+    run<3, 1 | 128 | 16384, 2>("no MFMA", chunks);
+    run<3, 1 | 128 | 16384 | 32768, 2>("no MFMA + trace", chunks);
+    run<3, 1 | 128 | 16384 | 4, 2>("no MFMA, no weight loads", chunks);
+    run<3, 1 | 128 | 16384 | 64, 2>("no MFMA, no staging / barrier", chunks);
+    run<3, 1 | 128 | 16384 | 4 | 64, 2>("no MFMA, no weights, no staging", chunks);
+    run<3, 1 | 128 | 16384 | 4 | 64 | 32768, 2>("no MFMA, no weights, no staging + trace", chunks);
+    run<3, 1 | 128 | 16384 | 4 | 64 | 32, 2>("no MFMA / weights / staging / split", chunks);
+    run<3, 1 | 128 | 16384 | 4 | 64 | 16, 2>("no MFMA / weights / staging / transform", chunks);
+    run<3, 1 | 128 | 16384 | 4 | 64 | 16 | 32, 2>("LDS reads only", chunks);
+    return 0;
+  }
   RUNS(3, 2)
   RUNS(2, 2)
   run16<2, 2>(chunks);
