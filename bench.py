@@ -79,8 +79,9 @@ def cpu_baseline(sd, cfg, sr_in):
 DTYPE_BY_FORM = {
     "winograd": "f32",
     "direct": "f32",
-    "bf16x6": "f32 in / out / accumulate; the wide-stage Winograd convs' products as 6 bf16 MFMAs over exact 3-piece splits "
-              "(conv_form='bf16x6': fp32-grade, dropped terms <= 2^-24 |a b|); everything else fp32 arithmetic",
+    "bf16x6": "f32 in / out / accumulate; the residual-stack convs' products (Winograd wide stages, direct narrow stages) as 6 bf16 "
+              "MFMAs over exact 3-piece splits (conv_form='bf16x6': fp32-grade, dropped terms <= 2^-24 |a b|); everything else fp32 "
+              "arithmetic",
 }
 KERNEL_BY_FAMILY = {
     "wino54": "conv_wino54_kernel (Winograd F(5,4) wide-stage conv, v_mfma_f32_32x32x2_f32)",
@@ -88,9 +89,10 @@ KERNEL_BY_FAMILY = {
     "wino43": "conv_wino_kernel (Winograd F(4,3): conv_pre, first two upsamplers, v_mfma_f32_32x32x2_f32)",
     "wino43_bf16x6": "conv_wino_kernel<BF> (Winograd F(4,3): conv_pre, first two upsamplers, bf16 x 6)",
     "amp": "amp_actconv_kernel (narrow-stage Winograd F(5,4) conv, v_mfma_f32_16x16x4_f32)",
+    "narrow_bf16x6": "narrow_bf_kernel (narrow-stage direct conv, 6 x v_mfma_f32_16x16x32_bf16 per fp32 k-block)",
     "direct": "conv_mfma_kernel (direct implicit-GEMM conv: last four upsamplers, v_mfma_f32_32x32x2_f32)",
 }
-PEAK_BY_FAMILY = {"wino54_bf16x6": 2500.0, "wino43_bf16x6": 2500.0}      # dense bf16 MFMA; every other family: the fp32 MFMA peak
+PEAK_BY_FAMILY = {"wino54_bf16x6": 2500.0, "wino43_bf16x6": 2500.0, "narrow_bf16x6": 2500.0}      # dense bf16 MFMA; every other family: the fp32 MFMA peak
 
 
 def family_split(conv_ev, launches, timed_steps):

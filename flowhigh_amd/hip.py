@@ -20,7 +20,7 @@ CONV_MAX_TAPS = 16
 CONV_MAX_SEG = 3
 CONV_MAX_HALO = 64
 
-ABI_VERSION = 4            # FH_ABI_VERSION of include/flowhigh_hip.h
+ABI_VERSION = 5            # FH_ABI_VERSION of include/flowhigh_hip.h
 EPI_LINEAR, EPI_GEGLU, EPI_MAG, EPI_LOGCLAMP = 0, 1, 2, 3
 
 
@@ -107,6 +107,8 @@ _SIGS = {
     "fh_amp_max_channels": [],
     "fh_sizeof_amp_tile": [],
     "fh_amp_actconv_f32": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "fh_narrow_tile_len": [],
+    "fh_narrow_conv_bf16x6_f32": [_P, _I, _P, _I, _I, _I, _I, _P],
     "fh_sizeof_sum_job": [],
     "fh_sum_multi_f32": [_P, _I, C.c_longlong, _P],
     "fh_attention_seg_f32": [_P, _P, _P, _I, _I, _I, _F, _P],

@@ -130,6 +130,48 @@ def pack_amp_weight(w, channels=None):
     return torch.cat(parts, dim=-1).contiguous()
 
 
+def narrow_slabs(channels):
+    """[(first octet, octets)] of the slabs the bf16 x 6 narrow-stage kernel cuts `channels` into (narrow_bf.hip: at most three
+    octets = 24 channels per slab, balanced: 24 -> (0, 3); 48 -> (0, 3), (3, 3); 32 -> (0, 2), (2, 2); 40 -> (0, 3), (3, 2))."""
+    octets = channels // 8
+    n = -(-octets // 3)
+    out, ob = [], 0
+    for i in range(n):
+        og = octets // n + (1 if i < octets % n else 0)
+        out.append((ob, og))
+        ob += og
+    return out
+
+
+def pack_narrow_bf_weight(w, channels=None):
+    """Conv1d weight [co, ci, k] (co, ci <= channels <= 48, channels % 8 == 0, k <= 11) -> the bf16 x 6 narrow-stage kernel's
+    weights (narrow_bf.hip, flowhigh_hip.h: fh_narrow_conv_bf16x6_f32): float32 container of bf16 bit patterns,
+    per slab (narrow_slabs) ceil(k og / 4) k-blocks x [N tile][piece h, m, l][64 lanes][8 bf16]; lane l of k-block kb holds
+    w[16 n + (l & 15), 8 (ob + o) + 0 .. 7, tap] for the pair q = 4 kb + (l >> 4) = tap og + o, zero past k og / past the channels."""
+    co, ci, k = w.shape
+    c = max(co, ci) if channels is None else channels
+    if c % 8 or c > 48 or co > c or ci > c or k > 11:
+        raise ValueError(f"narrow-stage conv: {co} x {ci} channels, {k} taps do not fit {c} channels (a multiple of 8, <= 48) / 11 taps")
+    ma = -(-c // 16)
+    wp = torch.zeros(16 * ma, c, k, dtype=torch.float32)
+    wp[:co, :ci] = w.float()
+    parts = []
+    for ob, og in narrow_slabs(c):
+        nb = -(-(k * og) // 4)
+        # [tap, o, e] -> q = tap og + o, padded to 4 nb pairs
+        blk = wp[:, 8 * ob:8 * (ob + og)].reshape(16 * ma, og, 8, k).permute(0, 3, 1, 2).reshape(16 * ma, k * og, 8)
+        full = torch.zeros(16 * ma, 4 * nb, 8, dtype=torch.float32)
+        full[:, :k * og] = blk
+        # [na, n, kb, lg, e] -> [kb, na, lane = 16 lg + n, e]
+        full = full.view(ma, 16, nb, 4, 8).permute(2, 0, 3, 1, 4).reshape(nb, ma, 64, 8)
+        h = full.to(torch.bfloat16)
+        r = full - h.float()
+        m = r.to(torch.bfloat16)
+        l = (r - m.float()).to(torch.bfloat16)
+        parts.append(torch.stack([h, m, l], dim=2).contiguous().view(torch.int16).reshape(-1))      # [kb, na, piece, lane, 8]
+    return torch.cat(parts).contiguous().view(torch.float32)
+
+
 def split_bf3(u):
     """fp32 tensor [..., 16] -> int16 tensor [..., 3, 16] of bf16 bit patterns: x = h + m + l with h = bf16(x),
     m = bf16(x - h), l = bf16(x - h - m) (round to nearest even; the subtractions are exact in fp32)."""

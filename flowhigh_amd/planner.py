@@ -304,21 +304,31 @@ def amp_tile_len(d):
 
 
 AMP_MAX_D = 6             # F_MAX_D of amp_fused.hip
+AMP_DIRECT = 4            # plan flag of a narrow-stage launch: the direct bf16 x 6 form (fh_narrow_conv_bf16x6_f32, narrow_bf.hip)
+NARROW_TILE = 256         # fh_narrow_tile_len(): outputs per block and row of that form, any dilation
 
 
-def make_amp_seg(x, u, k, center=None):
-    """One K segment of a narrow-stage group: conv weights `u` (pack_amp_weight) applied to x."""
+def use_amp_bf16x6(form=None):
+    """Narrow stages of a bf16 x 6 model run the direct bf16 x 6 kernel (narrow_bf.hip) instead of the fp32-MFMA Winograd one
+    (amp_fused.hip).  FH_AMP_BF16X6=0: the Winograd one (A/B; part of the weight blob's format tag)."""
+    form = resolve_conv_form()[0] if form is None else form
+    return form == "bf16x6" and os.environ.get("FH_AMP_BF16X6", "1") != "0"
+
+
+def make_amp_seg(x, u, k, center=None, direct=False):
+    """One K segment of a narrow-stage group: conv weights `u` (pack_amp_weight; direct: pack_narrow_bf_weight, and the
+    descriptor's ngrp field carries the tap count -- flowhigh_hip.h: fh_narrow_conv_bf16x6_f32) applied to x."""
     s = hip.AmpSeg()
-    s.x, s.u, s.ngrp = _addr(x), _addr(u), -(-k // 4)
+    s.x, s.u, s.ngrp = _addr(x), _addr(u), k if direct else -(-k // 4)
     s.center = (k - 1) // 2 if center is None else center
     return s
 
 
-def make_amp_group(segs, bias, res, out, length, scale=1.0):
+def make_amp_group(segs, bias, res, out, length, scale=1.0, direct=False):
     g = hip.AmpGroup()
     # the kernel walks the segments in one pass per tap-group count, largest first
     segs = sorted(segs, key=lambda s: -s.ngrp)
-    if any(s.ngrp > 3 or s.center > 5 for s in segs):
+    if any(s.ngrp > (11 if direct else 3) or s.center > 5 or (direct and s.center >= s.ngrp) for s in segs):
         raise NotImplementedError("narrow-stage kernel: kernels of at most 11 taps")
     for i, s in enumerate(segs):
         g.seg[i] = s
@@ -330,7 +340,7 @@ def make_amp_group(segs, bias, res, out, length, scale=1.0):
     return g
 
 
-def amp_tile_list(lens, batch, dilation, interleave=True):
+def amp_tile_list(lens, batch, dilation, interleave=True, direct=False):
     """The work list of a narrow-stage launch (fh_amp_tile: group, batch item, first output, len): int32 tensor [tiles, 4].
     The launch's persistent blocks take tiles b, b + grid, b + 2 grid, ... of this list.  Order: the groups' tiles dealt
     round-robin (group 0's first tile, group 1's first, ...), so that blocks with neighbouring ids work on tiles of DIFFERENT
@@ -339,7 +349,7 @@ def amp_tile_list(lens, batch, dilation, interleave=True):
     quarter of the launch, tools/exp/amp_ab.sh).  A block still gets the same share of every group.  interleave=False: group
     after group (heavy first).  (Both orders, and a layout that deals the tiles to the blocks by weight, longest first, measure
     the same to +-0.1 %: profiles/r05_amp_ablation.txt item 9; the environment switch for it left in round 6.)"""
-    tb = amp_tile_len(dilation)
+    tb = hip.lib().fh_narrow_tile_len() if direct else amp_tile_len(dilation)
     per_group = []
     for gi, length in enumerate(lens):
         t0 = torch.arange(0, length, tb, dtype=torch.int32)
@@ -357,10 +367,13 @@ def amp_tile_list(lens, batch, dilation, interleave=True):
     return rows[torch.argsort(keys)].contiguous()
 
 
-def amp_max_center(groups):
-    """max_center of a narrow-stage launch; raises if some segment's taps do not fit the slab it implies."""
+def amp_max_center(groups, direct=False):
+    """max_center of a narrow-stage launch; raises if some segment's taps do not fit the slab it implies (direct form: every
+    segment has its own slab, nothing to check)."""
     segs = [g.seg[i] for g in groups for i in range(g.nseg)]
     cmax = max(s.center for s in segs)
+    if direct:
+        return cmax
     if any(cmax - s.center + 4 * s.ngrp + 3 > 16 for s in segs):
         raise NotImplementedError("narrow-stage kernel: the kernel sizes of one launch are too far apart")
     return cmax
@@ -563,17 +576,20 @@ class _PlanBuilder:
         self.add(("wino", d, len(groups), wpad, length, dil, flops, wcfg, int(pm), B), groups)
 
     def amp(self, groups, c, length, dil):
-        """Narrow-stage launch (fh_amp_actconv_f32): the groups' convs."""
+        """Narrow-stage launch: the groups' convs (fh_amp_actconv_f32; the model's narrow stages in the direct bf16 x 6 form:
+        fh_narrow_conv_bf16x6_f32, plan flag AMP_DIRECT)."""
         B = self.B
-        tiles = amp_tile_list([g.len for g in groups], B, dil).to(self.v.device)
+        direct = self.v.amp_direct
+        tiles = amp_tile_list([g.len for g in groups], B, dil, direct=direct).to(self.v.device)
         d = hip.to_device_struct_array(groups, self.v.device)
         self.keep += [d, tiles]
         flops = sum(2.0 * c * c * (2 * g.seg[i].center + 1) * length * B for g in groups for i in range(g.nseg))
-        ex = sum(2.0 * c * c * 1.6 * g.seg[i].ngrp * length * B for g in groups for i in range(g.nseg))
+        # executed: Winograd F(5,4) 1.6 ceil(k / 4) multiply-adds per output; direct: the taps themselves
+        ex = flops if direct else sum(2.0 * c * c * 1.6 * g.seg[i].ngrp * length * B for g in groups for i in range(g.nseg))
         self.executed += ex
-        self.conv_launches.append(("amp", ex, flops))
-        flags = int(all(g.len % 4 == 0 for g in groups)) | 2
-        self.add(("amp", d, len(groups), tiles, tiles.shape[0], c, dil, amp_max_center(groups), flags, flops), groups)
+        self.conv_launches.append(("narrow_bf16x6" if direct else "amp", ex, flops))
+        flags = int(all(g.len % 4 == 0 for g in groups)) | (AMP_DIRECT if direct else 2)
+        self.add(("amp", d, len(groups), tiles, tiles.shape[0], c, dil, amp_max_center(groups, direct), flags, flops), groups)
 
     def act(self, groups, c, length, din=1, dout=1):
         d = hip.to_device_struct_array(groups, self.v.device)
@@ -587,8 +603,9 @@ class _PlanBuilder:
         c, cpad, wpad, L, B = st["c"], st["cpad"], st["wpad"], self.L, self.B
         biases = [e["b"] for e in ents]
         if all("ua" in e for e in ents):               # narrow stage: plain tensors whatever the dilation
-            self.amp([make_amp_group([make_amp_seg(xs_in[i], ents[i]["ua"], ks[i])], biases[i], res[i],
-                                     outs[i], L) for i in range(len(ents))], c, L, dil)
+            dr = self.v.amp_direct
+            self.amp([make_amp_group([make_amp_seg(xs_in[i], ents[i]["ua"], ks[i], direct=dr)], biases[i], res[i],
+                                     outs[i], L, direct=dr) for i in range(len(ents))], c, L, dil)
             return [[o] for o in outs]
         all_wino = all("u" in e for e in ents)
         nsplit = wino_split_k(ks, c, wpad, self.Lref, dil, st["wcfg"], self.v.bf, self.v.sw["splitk"]) if all_wino else 1
@@ -793,8 +810,9 @@ class _PlanBuilder:
         fusable = v.nk <= hip.CONV_MAX_SEG          # (K segments of one group; more blocks: one group each + one averaging pass)
         if all("ua" in e for e in ents) and fusable and all(d == ds[0] for d in ds):
             # narrow stage: always the fused form (its blocks are short whatever the length: nothing to decide per clip)
-            segs = [make_amp_seg(T1[j], e["ua"], k) for j, e, k in zip(order, ents, ks)]
-            self.amp([make_amp_group(segs, st["last_bias"], [xin[j] for j in order], S, L, scale=scale)], c, L, ds[0])
+            dr = self.v.amp_direct
+            segs = [make_amp_seg(T1[j], e["ua"], k, direct=dr) for j, e, k in zip(order, ents, ks)]
+            self.amp([make_amp_group(segs, st["last_bias"], [xin[j] for j in order], S, L, scale=scale, direct=dr)], c, L, ds[0])
             return
         if all("u" in e for e in ents):
             ksteps = [c // 16 * -(-k // st["taps"]) for k in ks]
@@ -956,17 +974,18 @@ def merge_ragged(voc, frames):
             classes = {}
             for ci, st_, groups in items:
                 _, _d, ng, _t, _nt, c, dil, _cm, flags, _fl = st_
-                classes.setdefault((c, dil, flags & 2), []).append(groups)
-            for (c, dil, noact), lst in classes.items():
+                classes.setdefault((c, dil, flags & (2 | AMP_DIRECT)), []).append(groups)
+            for (c, dil, form_bits), lst in classes.items():
                 allg = [g for groups in lst for g in groups]
+                direct = bool(form_bits & AMP_DIRECT)
                 # heavy groups first (the persistent blocks walk the tile list in order), then long ones
                 allg.sort(key=lambda g: (-sum(g.seg[i].ngrp for i in range(g.nseg)), -g.len))
-                tl = amp_tile_list([g.len for g in allg], 1, dil)
+                tl = amp_tile_list([g.len for g in allg], 1, dil, direct=direct)
                 off_t = sum(len(b) for b in blobs)
                 raw = tl.numpy().tobytes()
                 blobs.append(raw + bytes(-len(raw) % 16))
-                merged.append(("ramp", blob(allg), len(allg), off_t, tl.shape[0], c, dil, amp_max_center(allg),
-                               int(all(g.len % 4 == 0 for g in allg)) | noact))
+                merged.append(("ramp", blob(allg), len(allg), off_t, tl.shape[0], c, dil, amp_max_center(allg, direct),
+                               int(all(g.len % 4 == 0 for g in allg)) | form_bits))
         elif kind == "act":
             classes = {}
             for ci, st_, groups in items:

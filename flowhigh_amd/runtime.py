@@ -9,16 +9,21 @@ import torch
 
 from . import hip
 from .packing import pack_wino54_weight_any, pack_wino_weight_any
-from .planner import (WINO_F54, amp_max_center, amp_tile_list, make_act_group, make_wino_group, make_wino_seg, pick_wino54_tile,
+from .planner import (AMP_DIRECT, WINO_F54, amp_max_center, amp_tile_list, make_act_group, make_wino_group, make_wino_seg, pick_wino54_tile,
                       pick_wino_tile, use_wino54)
 
-def amp_actconv(groups, batch, channels, dilation, device):
-    """Upload descriptors and enqueue one narrow-stage launch (test / one-off use)."""
-    tiles = amp_tile_list([g.len for g in groups], batch, dilation).to(device)
+def amp_actconv(groups, batch, channels, dilation, device, direct=False):
+    """Upload descriptors and enqueue one narrow-stage launch (test / one-off use).  direct: the bf16 x 6 form (groups made with
+    make_amp_seg / make_amp_group(..., direct=True), weights from pack_narrow_bf_weight)."""
+    tiles = amp_tile_list([g.len for g in groups], batch, dilation, direct=direct).to(device)
     d = hip.to_device_struct_array(groups, device)
-    flags = int(all(g.len % 4 == 0 for g in groups)) | 2
-    hip.check(hip.lib().fh_amp_actconv_f32(d.data_ptr(), len(groups), tiles.data_ptr(), tiles.shape[0], channels, dilation,
-                                           amp_max_center(groups), flags, hip.stream()), "fh_amp_actconv_f32")
+    vec = int(all(g.len % 4 == 0 for g in groups))
+    if direct:
+        hip.check(hip.lib().fh_narrow_conv_bf16x6_f32(d.data_ptr(), len(groups), tiles.data_ptr(), tiles.shape[0], channels, dilation,
+                                                      vec, hip.stream()), "fh_narrow_conv_bf16x6_f32")
+    else:
+        hip.check(hip.lib().fh_amp_actconv_f32(d.data_ptr(), len(groups), tiles.data_ptr(), tiles.shape[0], channels, dilation,
+                                               amp_max_center(groups), vec | 2, hip.stream()), "fh_amp_actconv_f32")
     return d, tiles
 
 
@@ -279,7 +284,10 @@ def launch_step(voc, s, B, st):
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(L.fh_amp_actconv_f32(d.data_ptr(), ng, tiles.data_ptr(), nt, c, dil, cmax, flags, st), "fh_amp_actconv_f32")
+        if flags & AMP_DIRECT:
+            hip.check(L.fh_narrow_conv_bf16x6_f32(d.data_ptr(), ng, tiles.data_ptr(), nt, c, dil, flags & 1, st), "fh_narrow_conv_bf16x6_f32")
+        else:
+            hip.check(L.fh_amp_actconv_f32(d.data_ptr(), ng, tiles.data_ptr(), nt, c, dil, cmax, flags, st), "fh_amp_actconv_f32")
         if timing is not None:
             e1.record()
             timing.append((e0, e1))
@@ -334,7 +342,10 @@ def run_ragged_steps(voc, rp):
             hip.check(L.fh_conv_transpose_fused_f32(base + off, ng, 1, cpad, maxlen, tcfg, phases, st), "fh_conv_transpose_fused_f32")
         elif s[0] == "ramp":
             _, off, ng, off_t, nt, c, dil, cmax, flags = s
-            hip.check(L.fh_amp_actconv_f32(base + off, ng, base + off_t, nt, c, dil, cmax, flags, st), "fh_amp_actconv_f32")
+            if flags & AMP_DIRECT:
+                hip.check(L.fh_narrow_conv_bf16x6_f32(base + off, ng, base + off_t, nt, c, dil, flags & 1, st), "fh_narrow_conv_bf16x6_f32")
+            else:
+                hip.check(L.fh_amp_actconv_f32(base + off, ng, base + off_t, nt, c, dil, cmax, flags, st), "fh_amp_actconv_f32")
         elif s[0] == "rsum":
             _, off, nj, max_n = s
             hip.check(L.fh_sum_multi_f32(base + off, nj, max_n, st), "fh_sum_multi_f32")

@@ -24,7 +24,7 @@ import torch
 
 from . import hip
 from .packing import (  # noqa: F401
-    _WINO54_G, _WINO_G, fold_weight_norm, from_phase_major, pack_amp_weight, pack_conv_weight,
+    _WINO54_G, _WINO_G, fold_weight_norm, from_phase_major, pack_amp_weight, pack_conv_weight, pack_narrow_bf_weight,
     pack_wino54_weight, pack_wino54_weight_any, pack_wino_weight, pack_wino_weight_any, phase_len, pick_ck, split_bf3, to_phase_major,
     transposed_conv_extra, transposed_conv_phases, wino_phase_weight)
 from .planner import (  # noqa: F401
@@ -33,7 +33,7 @@ from .planner import (  # noqa: F401
     _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_max_center,
     amp_tile_len, amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,
     make_conv_seg, make_wino_group, make_wino_seg, merge_ragged, pick_tile_cfg, pick_wino54_tile,
-    pick_wino_tile, plan_switches, resolve_conv_form, ups_fused_ok, use_amp, use_bf16x6, use_wino, use_wino54, wino_block_mapping,
+    pick_wino_tile, plan_switches, resolve_conv_form, ups_fused_ok, use_amp, use_amp_bf16x6, use_bf16x6, use_wino, use_wino54, wino_block_mapping,
     wino_conv_ok, wino_launch_cost, wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
 from .runtime import (  # noqa: F401
     ACT_BLOCKS_CHOICES, _act_blocks, _act_choice, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped, ensure_act_blocks,
@@ -62,6 +62,8 @@ class Vocoder:
         self.form, self.form_auto = resolve_conv_form(conv_form, bf16x6)
         # bf: the Winograd convs contract on the BF16 matrix cores, operands split into three bf16 pieces
         self.bf = self.form == "bf16x6"
+        # ... and the narrow stages (<= 48 channels) run the direct bf16 x 6 kernel (narrow_bf.hip) instead of the fp32 Winograd one
+        self.amp_direct = use_amp_bf16x6(self.form)
         # plan-shaping environment switches, read once: every plan of this model uses this snapshot (planner.plan_switches)
         self.sw = plan_switches()
         self.rates = list(cfg["upsample_rates"])
@@ -189,8 +191,10 @@ class Vocoder:
             st["wcfg"], st["wpad"] = pick_wino54_tile(c, self.bf) if st["w54"] else (st["up_wcfg"], st["up_wpad"])
             st["taps"] = 4 if st["w54"] else 3
             # narrow stages (<= 48 channels): the residual-stack convs run on the narrow-stage kernel (planner.use_amp)
-            # (also in the bf16 x 6 form, which has no narrow-stage kernel of its own: those stages keep the fp32 one)
+            # (a bf16 x 6 model: in the direct bf16 x 6 form, narrow_bf.hip -- self.amp_direct)
             st["amp"] = use_amp(c, self.ks, self.dil, self.form)
+            pack_narrow = pack_narrow_bf_weight if self.amp_direct else pack_amp_weight
+            ua_key = "unb" if self.amp_direct else "ua"
             pack_res = (lambda w_: pack_wino54_weight_any(w_, st["wpad"], self.bf)) if st["w54"] else \
                 (lambda w_: pack_wino_weight_any(w_, st["wpad"], self.bf))
             wt = lambda i=i: g(f"ups.{i}.0.weight")               # [cin, c, k]
@@ -220,7 +224,7 @@ class Vocoder:
                         ent = dict(b=W.dev(f"v.{kn}.b", lambda kn=kn: g(kn + ".bias")))
                         w = lambda kn=kn: g(kn + ".weight")
                         if st["amp"] and all(self.dil[jj][m] == d for jj in range(self.nk)):
-                            ent["ua"] = W.dev(f"v.{kn}.ua", lambda w=w: pack_amp_weight(w(), c))
+                            ent["ua"] = W.dev(f"v.{kn}.{ua_key}", lambda w=w: pack_narrow(w(), c))
                         elif wino_k and use_wino(c, d, self.form) and all(self.dil[jj][m] == d for jj in range(self.nk)):
                             ent["u"] = W.dev(f"v.{kn}.u", lambda w=w: pack_res(w()))
                         else:
@@ -237,7 +241,7 @@ class Vocoder:
                         # convs1[m] of the nk blocks share one launch: Winograd only if they share the dilation
                         same_d = tag == "convs2" or all(self.dil[jj][m] == d for jj in range(self.nk))
                         if st["amp"] and same_d:
-                            ent["ua"] = W.dev(f"v.{kn}.ua", lambda w=w: pack_amp_weight(w(), c))
+                            ent["ua"] = W.dev(f"v.{kn}.{ua_key}", lambda w=w: pack_narrow(w(), c))
                         elif wino_k and use_wino(c, d, self.form) and same_d:
                             ent["u"] = W.dev(f"v.{kn}.u", lambda w=w: pack_res(w()))
                         else:

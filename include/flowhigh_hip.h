@@ -27,7 +27,7 @@ extern "C" {
 #define FH_E_ARG (-1)     /* bad argument / unsupported shape */
 #define FH_E_LAUNCH (-2)  /* HIP launch error */
 
-#define FH_ABI_VERSION 4
+#define FH_ABI_VERSION 5
 
 int fh_abi_version(void);
 const char* fh_last_error(void);
@@ -346,6 +346,25 @@ int fh_amp_tile_len(int dilation);     /* outputs per block and row: 320, 320, 3
 int fh_amp_max_channels(void);         /* 48 */
 int fh_amp_actconv_f32(const fh_amp_group* groups, int n_groups, const fh_amp_tile* tiles, int total_tiles, int channels,
                        int dilation, int max_center, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * The same launches in the bf16 x 6 form (conv_form = 'bf16x6'; narrow_bf.hip): the narrow stages' residual-stack convs as a
+ * DIRECT implicit GEMM on v_mfma_f32_16x16x32_bf16 -- every input sample is split once into three bf16 pieces (exact), a
+ * product is six MFMAs with fp32 accumulation (dropped terms <= 2^-24 |a b|), no Winograd transforms.  Replaces the same
+ * reference lines as fh_amp_actconv_f32 (bigvgan/models.py:63-72, :108-117, :181-187).  Same descriptors, read differently:
+ *   fh_amp_seg.ngrp = k (taps, 1 .. 11), fh_amp_seg.center = zero-padding on the left in taps (<= 5; "same": (k - 1) / 2);
+ *   fh_amp_seg.u = packing.pack_narrow_bf_weight: the channels' octets (8 channels) in slabs of at most three (24 channels: one
+ *     slab; 48: two of three octets; balanced otherwise); per slab ceil(k og / 4) k-blocks of 32 = four (tap, octet) pairs,
+ *     pair index q = tap og + octet; per k-block [N tile = 16 output channels][piece h, m, l][lane][8 bf16]: lane l holds
+ *     w[co = 16 n + (l & 15)][ci = 8 (slab's first octet + octet of pair 4 kb + (l >> 4))  + 0 .. 7][tap of that pair], zero past
+ *     the last pair / channel: ceil(C / 16) x 3 KB per k-block;
+ *   tiles: t0 a multiple of fh_narrow_tile_len() = 256 outputs per block and row, any dilation 1 .. 6.
+ * flags: bit 0 = every row of every group is 16-byte aligned (len % 4 == 0: vector accesses; same bits without).
+ * A sample's bits depend on its position in the row only (fixed K order): alone, batched, ragged and chunked runs agree.
+ * --------------------------------------------------------------------------------- */
+int fh_narrow_tile_len(void);          /* 256 */
+int fh_narrow_conv_bf16x6_f32(const fh_amp_group* groups, int n_groups, const fh_amp_tile* tiles, int total_tiles, int channels,
+                              int dilation, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 MFMA GEMM:  C[M, N] = epilogue( A[M, K] * W[N, K]^T )

@@ -1,5 +1,5 @@
-"""GPU: the narrow-stage conv kernel (amp_fused.hip: the AMP-block convs of the stages with <= 48 channels) against the float64
-definition of the conv, through the C ABI.  (The form with the Activation1d inside the launch, and its tests against the oracle's
+"""GPU: the narrow-stage conv kernels (the AMP-block convs of the stages with <= 48 channels: amp_fused.hip = fp32-MFMA Winograd
+F(5,4), narrow_bf.hip = direct bf16 x 6, parameter `direct`) against the float64 definition of the conv, through the C ABI.  (The form with the Activation1d inside the launch, and its tests against the oracle's
 activation, left with ABI 4: `git show 60fcf48:tests/test_hip_amp.py`.)"""
 import sys
 from pathlib import Path
@@ -25,6 +25,13 @@ def maxdiff(a, b):
     return float((a.double() - b.double()).abs().max())
 
 
+def pack(w, C, direct):
+    return (V.pack_narrow_bf_weight if direct else V.pack_amp_weight)(w, C)
+
+
+FORMS = pytest.mark.parametrize("direct", [False, True], ids=["winograd_f32", "direct_bf16x6"])
+
+
 def conv_ref(a, w, d):
     k = w.shape[-1]
     return F.conv1d(a.double(), w.double(), None, dilation=d, padding=(k - 1) // 2 * d)
@@ -33,42 +40,45 @@ def conv_ref(a, w, d):
 @pytest.mark.parametrize("C,k,d,L,B", [(24, 11, 1, 1000, 1), (24, 7, 3, 1201, 2), (48, 11, 5, 2000, 1), (48, 3, 1, 644, 2),
                                        (8, 7, 1, 333, 1), (16, 11, 3, 900, 1), (32, 5, 2, 1280, 1), (40, 9, 4, 777, 1),
                                        (48, 7, 6, 1500, 1), (24, 3, 5, 7, 1), (24, 11, 5, 24, 2), (48, 11, 1, 320, 1)])
-def test_amp_conv_only(C, k, d, L, B):
-    """flags bit 1: the conv alone (Winograd F(5,4), one wave per 16 tiles x 8 points) against float64, bias + residual + scale."""
+@FORMS
+def test_amp_conv_only(C, k, d, L, B, direct):
+    """The conv alone against float64, bias + residual + scale."""
     x, w, b = rnd(B, C, L, seed=1), rnd(C, C, k, seed=2, scale=1.0 / (C * k) ** 0.5), rnd(C, seed=3)
     r1 = rnd(B, C, L, seed=4)
     ref = ((conv_ref(x, w, d) + b.double()[None, :, None] + r1.double()) * 0.5).float()
     xd, rd, bd = x.to(DEV), r1.to(DEV), b.to(DEV)
     out = torch.full_like(xd, float("nan"))
-    ud = V.pack_amp_weight(w, C).to(DEV)
-    g = V.make_amp_group([V.make_amp_seg(xd, ud, k)], bd, [rd], out, L, scale=0.5)
-    keep = V.amp_actconv([g], B, C, d, DEV)
+    ud = pack(w, C, direct).to(DEV)
+    g = V.make_amp_group([V.make_amp_seg(xd, ud, k, direct=direct)], bd, [rd], out, L, scale=0.5, direct=direct)
+    keep = V.amp_actconv([g], B, C, d, DEV, direct=direct)
     torch.cuda.synchronize()
-    assert maxdiff(out.cpu(), ref) <= 2e-5
+    assert maxdiff(out.cpu(), ref) <= (4e-6 if direct else 2e-5)
     del keep
 
 
 @pytest.mark.parametrize("C,k,d,L,B", [(24, 11, 1, 1000, 1), (24, 7, 3, 1201, 2), (48, 11, 5, 2000, 1), (8, 3, 1, 5, 1),
                                        (32, 7, 2, 1283, 1), (24, 3, 1, 1, 1)])
-def test_amp_three_groups_in_one_launch(C, k, d, L, B):
+@FORMS
+def test_amp_three_groups_in_one_launch(C, k, d, L, B, direct):
     """Three groups (the AMP blocks of a stage) with their own weights, inputs and residuals in one launch."""
     groups, keep, refs, outs = [], [], [], []
     for j in range(3):
         x, w, b = rnd(B, C, L, seed=20 + j, scale=1.5), rnd(C, C, k, seed=30 + j, scale=1.0 / (C * k) ** 0.5), rnd(C, seed=40 + j)
         r1 = rnd(B, C, L, seed=50 + j)
         refs.append((conv_ref(x, w, d) + b.double()[None, :, None] + r1.double()).float())
-        xd, rd, bd, ud = x.to(DEV), r1.to(DEV), b.to(DEV), V.pack_amp_weight(w, C).to(DEV)
+        xd, rd, bd, ud = x.to(DEV), r1.to(DEV), b.to(DEV), pack(w, C, direct).to(DEV)
         out = torch.full_like(xd, float("nan"))
         keep += [xd, rd, bd, ud]
         outs.append(out)
-        groups.append(V.make_amp_group([V.make_amp_seg(xd, ud, k)], bd, [rd], out, L))
-    keep.append(V.amp_actconv(groups, B, C, d, DEV))
+        groups.append(V.make_amp_group([V.make_amp_seg(xd, ud, k, direct=direct)], bd, [rd], out, L, direct=direct))
+    keep.append(V.amp_actconv(groups, B, C, d, DEV, direct=direct))
     torch.cuda.synchronize()
     for j in range(3):
         assert maxdiff(outs[j].cpu(), refs[j]) <= 3e-5
 
 
-def test_amp_three_segments_fused_average():
+@FORMS
+def test_amp_three_segments_fused_average(direct):
     """The stage-closing position: one group, three K segments (k = 11 / 7 / 3 on three inputs), three residuals,
     scale 1 / 3 (models.py:181-187)."""
     C, L, B = 24, 1100, 2
@@ -78,15 +88,15 @@ def test_amp_three_segments_fused_average():
     for j, k in enumerate((3, 11, 7)):
         x, w = rnd(B, C, L, seed=80 + j, scale=1.5), rnd(C, C, k, seed=90 + j, scale=1.0 / (C * k) ** 0.5)
         total = total + conv_ref(x, w, 1)
-        xd, ud = x.to(DEV), V.pack_amp_weight(w, C).to(DEV)
+        xd, ud = x.to(DEV), pack(w, C, direct).to(DEV)
         keep += [xd, ud]
-        segs.append(V.make_amp_seg(xd, ud, k))
+        segs.append(V.make_amp_seg(xd, ud, k, direct=direct))
     ref = ((total + bias.double()[None, :, None] + sum(r.double() for r in res)) / 3.0).float()
     rd = [r.to(DEV) for r in res]
     out = torch.full((B, C, L), float("nan"), device=DEV)
     bd = bias.to(DEV)            # (descriptors hold raw pointers: every tensor they name must outlive the launch)
-    g = V.make_amp_group(segs, bd, rd, out, L, scale=1.0 / 3.0)
-    keep.append(V.amp_actconv([g], B, C, 1, DEV))
+    g = V.make_amp_group(segs, bd, rd, out, L, scale=1.0 / 3.0, direct=direct)
+    keep.append(V.amp_actconv([g], B, C, 1, DEV, direct=direct))
     torch.cuda.synchronize()
     assert maxdiff(out.cpu(), ref) <= 3e-5
 
@@ -102,20 +112,21 @@ def test_amp_refuses_the_form_that_left_with_abi_4():
     assert rc != 0 and "left the library" in hip.lib().fh_last_error().decode()
 
 
+@FORMS
 @pytest.mark.parametrize("d", [1, 3, 5])
-def test_amp_ragged_groups_and_alignment_give_the_same_bits(d):
+def test_amp_ragged_groups_and_alignment_give_the_same_bits(d, direct):
     """Groups of different lengths in one launch (ragged batches), a clip inside a batch, and rows that are not 16-byte
     aligned (4-byte accesses): every clip gets the bits of its own single-group, aligned launch."""
     C, k = 24, 7
     w, b = rnd(C, C, k, seed=6, scale=0.1), rnd(C, seed=7)
-    ud, bd = V.pack_amp_weight(w, C).to(DEV), b.to(DEV)
+    ud, bd = pack(w, C, direct).to(DEV), b.to(DEV)
     lens = [1203, 320, 2000, 17]
     xs = [rnd(1, C, L, seed=200 + i, scale=1.5).to(DEV) for i, L in enumerate(lens)]
 
     def run(items, batch=1):
         outs = [torch.full_like(x, float("nan")) for x in items]
-        gs = [V.make_amp_group([V.make_amp_seg(x, ud, k)], bd, [x], o, x.shape[-1]) for x, o in zip(items, outs)]
-        keep = V.amp_actconv(gs, batch, C, d, DEV)
+        gs = [V.make_amp_group([V.make_amp_seg(x, ud, k, direct=direct)], bd, [x], o, x.shape[-1], direct=direct) for x, o in zip(items, outs)]
+        keep = V.amp_actconv(gs, batch, C, d, DEV, direct=direct)
         torch.cuda.synchronize()
         del keep
         return outs
@@ -128,7 +139,8 @@ def test_amp_ragged_groups_and_alignment_give_the_same_bits(d):
     xb = torch.cat([xs[0].flip(-1), xs[0]], dim=0).contiguous()
     assert torch.equal(run([xb], batch=2)[0][1:], alone[0])
     # a chunk of the clip that starts on a block boundary of every dilation: its inner samples keep their bits
-    s = 1200
+    # (the direct form's bits do not depend on where a chunk starts at all: any start)
+    s = 1203 if direct else 1200
     tail = run([xs[2][..., s:].contiguous()])[0]
     halo = ((k - 1) // 2 + 5) * d             # taps + the other inputs of an F(5,4) tile (rounding)
     assert torch.equal(tail[..., halo:], alone[2][..., s + halo:])

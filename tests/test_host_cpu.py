@@ -403,14 +403,27 @@ def test_conv_form_keyword_and_environment(monkeypatch):
         wide, narrow = voc.stages[0], voc.stages[-1]
         e = wide["blocks"][0]["c1"][0]
         assert ("u" in e) == (f != "direct") and ("w" in e) == (f == "direct")
-        assert ("ua" in narrow["blocks"][0]["c1"][0]) == (f != "direct")            # the narrow-stage kernel: fp32 in both Winograd forms
+        assert ("ua" in narrow["blocks"][0]["c1"][0]) == (f != "direct")            # a narrow-stage kernel in both other forms:
+        assert voc.amp_direct == (f == "bf16x6")                                    # fp32 Winograd / direct bf16 x 6
+        if f != "direct":
+            c, k = narrow["c"], voc.ks[0]
+            from flowhigh_amd import packing
+            want = packing.pack_narrow_bf_weight if f == "bf16x6" else packing.pack_amp_weight
+            assert narrow["blocks"][0]["c1"][0]["ua"].numel() == want(torch.zeros(c, c, k), c).numel()
         if f != "direct":
             assert e["u"].dtype == (torch.int16 if f == "bf16x6" else torch.float32)
             assert wide["w54"] and wide["wcfg"] == (P.WINO_F54 | 1 if f == "bf16x6" else P.WINO_F54 | 0)
     assert Vocoder(cfg, sd, "cpu").form == P.DEFAULT_CONV_FORM and Vocoder(cfg, sd, "cpu").form_auto
-    # the bf16 x 6 launch plan: wide stages on the F(5,4) bf16 x 6 kernel (96- / 64-row blocks only), narrow ones on the amp kernel
+    # the bf16 x 6 launch plan: wide stages on the F(5,4) bf16 x 6 kernel (96- / 64-row blocks only), narrow ones on the direct
+    # bf16 x 6 kernel (FH_AMP_BF16X6=0: on the fp32 Winograd one, an A/B switch that is part of the blob's format tag)
     fams = {n for n, _, _ in forms["bf16x6"].plan(1, 100)["conv_launches"]}
-    assert fams == {"wino54_bf16x6", "wino43_bf16x6", "amp", "direct"}
+    assert fams == {"wino54_bf16x6", "wino43_bf16x6", "narrow_bf16x6", "direct"}
+    monkeypatch.setenv("FH_AMP_BF16X6", "0")
+    tag0 = weights.format_tag("bf16x6")
+    old_narrow = Vocoder(cfg, sd, "cpu", conv_form="bf16x6")
+    monkeypatch.delenv("FH_AMP_BF16X6")
+    assert not old_narrow.amp_direct and tag0 != weights.format_tag("bf16x6")
+    assert {n for n, _, _ in old_narrow.plan(1, 100)["conv_launches"]} == {"wino54_bf16x6", "wino43_bf16x6", "amp", "direct"}
     assert {n for n, _, _ in forms["winograd"].plan(1, 100)["conv_launches"]} == {"wino54", "wino43", "amp", "direct"}
     assert {n for n, _, _ in forms["direct"].plan(1, 100)["conv_launches"]} == {"direct"}
     # a store that holds another form's tensors is refused at construction

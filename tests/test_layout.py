@@ -178,6 +178,39 @@ def test_pack_wino54_weight_is_the_f54_transform_of_the_conv(c, k):
     assert (y - ref).abs().max().item() <= 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("c,co,ci,k", [(24, 24, 24, 11), (48, 48, 48, 7), (32, 32, 32, 3), (40, 33, 40, 5), (8, 8, 5, 1), (16, 16, 16, 11)])
+def test_pack_narrow_bf_weight_is_the_conv_in_k_blocks(c, co, ci, k):
+    """pack_narrow_bf_weight as narrow_bf.hip reads it: per slab (narrow_slabs) and k-block, lane l of [N tile][piece] holds the
+    8 input channels of pair q = 4 kb + (l >> 4) = tap og + octet for output channel 16 n + (l & 15); the three bf16 pieces sum to
+    the fp32 weight EXACTLY, padding pairs / rows / channels are zero, and the size is what the kernel's cursor advances by."""
+    from flowhigh_amd import packing as P
+    g = torch.Generator().manual_seed(k + c)
+    w = torch.randn(co, ci, k, generator=g)
+    u = P.pack_narrow_bf_weight(w, c)
+    ma = -(-c // 16)
+    slabs = P.narrow_slabs(c)
+    assert sum(og for _, og in slabs) == c // 8 and all(og <= 3 for _, og in slabs)
+    assert u.numel() * 4 == sum(-(-(k * og) // 4) for _, og in slabs) * ma * 3 * 1024
+    pieces = u.view(torch.int16).view(torch.bfloat16).float()
+    back, pos = torch.zeros(16 * ma, c, k), 0
+    for ob, og in slabs:
+        nb = -(-(k * og) // 4)
+        blk = pieces[pos:pos + nb * ma * 3 * 512].view(nb, ma, 3, 64, 8)
+        pos += nb * ma * 3 * 512
+        full = blk[:, :, 0] + blk[:, :, 1] + blk[:, :, 2]             # exact: h + m + l is the fp32 value
+        for kb in range(nb):
+            for lg in range(4):
+                q = 4 * kb + lg
+                vals = full[kb, :, 16 * lg:16 * lg + 16]              # [na, n, 8]
+                if q >= k * og:
+                    assert float(vals.abs().max()) == 0.0
+                    continue
+                tap, o = divmod(q, og)
+                back[:, 8 * (ob + o):8 * (ob + o) + 8, tap] = vals.reshape(16 * ma, 8)
+    assert torch.equal(back[:co, :ci], w) and float(back[co:].abs().max() if co < 16 * ma else 0.0) == 0.0
+    assert float(back[:, ci:].abs().max() if ci < c else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("L,d,pm", [(5000, 5, 1), (5000, 3, 1), (20000, 5, 1), (250, 5, 1), (13, 3, 1), (1, 1, 1), (5000, 5, 0), (777, 1, 0)])
 def test_wino54_tile_counts_host_and_library_agree(L, d, pm):
     """vocoder.wino_n_tiles (run maps, launch model) = fh_wino54_n_tiles (the launcher): phase-major rows are tiled as one
