@@ -28,7 +28,7 @@ from .packing import (  # noqa: F401
     pack_wino54_weight, pack_wino54_weight_any, pack_wino_weight, pack_wino_weight_any, phase_len, pick_ck, split_bf3, to_phase_major,
     transposed_conv_extra, transposed_conv_phases, wino_phase_weight)
 from .planner import (  # noqa: F401
-    AMP_MAX_D, WINO54_MIN_C, WINO_BF16X6, WINO_BM, WINO_F54, WINO_MAX_K, WINO_MIN_C, WINO_NARROW, WINO_NOVL,
+    AMP_DIRECT, AMP_MAX_D, WINO54_MIN_C, WINO_BF16X6, WINO_BM, WINO_F54, WINO_MAX_K, WINO_MIN_C, WINO_NARROW, WINO_NOVL,
     WINO_UPS_MIN_CIN, WINO_XCD_RANGES, _PlanBuilder, _TILE_PREF, _WINO_BF_SPEED, _WINO_COST, _WINO_RUN,
     _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_max_center,
     amp_tile_len, amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,

@@ -45,7 +45,8 @@ for i, (s, (fam, ex, fl)) in enumerate(zip(convs, launches)):
         blocks = ng * s[9] * (cpad // bm) * V.wino_n_tiles(wcfg | f54, n_len, d_, _pm)
     elif s[0] == 'amp':
         _, d, ng, tiles, nt, c, d_ = s[:7]
-        bm, bn, cpad, n_len, blocks = c, V.amp_tile_len(d_), c, p["L"] if False else 0, nt
+        bn = V.hip.lib().fh_narrow_tile_len() if s[9] & V.AMP_DIRECT else V.amp_tile_len(d_)
+        bm, cpad, n_len, blocks = c, c, 0, nt
     else:
         _, d, ng, cpad, n_len, tcfg = s[:6]
         bm, bn = TILES[tcfg]

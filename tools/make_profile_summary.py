@@ -17,7 +17,7 @@ short = lambda n: n.replace('void ', '').replace('(anonymous namespace)::', '').
 def agg(keys):
     sel = [r for r in rows if any(k in r['Name'] for k in keys)]
     return sum(int(r['Calls']) for r in sel), sum(float(r['TotalDurationNs']) for r in sel)
-ccalls, ctot = agg(('conv_mfma_kernel', 'conv_wino_kernel', 'conv_wino54_kernel', 'amp_actconv_kernel'))
+ccalls, ctot = agg(('conv_mfma_kernel', 'conv_wino_kernel', 'conv_wino54_kernel', 'amp_actconv_kernel', 'narrow_bf_kernel'))
 acalls, atot = agg(('act1d_strip_kernel',))
 rl, rh = line['roofline'], line['roofline_hbm']
 rnd = int(''.join(ch for ch in tag[1:3] if ch.isdigit()))
@@ -29,7 +29,7 @@ o = [f"# Round {rnd} profile summary (1 x MI355X, B = {bsuf[1:]}, 10 s clips, 12
      f"* conv form `{line['config'].get('conv_form')}` (dtype: {line['dtype']}).  Dominant kernel family `{next(iter(rl['by_family']))}`: {rl['kernel']}: "
      f"{rl['launches_per_step']} launches per step, {rl['avg_launch_us']} us each (HIP events, un-profiled run; profiled run: {prl['avg_launch_us']} us) "
      f"-> **{rl['achieved']} TFLOP/s on its matrix instructions = {rl['frac']} of the {rl['peak']} TFLOP/s peak**.",
-     f"* all conv launches (conv_wino54_kernel + amp_actconv_kernel + conv_wino_kernel + conv_mfma_kernel): {ccalls} launches, average duration **{ctot / ccalls / 1e3:.1f} us** under the "
+     f"* all conv launches (conv_wino54_kernel + narrow_bf_kernel / amp_actconv_kernel + conv_wino_kernel + conv_mfma_kernel): {ccalls} launches, average duration **{ctot / ccalls / 1e3:.1f} us** under the "
      f"profiler; bench.py HIP events in the same run: {prl['all_conv']['avg_launch_us']} us; un-profiled bench run: {rl['all_conv']['avg_launch_us']} us "
      f"-> {rl['all_conv']['executed_fp32_equiv_tflops']} TFLOP/s executed in fp32-equivalent FLOPs = {rl['all_conv']['frac_of_fp32_mfma_peak']} of the 157.3 TFLOP/s fp32 MFMA peak "
      f"({rl['all_conv']['executed_gflop_per_launch']} GFLOP per launch; direct-form equivalent {rl['all_conv']['algorithmic_equiv']} TFLOP/s = {rl['all_conv']['algorithmic_equiv_frac']}: "

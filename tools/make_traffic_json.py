@@ -28,7 +28,7 @@ def source_fingerprint(root):
 def main():
     fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
     which = sys.argv[4] if len(sys.argv) > 4 else "conv"
-    names = {"conv": ("conv_mfma_kernel", "conv_wino_kernel", "conv_wino54_kernel", "amp_actconv_kernel"),
+    names = {"conv": ("conv_mfma_kernel", "conv_wino_kernel", "conv_wino54_kernel", "amp_actconv_kernel", "narrow_bf_kernel"),
              "act": ("act1d_strip_kernel",)}[which]
 
     def total(d, name):
