@@ -144,3 +144,15 @@ def test_amp_ragged_groups_and_alignment_give_the_same_bits(d, direct):
     tail = run([xs[2][..., s:].contiguous()])[0]
     halo = ((k - 1) // 2 + 5) * d             # taps + the other inputs of an F(5,4) tile (rounding)
     assert torch.equal(tail[..., halo:], alone[2][..., s + halo:])
+
+
+@pytest.mark.parametrize("form", ["direct", "winograd"])
+def test_narrow_kernels_randomised_configurations(form):
+    """tests/tools/narrow_fuzz.py as a test: 150 random (channels, taps, dilation, batch, ragged lengths, K segments, residuals,
+    bias, scale) launches of each narrow-stage kernel against float64 F.conv1d (5e-6 direct bf16 x 6, 3e-5 Winograd fp32)."""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tests" / "tools" / "narrow_fuzz.py"), "150", "11", form], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "FAIL" not in r.stdout and "150 cases" in r.stdout and " 0 failures" in r.stdout, r.stdout[-2000:]
