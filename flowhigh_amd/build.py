@@ -8,7 +8,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libflowhigh_hip.so"
-SOURCES = ["api_common.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino54.hip", "conv_wino54_bf.hip", "amp_fused.hip", "narrow_bf.hip", "act1d.hip", "gemm_mfma.hip", "flow_ops.hip",
+SOURCES = ["api_common.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino54.hip", "conv_wino54_bf.hip", "amp_fused.hip", "narrow_bf.hip", "act1d.hip", "gemm_mfma.hip", "gemm_bf.hip", "flow_ops.hip",
            "attention.hip", "frontend.hip", "fft.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-source extra flags.  The bf16 x 6 kernels keep everything beside their MFMAs one result per lane: the SLP vectoriser

@@ -19,7 +19,8 @@ from .vocoder import Vocoder
 def build_store(sd, cfg, device="cpu", record=True, conv_form=None):
     """Run both constructors through one recording store (the order of the keys is the file order)."""
     store = weights.WeightStore(device, record=record)
-    FlowNet(sd, device, store=store)
+    from .planner import resolve_conv_form, use_gemm_bf16x6
+    FlowNet(sd, device, store=store, bf=use_gemm_bf16x6(resolve_conv_form(conv_form)[0]))
     Vocoder(cfg, sd, device, store=store, conv_form=conv_form)
     return store
 

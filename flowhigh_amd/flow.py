@@ -52,7 +52,7 @@ def pack_geglu(w, b):
 
 
 class FlowNet:
-    def __init__(self, sd, device, depth=2, heads=16, dim_head=64, store=None):
+    def __init__(self, sd, device, depth=2, heads=16, dim_head=64, store=None, bf=False):
         if dim_head != 64:
             raise NotImplementedError("dim_head must be 64")
         self.device = hip.norm_device(device)
@@ -62,14 +62,22 @@ class FlowNet:
         W = store if store is not None else WeightStore(dev)
         g = lambda name: sd[FH + name].detach().float().cpu()
         self.depth, self.heads = depth, heads
+        # bf: the linears run in the bf16 x 6 form (gemm_bf.hip: six bf16 MFMAs per product over exact three-piece splits,
+        # fp32-grade; the model's conv_form = 'bf16x6'): their weights are stored split (6 bytes per weight)
+        self.bf = bool(bf)
+        if self.bf:
+            from .packing import pack_gemm_bf_weight
+            dev_w = lambda key, make: W.dev(key + ".bf3", lambda: pack_gemm_bf_weight(make()))
+        else:
+            dev_w = W.dev
         w_embed = lambda: g("to_embed.weight")
         dims = W.host("f.dims", lambda: torch.tensor([w_embed().shape[0], w_embed().shape[1] // 2,
                                                       g("conv_embed.dw_conv1d.0.weight").shape[-1]], dtype=torch.int32)).tolist()
         self.dim, self.dim_in, self.dw_k = dims
         if self.dim % 256 or self.dim_in % 32 or heads * dim_head != self.dim:
             raise NotImplementedError("unsupported transformer dims")
-        self.w_x = W.dev("f.w_x", lambda: _pad_rows(w_embed()[:, :self.dim_in]))
-        self.w_c = W.dev("f.w_c", lambda: _pad_rows(w_embed()[:, self.dim_in:]))
+        self.w_x = dev_w("f.w_x", lambda: _pad_rows(w_embed()[:, :self.dim_in]))
+        self.w_c = dev_w("f.w_c", lambda: _pad_rows(w_embed()[:, self.dim_in:]))
         self.b_embed = W.dev("f.b_embed", lambda: g("to_embed.bias"))
         self.null_cond = W.dev("f.null_cond", lambda: g("null_cond").reshape(1, -1))
         self._e_null = None
@@ -97,10 +105,10 @@ class FlowNet:
             self.layers.append(dict(
                 gq=W.dev(k + "gq", lambda: g(p + "3.q_norm.gamma").reshape(heads, 64)),
                 gk=W.dev(k + "gk", lambda: g(p + "3.k_norm.gamma").reshape(heads, 64)),
-                w_qkv=W.dev(k + "w_qkv", lambda: _pad_rows(g(p + "3.to_qkv.weight"))),
-                w_out=W.dev(k + "w_out", lambda: _pad_rows(g(p + "3.to_out.weight"))),
-                w1=W.dev(k + "w1", lambda: ff1()["w1"]), b1=W.dev(k + "b1", lambda: ff1()["b1"]),
-                w2=W.dev(k + "w2", w2_padded), b2=W.dev(k + "b2", lambda: g(p + "5.3.bias")),
+                w_qkv=dev_w(k + "w_qkv", lambda: _pad_rows(g(p + "3.to_qkv.weight"))),
+                w_out=dev_w(k + "w_out", lambda: _pad_rows(g(p + "3.to_out.weight"))),
+                w1=dev_w(k + "w1", lambda: ff1()["w1"]), b1=W.dev(k + "b1", lambda: ff1()["b1"]),
+                w2=dev_w(k + "w2", w2_padded), b2=W.dev(k + "b2", lambda: g(p + "5.3.bias")),
                 inner_pad=int(W.host(k + "inner_pad", lambda: torch.tensor([ff1()["inner_pad"]], dtype=torch.int32))[0])))
 
         def gamma_beta(which_tensor):
@@ -113,9 +121,12 @@ class FlowNet:
         self.gb_w = W.dev("f.gb_w", lambda: gamma_beta("weight"))      # [depth*4*dim, dim]
         self.gb_b = W.dev("f.gb_b", lambda: gamma_beta("bias"))
         self.final_gamma = W.dev("f.final_gamma", lambda: g("transformer.final_norm.gamma"))
-        self.w_pred = W.dev("f.w_pred", lambda: _pad_rows(g("to_pred.weight")))
+        self.w_pred = dev_w("f.w_pred", lambda: _pad_rows(g("to_pred.weight")))
         self.inv_freq = W.host("f.inv_freq", lambda: g("transformer.rotary_emb.inv_freq"))
         self._ws = hip.ShapeCache()
+
+    def gemm(self, A, W, C_out, M, N, K, **kw):
+        return hip.gemm(A, W, C_out, M, N, K, bf=self.bf, **kw)
 
     @hip.on_device
     def workspace(self, batch, n):
@@ -164,7 +175,7 @@ class FlowNet:
         """cond [B*n, dim_in] (log-mel of the low-res clip): e_cond = cond @ W_c^T + b."""
         ws = ragged if ragged is not None else self.workspace(batch, n)
         M = ragged["rows"] if ragged is not None else batch * n
-        hip.gemm(cond, self.w_c, ws["e_cond"], M, self.dim, self.dim_in, bias=self.b_embed)
+        self.gemm(cond, self.w_c, ws["e_cond"], M, self.dim, self.dim_in, bias=self.b_embed)
 
     @hip.on_device
     def forward(self, x, t, out, batch, n, alpha=1.0, res=None, null_cond=False, ragged=None):
@@ -184,10 +195,10 @@ class FlowNet:
         if null_cond:
             if self._e_null is None:            # null_cond @ W_c^T + b: one row, broadcast with ldr = 0
                 self._e_null = torch.empty(1, D, dtype=torch.float32, device=self.device)
-                hip.gemm(self.null_cond, self.w_c, self._e_null, 1, D, self.dim_in, bias=self.b_embed)
-            hip.gemm(x, self.w_x, h, M, D, self.dim_in, R=self._e_null, ldr=0)
+                self.gemm(self.null_cond, self.w_c, self._e_null, 1, D, self.dim_in, bias=self.b_embed)
+            self.gemm(x, self.w_x, h, M, D, self.dim_in, R=self._e_null, ldr=0)
         else:
-            hip.gemm(x, self.w_x, h, M, D, self.dim_in, R=ws["e_cond"])
+            self.gemm(x, self.w_x, h, M, D, self.dim_in, R=ws["e_cond"])
         if seg is None:
             hip.check(L.fh_dwconv_gelu_res_f32(h.data_ptr(), self.dw_w.data_ptr(), self.dw_b.data_ptr(),
                                                h2.data_ptr(), batch, n, D, self.dw_k, st), "fh_dwconv_gelu_res_f32")
@@ -207,7 +218,7 @@ class FlowNet:
             g1, b1, g2, b2 = (gb[o + i * D: o + (i + 1) * D] for i in range(4))
             hip.check(L.fh_rmsnorm_f32(cur.data_ptr(), g1.data_ptr(), b1.data_ptr(), a.data_ptr(), M, D, st),
                       "fh_rmsnorm_f32")
-            hip.gemm(a, lay["w_qkv"], qkv, M, 3 * D, D)
+            self.gemm(a, lay["w_qkv"], qkv, M, 3 * D, D)
             if seg is None:
                 hip.check(L.fh_qknorm_rope_f32(qkv.data_ptr(), lay["gq"].data_ptr(), lay["gk"].data_ptr(),
                                                ws["cos"].data_ptr(), ws["sin"].data_ptr(), batch, n, self.heads, st),
@@ -220,15 +231,15 @@ class FlowNet:
                                                    self.heads, st), "fh_qknorm_rope_seg_f32")
                 hip.check(L.fh_attention_seg_f32(qkv.data_ptr(), att.data_ptr(), seg, n_seg, max_n, self.heads, 10.0, st),
                           "fh_attention_seg_f32")
-            hip.gemm(att, lay["w_out"], other, M, D, D, R=cur)
+            self.gemm(att, lay["w_out"], other, M, D, D, R=cur)
             cur, other = other, cur
             hip.check(L.fh_rmsnorm_f32(cur.data_ptr(), g2.data_ptr(), b2.data_ptr(), a.data_ptr(), M, D, st),
                       "fh_rmsnorm_f32")
             ip = lay["inner_pad"]
-            hip.gemm(a, lay["w1"], ws["g"], M, 2 * ip, D, bias=lay["b1"], epilogue=hip.EPI_GEGLU, ldc=ws["g"].shape[1])
-            hip.gemm(ws["g"], lay["w2"], other, M, D, ip, bias=lay["b2"], R=cur, lda=ws["g"].shape[1])
+            self.gemm(a, lay["w1"], ws["g"], M, 2 * ip, D, bias=lay["b1"], epilogue=hip.EPI_GEGLU, ldc=ws["g"].shape[1])
+            self.gemm(ws["g"], lay["w2"], other, M, D, ip, bias=lay["b2"], R=cur, lda=ws["g"].shape[1])
             cur, other = other, cur
         hip.check(L.fh_rmsnorm_f32(cur.data_ptr(), self.final_gamma.data_ptr(), 0, a.data_ptr(), M, D, st),
                   "fh_rmsnorm_f32")
-        hip.gemm(a, self.w_pred, out, M, self.dim_in, D, R=res, alpha=alpha)
+        self.gemm(a, self.w_pred, out, M, self.dim_in, D, R=res, alpha=alpha)
         return out

@@ -206,7 +206,10 @@ class FLowHigh:
             if missing:
                 raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
         with hip.device_guard(device):
-            self.net = FlowNet(state_dict, device, depth=depth, store=store)
+            # (the transformer's linears follow the REQUESTED form -- bf16 x 6 linears have no Winograd transform to be ill-conditioned,
+            # so a probe that moves the vocoder to the direct form below leaves them as they are)
+            from .planner import resolve_conv_form, use_gemm_bf16x6
+            self.net = FlowNet(state_dict, device, depth=depth, store=store, bf=use_gemm_bf16x6(resolve_conv_form(conv_form, conv_bf16x6)[0]))
             # conv_form: the arithmetic form of the vocoder's convs, 'auto' | 'winograd' | 'bf16x6' | 'direct'
             # (planner.resolve_conv_form; None: FH_CONV_FORM / the older switches, else 'auto'.  conv_bf16x6: the boolean keyword
             # of rounds 2-5.)  'auto' = the default form, checked once against the direct form through THESE weights when the

@@ -115,6 +115,7 @@ _SIGS = {
     "fh_dwconv_gelu_res_seg_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "fh_qknorm_rope_seg_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "fh_gemm_f32": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P],
+    "fh_gemm_bf16x6_f32": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P],
     "fh_gemv_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
     "fh_time_fourier_f32": [_P, _F, _P, _I, _P],
     "fh_dwconv_gelu_res_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -303,11 +304,16 @@ def _f32c(t, name):
 
 
 def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, alpha=1.0, epilogue=EPI_LINEAR, lda=None,
-         ldc=None, ldr=None):
-    """C[M, N or N/2] = epi(A[M,K] @ W[N,K]^T).  W must have rows padded to a multiple of 128."""
+         ldc=None, ldr=None, bf=False):
+    """C[M, N or N/2] = epi(A[M,K] @ W[N,K]^T).  W must have rows padded to a multiple of 128.
+    bf: the bf16 x 6 form (fh_gemm_bf16x6_f32): W = packing.pack_gemm_bf_weight of such a matrix (6 bytes per weight)."""
     for t, n in ((A, "A"), (W, "W"), (C_out, "C"), (bias, "bias"), (R, "R")):
         _f32c(t, n)
-    if W.shape[0] % 128 or W.shape[1] != K:
+    if bf:
+        n_pad = -(-N // 128) * 128
+        if W.numel() * 4 != n_pad * K * 6:
+            raise HipError(f"gemm: packed bf16 x 6 W of {W.numel() * 4} bytes does not fit [{n_pad}, {K}] x 6 bytes")
+    elif W.shape[0] % 128 or W.shape[1] != K:
         raise HipError(f"gemm: W must be [n_pad % 128 == 0, K], got {tuple(W.shape)} K={K}")
     lda = lda if lda is not None else A.shape[-1]
     out_w = N // 2 if epilogue in (EPI_GEGLU, EPI_MAG) else N
@@ -315,6 +321,7 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, alpha=1.0, epilogue=EPI_LIN
     ldr = ldr if ldr is not None else (R.shape[-1] if R is not None else 0)
     if ldc < out_w:
         raise HipError("gemm: output row too short")
-    check(lib().fh_gemm_f32(ptr(A), lda, ptr(W), ptr(bias), ptr(R), ldr, ptr(C_out), ldc, M, N, K,
-                            float(alpha), epilogue, stream()), "fh_gemm_f32")
+    fn = lib().fh_gemm_bf16x6_f32 if bf else lib().fh_gemm_f32
+    check(fn(ptr(A), lda, ptr(W), ptr(bias), ptr(R), ldr, ptr(C_out), ldc, M, N, K,
+             float(alpha), epilogue, stream()), "fh_gemm_bf16x6_f32" if bf else "fh_gemm_f32")
     return C_out

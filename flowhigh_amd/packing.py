@@ -130,6 +130,21 @@ def pack_amp_weight(w, channels=None):
     return torch.cat(parts, dim=-1).contiguous()
 
 
+def pack_gemm_bf_weight(w):
+    """Linear weight [n_pad, K] (n_pad % 64 == 0, K % 32 == 0; rows past N zero) -> the bf16 x 6 GEMM's weights (gemm_bf.hip,
+    fh_gemm_bf16x6_f32): float32 container of bf16 bit patterns [n_pad / 64][K / 32][piece h, m, l][k-octet][64 rows][8 bf16]."""
+    n_pad, k = w.shape
+    if n_pad % 64 or k % 32:
+        raise ValueError(f"bf16 x 6 GEMM weight: [{n_pad}, {k}] (rows a multiple of 64, K of 32)")
+    w = w.float()
+    h = w.to(torch.bfloat16)
+    r = w - h.float()
+    m = r.to(torch.bfloat16)
+    l = (r - m.float()).to(torch.bfloat16)
+    p = torch.stack([h, m, l], dim=0).view(3, n_pad // 64, 64, k // 32, 4, 8)           # [piece, granule, row, stage, octet, e]
+    return p.permute(1, 3, 0, 4, 2, 5).contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+
+
 def narrow_slabs(channels):
     """[(first octet, octets)] of the slabs the bf16 x 6 narrow-stage kernel cuts `channels` into (narrow_bf.hip: at most three
     octets = 24 channels per slab, balanced: 24 -> (0, 3); 48 -> (0, 3), (3, 3); 32 -> (0, 2), (2, 2); 40 -> (0, 3), (3, 2))."""

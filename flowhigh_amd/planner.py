@@ -298,6 +298,13 @@ def plan_switches():
     return dict(splitk=os.environ.get("FH_WINO_SPLITK", "1") != "0", ups_fuse=os.environ.get("FH_UPS_FUSE", "1") != "0")
 
 
+def use_gemm_bf16x6(form=None):
+    """The transformer's linears of a bf16 x 6 model run in the bf16 x 6 form too (gemm_bf.hip; flow.FlowNet(bf=)).
+    FH_GEMM_BF16X6=0: on the fp32 matrix instructions (A/B; part of the weight blob's format tag)."""
+    form = resolve_conv_form()[0] if form is None else form
+    return form == "bf16x6" and os.environ.get("FH_GEMM_BF16X6", "1") != "0"
+
+
 def amp_tile_len(d):
     """Outputs per block and row of the narrow-stage kernel at dilation d (fh_amp_tile_len)."""
     return 5 * d * 4 * (16 // d)

@@ -389,6 +389,15 @@ int fh_gemm_f32(const float* A, int lda, const float* W, const float* bias, cons
                 int ldr, float* C, int ldc, int M, int N, int K, float alpha, int epilogue,
                 void* stream);
 
+/* The same GEMM in the bf16 x 6 form (gemm_bf.hip; the transformer's linears of a conv_form = 'bf16x6' model): fp32 in / out /
+ * accumulate, every product as six v_mfma_f32_32x32x16_bf16 over exact three-piece bf16 splits (dropped terms <= 2^-24 |a b|).
+ * A is split by the kernel on its way into LDS; Wp = packing.pack_gemm_bf_weight(W [n_pad, K]): bf16 bit patterns
+ * [n_pad / 64][K / 32][piece h, m, l][k-octet 0..3][64 rows][8 bf16] (6 bytes per weight).  Same arguments, epilogues and
+ * restrictions as fh_gemm_f32 (flow.py:239,261; attend.py:170-171; transformer.py:98-104). */
+int fh_gemm_bf16x6_f32(const float* A, int lda, const float* Wp, const float* bias, const float* R,
+                       int ldr, float* C, int ldc, int M, int N, int K, float alpha, int epilogue,
+                       void* stream);
+
 /* y[n] = act(bias[n] + sum_k W[n, k] * x[k]),  act: 0 none, 1 SiLU.  One vector (the time
  * embedding is the same for every clip: flow.py:208-211,242; transformer.py:81-83). */
 int fh_gemv_f32(const float* W, const float* x, const float* bias, float* y, int N, int K,

@@ -667,19 +667,31 @@ def pad_rows(w):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 1024, 1024), (37, 256, 256), (4096, 2048, 512), (130, 3072, 1024)])
-def test_gemm_linear(M, N, K):
+@pytest.mark.parametrize("bf", [False, True], ids=["f32", "bf16x6"])
+def test_gemm_linear(M, N, K, bf):
+    """fp32-MFMA GEMM and (bf) the bf16 x 6 form (gemm_bf.hip: six bf16 MFMAs per product over exact three-piece splits) against
+    float64, SAME tolerance."""
+    from flowhigh_amd.packing import pack_gemm_bf_weight
     a, w, b, r = rnd(M, K, seed=100), rnd(N, K, seed=101, scale=K ** -0.5), rnd(N, seed=102), rnd(M, N, seed=103)
-    ref = 0.25 * F.linear(a, w, b) + r
+    ref = 0.25 * F.linear(a.double(), w.double(), b.double()) + r.double()
     out = torch.full((M, N), float("nan"), device=DEV)
-    hip.gemm(a.to(DEV), pad_rows(w).to(DEV), out, M, N, K, bias=b.to(DEV), R=r.to(DEV), alpha=0.25)
+    wd = (pack_gemm_bf_weight(pad_rows(w)) if bf else pad_rows(w)).to(DEV)
+    hip.gemm(a.to(DEV), wd, out, M, N, K, bias=b.to(DEV), R=r.to(DEV), alpha=0.25, bf=bf)
     assert maxdiff(out, ref) <= 1e-5
     out2 = torch.empty(M, N, device=DEV)
-    hip.gemm(a.to(DEV), pad_rows(w).to(DEV), out2, M, N, K)
-    assert maxdiff(out2, F.linear(a, w)) <= 1e-5
+    hip.gemm(a.to(DEV), wd, out2, M, N, K, bf=bf)
+    assert maxdiff(out2, F.linear(a.double(), w.double())) <= 1e-5
+    if bf:      # large and tiny operands: the split is exact at every magnitude (bf16 has fp32's exponent range)
+        a2 = a * torch.logspace(-6, 6, K)[None, :]
+        hip.gemm(a2.to(DEV), wd, out2, M, N, K, bf=True)
+        ref2 = F.linear(a2.double(), w.double())
+        assert maxdiff(out2, ref2) <= 2e-6 * float(ref2.abs().max())
 
 
-def test_gemm_geglu_packed():
+@pytest.mark.parametrize("bf", [False, True], ids=["f32", "bf16x6"])
+def test_gemm_geglu_packed(bf):
     from flowhigh_amd.flow import pack_geglu
+    from flowhigh_amd.packing import pack_gemm_bf_weight
     M, K, inner = 333, 1024, 2730
     a, w, b = rnd(M, K, seed=110), rnd(2 * inner, K, seed=111, scale=K ** -0.5), rnd(2 * inner, seed=112)
     h = F.linear(a, w, b)
@@ -687,7 +699,7 @@ def test_gemm_geglu_packed():
     ref = F.gelu(gate) * val
     wp, bp, ip = pack_geglu(w, b)
     out = torch.full((M, ip), float("nan"), device=DEV)
-    hip.gemm(a.to(DEV), wp.to(DEV), out, M, 2 * ip, K, bias=bp.to(DEV), epilogue=hip.EPI_GEGLU)
+    hip.gemm(a.to(DEV), (pack_gemm_bf_weight(wp) if bf else wp).to(DEV), out, M, 2 * ip, K, bias=bp.to(DEV), epilogue=hip.EPI_GEGLU, bf=bf)
     assert ip == 2752
     assert maxdiff(out[:, :inner], ref) <= 5e-5       # product of two K=1024 fp32 dot products, |h| up to ~5
     assert out[:, inner:].abs().max().item() == 0.0        # zero padding stays exactly zero
@@ -856,13 +868,15 @@ def test_ragged_transformer_ops_equal_per_clip_calls_bitwise():
         assert torch.equal(y1, y[s0:s0 + n])
 
 
+@pytest.mark.parametrize("bf", [False, True], ids=["f32", "bf16x6"])
 @pytest.mark.parametrize("B,n,t", [(1, 25, 0.0), (2, 200, 0.3), (1, 3000, 0.5)])
-def test_flow_forward(B, n, t):
+def test_flow_forward(B, n, t, bf):
+    """The CFM transformer forward against the oracle; bf: its linears in the bf16 x 6 form (the default model's), same bar."""
     from flowhigh_amd.flow import FlowNet
     sd = synth.make_flow_state_dict(seed=0)
     x, cond = rnd(B, n, 256, seed=160), rnd(B, n, 256, seed=161, scale=3.0) - 4.0
     ref = ref_cpu.flow_forward(sd, x, cond, t)
-    net = FlowNet(sd, DEV)
+    net = FlowNet(sd, DEV, bf=bf)
     xd, cd = x.view(B * n, 256).to(DEV), cond.view(B * n, 256).to(DEV)
     net.set_cond(cd, B, n)
     out = torch.empty(B * n, 256, device=DEV)

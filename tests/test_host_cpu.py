@@ -340,11 +340,13 @@ def test_weight_blob_gives_the_packers_tensors_bit_for_bit(tmp_path, cfgname, mo
     info = convert.convert(tmp_path)
     assert Path(info["blob"]).name == weights.BLOB_NAME and info["tensors"] > 100
     sd, cfg_read = read_checkpoints(tmp_path)
-    ref_net, ref_voc = FlowNet(sd, "cpu"), Vocoder(cfg_read, sd, "cpu")
+    from flowhigh_amd.planner import use_gemm_bf16x6
+    gbf = use_gemm_bf16x6(info["form"])
+    ref_net, ref_voc = FlowNet(sd, "cpu", bf=gbf), Vocoder(cfg_read, sd, "cpu")
     srcs = {f: weights.file_digest(tmp_path / f) for f in CKPT_FILES}
     store = weights.WeightStore.open(info["blob"], "cpu", expect_format=weights.format_tag(info["form"]), sources=srcs)
     assert store is not None and store.cfg == cfg_read
-    net, voc = FlowNet(None, "cpu", store=store), Vocoder(store.cfg, None, "cpu", store=store)
+    net, voc = FlowNet(None, "cpu", store=store, bf=gbf), Vocoder(store.cfg, None, "cpu", store=store)
     for a, b in ((ref_net, net), (ref_voc, voc)):
         ta, tb = {}, {}
         _all_tensors({k: v for k, v in vars(a).items() if not k.startswith("_")}, ta)
