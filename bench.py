@@ -79,9 +79,9 @@ def cpu_baseline(sd, cfg, sr_in):
 DTYPE_BY_FORM = {
     "winograd": "f32",
     "direct": "f32",
-    "bf16x6": "f32 in / out / accumulate; the residual-stack convs' products (Winograd wide stages, direct narrow stages) as 6 bf16 "
-              "MFMAs over exact 3-piece splits (conv_form='bf16x6': fp32-grade, dropped terms <= 2^-24 |a b|); everything else fp32 "
-              "arithmetic",
+    "bf16x6": "f32 in / out / accumulate; the products of the residual-stack convs (Winograd wide stages, direct narrow stages) and of "
+              "the transformer's linears as 6 bf16 MFMAs over exact 3-piece splits (conv_form='bf16x6': fp32-grade, dropped terms "
+              "<= 2^-24 |a b|); everything else fp32 arithmetic",
 }
 KERNEL_BY_FAMILY = {
     "wino54": "conv_wino54_kernel (Winograd F(5,4) wide-stage conv, v_mfma_f32_32x32x2_f32)",
