@@ -299,10 +299,10 @@ def plan_switches():
 
 
 def use_gemm_bf16x6(form=None):
-    """The transformer's linears of a bf16 x 6 model run in the bf16 x 6 form too (gemm_bf.hip; flow.FlowNet(bf=)).
-    FH_GEMM_BF16X6=0: on the fp32 matrix instructions (A/B; part of the weight blob's format tag)."""
-    form = resolve_conv_form()[0] if form is None else form
-    return form == "bf16x6" and os.environ.get("FH_GEMM_BF16X6", "1") != "0"
+    """The transformer's linears of a bf16 x 6 model run in the bf16 x 6 form too (gemm_bf.hip; flow.FlowNet(bf=)).  (The A/B
+    against the fp32 GEMM inside a bf16 x 6 model -- 12.89 against 13.02 ms per step, configs[4] 632 against 593 x real time --
+    was run with an environment switch that left with the measurement; conv_form='winograd' is the fp32 path.)"""
+    return (resolve_conv_form()[0] if form is None else form) == "bf16x6"
 
 
 def amp_tile_len(d):
@@ -317,9 +317,9 @@ NARROW_TILE = 256         # fh_narrow_tile_len(): outputs per block and row of t
 
 def use_amp_bf16x6(form=None):
     """Narrow stages of a bf16 x 6 model run the direct bf16 x 6 kernel (narrow_bf.hip) instead of the fp32-MFMA Winograd one
-    (amp_fused.hip).  FH_AMP_BF16X6=0: the Winograd one (A/B; part of the weight blob's format tag)."""
-    form = resolve_conv_form()[0] if form is None else form
-    return form == "bf16x6" and os.environ.get("FH_AMP_BF16X6", "1") != "0"
+    (amp_fused.hip, the narrow-stage kernel of conv_form='winograd').  (A/B inside a bf16 x 6 model: same speed, five times
+    closer to float64 -- profiles/r06_narrow_bf16x6.txt; the switch it was run with left with the measurement.)"""
+    return (resolve_conv_form()[0] if form is None else form) == "bf16x6"
 
 
 def make_amp_seg(x, u, k, center=None, direct=False):

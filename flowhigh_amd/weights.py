@@ -36,8 +36,8 @@ def format_tag(form="winograd"):
     for name in ("packing.py", "planner.py", "vocoder.py", "flow.py"):
         fp.update((pkg / name).read_bytes())
     on = lambda k: os.environ.get(k, "1") != "0"
-    sw = dict(wino54=on("FH_WINO54"), wino54_h16=on("FH_WINO54_H16"), amp=on("FH_AMP"), amp_bf16x6=on("FH_AMP_BF16X6"), gemm_bf16x6=on("FH_GEMM_BF16X6"))
-    return json.dumps(dict(abi=hip.ABI_VERSION, layout=3, form=str(form), switches=sw, packers=fp.hexdigest()), sort_keys=True)
+    sw = dict(wino54=on("FH_WINO54"), wino54_h16=on("FH_WINO54_H16"), amp=on("FH_AMP"))
+    return json.dumps(dict(abi=hip.ABI_VERSION, layout=4, form=str(form), switches=sw, packers=fp.hexdigest()), sort_keys=True)
 
 
 def file_digest(path):

@@ -417,15 +417,9 @@ def test_conv_form_keyword_and_environment(monkeypatch):
             assert wide["w54"] and wide["wcfg"] == (P.WINO_F54 | 1 if f == "bf16x6" else P.WINO_F54 | 0)
     assert Vocoder(cfg, sd, "cpu").form == P.DEFAULT_CONV_FORM and Vocoder(cfg, sd, "cpu").form_auto
     # the bf16 x 6 launch plan: wide stages on the F(5,4) bf16 x 6 kernel (96- / 64-row blocks only), narrow ones on the direct
-    # bf16 x 6 kernel (FH_AMP_BF16X6=0: on the fp32 Winograd one, an A/B switch that is part of the blob's format tag)
+    # bf16 x 6 kernel
     fams = {n for n, _, _ in forms["bf16x6"].plan(1, 100)["conv_launches"]}
     assert fams == {"wino54_bf16x6", "wino43_bf16x6", "narrow_bf16x6", "direct"}
-    monkeypatch.setenv("FH_AMP_BF16X6", "0")
-    tag0 = weights.format_tag("bf16x6")
-    old_narrow = Vocoder(cfg, sd, "cpu", conv_form="bf16x6")
-    monkeypatch.delenv("FH_AMP_BF16X6")
-    assert not old_narrow.amp_direct and tag0 != weights.format_tag("bf16x6")
-    assert {n for n, _, _ in old_narrow.plan(1, 100)["conv_launches"]} == {"wino54_bf16x6", "wino43_bf16x6", "amp", "direct"}
     assert {n for n, _, _ in forms["winograd"].plan(1, 100)["conv_launches"]} == {"wino54", "wino43", "amp", "direct"}
     assert {n for n, _, _ in forms["direct"].plan(1, 100)["conv_launches"]} == {"direct"}
     # a store that holds another form's tensors is refused at construction
