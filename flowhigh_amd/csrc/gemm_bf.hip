@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void gemm_bf_kernel(const float* __restrict__ 
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr int AIT = MT;          // (row, k-octet) items of the A tile per thread: BM x 4 / 256
   constexpr int WIT = 3 * NT;      // 16-byte units of the W tile per thread: NT granules x 768 / 256
-  __shared__ __attribute__((aligned(16))) u32x4 As[3 * 4 * BM];
+  constexpr int AP = BM + 4;       // pitch of a (piece, k-octet) plane of the A tile: a staging pass's 16 lanes are 4 rows x 4 k-octets,
+                                   // 4 mod 16 puts them in 16 different bank groups (pitch BM: 4 to a group)
+  __shared__ __attribute__((aligned(16))) u32x4 As[3 * 4 * AP];
   __shared__ __attribute__((aligned(16))) u32x4 Ws[3 * 4 * BN];
 
   // XCD-aware order: the m-tiles of one n-tile (sharing the W panel) go to one XCD
@@ -104,9 +106,9 @@ __global__ __launch_bounds__(256) void gemm_bf_kernel(const float* __restrict__ 
       const int item = tid + 256 * i, row = item >> 2, ko = item & 3;
       u32x4 h, m, l;
       gb_split8(areg[i][0], areg[i][1], h, m, l);
-      As[(0 * 4 + ko) * BM + row] = h;
-      As[(1 * 4 + ko) * BM + row] = m;
-      As[(2 * 4 + ko) * BM + row] = l;
+      As[(0 * 4 + ko) * AP + row] = h;
+      As[(1 * 4 + ko) * AP + row] = m;
+      As[(2 * 4 + ko) * AP + row] = l;
     }
 #pragma unroll
     for (int i = 0; i < WIT; ++i) {
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_bf_kernel(const float* __restrict__ 
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt][p] = __builtin_bit_cast(gb_bf16x8, As[(p * 4 + 2 * q + lh) * BM + (wm * MT + mt) * 32 + l31]);
+        for (int mt = 0; mt < MT; ++mt) a[mt][p] = __builtin_bit_cast(gb_bf16x8, As[(p * 4 + 2 * q + lh) * AP + (wm * MT + mt) * 32 + l31]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt][p] = __builtin_bit_cast(gb_bf16x8, Ws[(p * 4 + 2 * q + lh) * BN + (wn * NT + nt) * 32 + l31]);
       }
