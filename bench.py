@@ -87,10 +87,10 @@ KERNEL_BY_FAMILY = {
     "wino54": "conv_wino54_kernel (Winograd F(5,4) wide-stage conv, v_mfma_f32_32x32x2_f32)",
     "wino54_bf16x6": "conv_wino54_kernel<BF> (Winograd F(5,4) wide-stage conv, 6 x v_mfma_f32_32x32x16_bf16 per fp32 k-block)",
     "wino43": "conv_wino_kernel (Winograd F(4,3): conv_pre, first two upsamplers, v_mfma_f32_32x32x2_f32)",
-    "wino43_bf16x6": "conv_wino_kernel<BF> (Winograd F(4,3): conv_pre, first two upsamplers, bf16 x 6)",
+    "wino43_bf16x6": "conv_wino_kernel<BF> (Winograd F(4,3): conv_pre, first four upsamplers, bf16 x 6)",
     "amp": "amp_actconv_kernel (narrow-stage Winograd F(5,4) conv, v_mfma_f32_16x16x4_f32)",
     "narrow_bf16x6": "narrow_bf_kernel (narrow-stage direct conv, 6 x v_mfma_f32_16x16x32_bf16 per fp32 k-block)",
-    "direct": "conv_mfma_kernel (direct implicit-GEMM conv: last four upsamplers, v_mfma_f32_32x32x2_f32)",
+    "direct": "conv_mfma_kernel (direct implicit-GEMM conv: the upsamplers below 768 (bf16 x 6 form: 192) input channels, v_mfma_f32_32x32x2_f32)",
 }
 PEAK_BY_FAMILY = {"wino54_bf16x6": 2500.0, "wino43_bf16x6": 2500.0, "narrow_bf16x6": 2500.0}      # dense bf16 MFMA; every other family: the fp32 MFMA peak
 

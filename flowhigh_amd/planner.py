@@ -24,13 +24,21 @@ WINO_NARROW = (96, 48)
 # transposed convs run as Winograd phase groups from this many INPUT channels on (366 -> 207 us for 1536 -> 768
 # channels at B = 1, a wash at 768 -> 384, slower below: one-tap-group blocks pay the per-chunk slab cost every step)
 WINO_UPS_MIN_CIN = 768
+# ... in the bf16 x 6 form from 192 on: the F(4,3) bf16 x 6 phase groups take 157 us against the direct fp32 kernel's 215 at 384 -> 192
+# channels, 97 against 105 at 192 -> 96, 77 against 72 at 96 -> 48 (tools/exp/ups_wino_threshold.py, B = 1, 10 s clip)
+WINO_UPS_MIN_CIN_BF = 192
+
+
+def wino_ups_min_cin(form):
+    return WINO_UPS_MIN_CIN_BF if form == "bf16x6" else WINO_UPS_MIN_CIN
 
 
 # ---- which arithmetic form the vocoder's convs run in (round 6: a constructor keyword of the drop-in class) ---------------------
 #   'winograd'  Winograd F(5,4) / F(4,3) on the fp32 matrix instructions (v_mfma_f32_32x32x2_f32): the default of rounds 3-5
 #   'bf16x6'    the same Winograd contractions on the BF16 matrix cores with every fp32 operand split EXACTLY into three bf16
 #               pieces and six piece-pair MFMAs per k-block (fp32 in / out / accumulate, fp32-grade products: the dropped pairs are
-#               <= 2^-24 |a b|); the narrow stages and the four direct-kernel upsamplers stay on the fp32 matrix instructions
+#               <= 2^-24 |a b|); the narrow stages as a direct conv in the same arithmetic (narrow_bf.hip), the transformer's linears too
+#               (gemm_bf.hip); the last two upsamplers stay on the fp32 matrix instructions
 #   'direct'    no Winograd anywhere: the direct implicit-GEMM kernel (fp32 MFMA), ~20 % closer to a float64 run where the
 #               weights' gain is high (profiles/r05_regime_sweep.txt) and ~2 x slower
 #   'auto'      DEFAULT_CONV_FORM, unless a load-time probe through the loaded weights (Vocoder.probe_conv_form: the default

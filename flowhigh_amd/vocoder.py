@@ -29,11 +29,11 @@ from .packing import (  # noqa: F401
     transposed_conv_extra, transposed_conv_phases, wino_phase_weight)
 from .planner import (  # noqa: F401
     AMP_DIRECT, AMP_MAX_D, WINO54_MIN_C, WINO_BF16X6, WINO_BM, WINO_F54, WINO_MAX_K, WINO_MIN_C, WINO_NARROW, WINO_NOVL,
-    WINO_UPS_MIN_CIN, WINO_XCD_RANGES, _PlanBuilder, _TILE_PREF, _WINO_BF_SPEED, _WINO_COST, _WINO_RUN,
+    WINO_UPS_MIN_CIN, WINO_UPS_MIN_CIN_BF, WINO_XCD_RANGES, _PlanBuilder, _TILE_PREF, _WINO_BF_SPEED, _WINO_COST, _WINO_RUN,
     _WINO_TILES, _WINO_TILES_OFF, _WINO_WIDE_PANEL_MAX, _addr, _choose_wino_cfg, amp_max_center,
     amp_tile_len, amp_tile_list, choose_wino_cfg, make_act_group, make_amp_group, make_amp_seg, make_conv_group,
     make_conv_seg, make_wino_group, make_wino_seg, merge_ragged, pick_tile_cfg, pick_wino54_tile,
-    pick_wino_tile, plan_switches, resolve_conv_form, ups_fused_ok, use_amp, use_amp_bf16x6, use_bf16x6, use_wino, use_wino54, wino_block_mapping,
+    pick_wino_tile, plan_switches, resolve_conv_form, ups_fused_ok, use_amp, use_amp_bf16x6, use_bf16x6, wino_ups_min_cin, use_wino, use_wino54, wino_block_mapping,
     wino_conv_ok, wino_launch_cost, wino_n_tiles, wino_split_k, wino_split_steps, wino_taps)
 from .runtime import (  # noqa: F401
     ACT_BLOCKS_CHOICES, _act_blocks, _act_choice, act1d_grouped, amp_actconv, calibrate_act_occupancy, conv_grouped, ensure_act_blocks,
@@ -207,7 +207,7 @@ class Vocoder:
                 st["up_phases"].append(dict(w=W.dev(f"v.ups.{i}.phase{r_}.w", phase_w), offs=[o for _, o in taps]))
             # the same transposed conv as Winograd phase groups (strided output) where the tile shapes fit
             st["up_wino"] = None
-            if use_wino(max(c, 48), 1, self.form) and c % 16 == 0 and c >= 48 and st["cin"] % 16 == 0 and st["cin"] >= WINO_UPS_MIN_CIN:
+            if use_wino(max(c, 48), 1, self.form) and c % 16 == 0 and c >= 48 and st["cin"] % 16 == 0 and st["cin"] >= wino_ups_min_cin(self.form):
                 st["up_wino"] = []
                 for r_, taps in enumerate(transposed_conv_phases(k, u)):
                     # (taps ordered by input offset: a stride-1 correlation of len(taps) taps, center = - smallest offset)
