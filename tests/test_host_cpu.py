@@ -421,6 +421,12 @@ def test_conv_form_keyword_and_environment(monkeypatch):
     fams = {n for n, _, _ in forms["bf16x6"].plan(1, 100)["conv_launches"]}
     assert fams == {"wino54_bf16x6", "wino43_bf16x6", "narrow_bf16x6", "direct"}
     assert {n for n, _, _ in forms["winograd"].plan(1, 100)["conv_launches"]} == {"wino54", "wino43", "amp", "direct"}
+    # transposed convs as Winograd phase groups: from 768 input channels on in the fp32 form, from 192 in the bf16 x 6 form
+    # (SYNTH-CFG: 1536 -> 768 -> 384 -> 192 -> 96 -> 48 -> 24)
+    count = lambda f, fam: sum(n == fam for n, _, _ in forms[f].plan(1, 100)["conv_launches"])
+    assert (P.wino_ups_min_cin("winograd"), P.wino_ups_min_cin("bf16x6")) == (768, 192)
+    assert (count("winograd", "wino43"), count("winograd", "direct")) == (3, 4)          # conv_pre + 2 upsamplers | 4 upsamplers
+    assert (count("bf16x6", "wino43_bf16x6"), count("bf16x6", "direct")) == (5, 2)
     assert {n for n, _, _ in forms["direct"].plan(1, 100)["conv_launches"]} == {"direct"}
     # a store that holds another form's tensors is refused at construction
     st = weights.WeightStore("cpu")
