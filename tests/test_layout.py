@@ -40,6 +40,13 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.fh_conv_wino54_f32(16, 1, 1, 96, (1 << 24) - 4096, 1, 0, 1, 0) == -1
     assert b"fh_conv_wino54_f32" in lib.fh_last_error() and b"rows of" in lib.fh_last_error()
     assert lib.fh_conv_wino54_f32(16, 1, 1, 100, 1000, 1, 0, 1, 0) == -1          # cout_pad not a multiple of the 96-row tile
+    # the two bf16 x 6 entries of ABI 5: channel count / dilation / flags of the narrow-stage conv, K and alignment of the GEMM
+    assert lib.fh_narrow_tile_len() == 256
+    assert lib.fh_narrow_conv_bf16x6_f32(16, 1, 16, 1, 50, 1, 1, 0) == -1 and b"channels" in lib.fh_last_error()
+    assert lib.fh_narrow_conv_bf16x6_f32(16, 1, 16, 1, 24, 7, 1, 0) == -1 and b"dilation" in lib.fh_last_error()
+    assert lib.fh_narrow_conv_bf16x6_f32(16, 1, 16, 1, 24, 1, 2, 0) == -1 and b"flags" in lib.fh_last_error()
+    assert lib.fh_gemm_bf16x6_f32(16, 32, 16, 0, 0, 0, 16, 64, 8, 64, 40, 1.0, 0, 0) == -1 and b"multiple of 32" in lib.fh_last_error()
+    assert lib.fh_gemm_bf16x6_f32(16, 30, 16, 0, 0, 0, 16, 64, 8, 64, 64, 1.0, 0, 0) == -1 and b"aligned" in lib.fh_last_error()
 
 
 def test_product_never_imports_oracle():
