@@ -65,6 +65,10 @@ class FlowNet:
         # bf: the linears run in the bf16 x 6 form (gemm_bf.hip: six bf16 MFMAs per product over exact three-piece splits,
         # fp32-grade; the model's conv_form = 'bf16x6'): their weights are stored split (6 bytes per weight)
         self.bf = bool(bf)
+        if getattr(W, "form", None) is not None and (W.form == "bf16x6") != self.bf:
+            # (a blob holds the linears in ONE form: asking it for the other would fail on the first missing key)
+            raise ValueError(f"the weight blob was packed for conv_form={W.form!r}: its linears are "
+                             f"{'split into bf16 pieces' if W.form == 'bf16x6' else 'fp32'}, this model asks for the other form")
         if self.bf:
             from .packing import pack_gemm_bf_weight
             dev_w = lambda key, make: W.dev(key + ".bf3", lambda: pack_gemm_bf_weight(make()))

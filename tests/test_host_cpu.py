@@ -433,6 +433,9 @@ def test_conv_form_keyword_and_environment(monkeypatch):
     st.form = "winograd"
     with pytest.raises(ValueError, match="packed for"):
         Vocoder(cfg, sd, "cpu", conv_form="bf16x6", store=st)
+    from flowhigh_amd.flow import FlowNet
+    with pytest.raises(ValueError, match="packed for"):                  # ... and by the transformer, whose linears have two forms too
+        FlowNet(synth.make_flow_state_dict(seed=0), "cpu", store=st, bf=True)
     assert weights.format_tag("bf16x6") != weights.format_tag("winograd") != weights.format_tag("direct")
     monkeypatch.setenv("FH_AMP", "1")
     tag = weights.format_tag("bf16x6")
